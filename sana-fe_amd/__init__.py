@@ -1,0 +1,8 @@
+"""sanafe_amd -- MI355X-native drop-in for SANA-FE's per-timestep simulation loop.
+
+The directory is called ``sana-fe_amd`` (not importable by name); load it with
+``_sanafe_pkg.load()`` at the repo root, which registers it as ``sanafe_amd``.
+"""
+from .description import (Architecture, Network, NeuronGroup, Neuron, Tile, Core, HardwareMappingError,  # noqa: F401
+                          to_desc)
+from .yaml_io import load_arch, load_net  # noqa: F401
