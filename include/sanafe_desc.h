@@ -80,15 +80,22 @@ typedef struct sanafe_desc
     const int32_t *core_buffer_pos;  /* [n_cores] SANAFE_BUF_* */
     const int64_t *core_max_neurons; /* [n_cores] */
     const uint8_t *core_log_energy;  /* [n_cores] */
-    const int32_t *core_axon_in_ptr; /* [n_cores+1] */
+    const int32_t *core_template;    /* [n_cores] index of the core's unit template */
+
+    /* ---- core templates: the axon units and pipeline units of a core.  Cores
+     * replicated from one description entry (`name[a..b]`) share a template;
+     * every core still gets its OWN unit instances, created in template order
+     * (src/chip.cpp:70-93). ---- */
+    int32_t n_templates;
+    const int32_t *tmpl_axon_in_ptr; /* [n_templates+1] */
     const double *axon_in_energy;    /* energy_message_in  */
     const double *axon_in_latency;   /* latency_message_in */
-    const int32_t *core_axon_out_ptr;/* [n_cores+1] */
+    const int32_t *tmpl_axon_out_ptr;/* [n_templates+1] */
     const double *axon_out_energy;   /* energy_message_out  */
     const double *axon_out_latency;  /* latency_message_out */
-    const int32_t *core_unit_ptr;    /* [n_cores+1] range into unit_* */
+    const int32_t *tmpl_unit_ptr;    /* [n_templates+1] range into unit_* */
 
-    /* ---- pipeline units, creation order inside each core ---- */
+    /* ---- pipeline units of each template, creation order ---- */
     int32_t n_units;
     const int32_t *unit_name;        /* [n_units] */
     const int32_t *unit_model;       /* [n_units] model name (string id) */

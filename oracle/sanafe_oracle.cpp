@@ -699,6 +699,8 @@ struct Core
     size_t max_neurons{1024};
     double energy{0.0}, next_delay{0.0};
     size_t id{0}, offset{0}, tile{0};
+    int tmpl{0};               // core template (include/sanafe_desc.h)
+    unsigned input_seed_base{0}; // InputModel instances created before this core's units
 };
 
 struct Tile
@@ -737,6 +739,7 @@ struct oracle_chip
     size_t mapped_tiles{0}, mapped_cores{0};
     long total_timesteps{0}, total_messages_sent{0};
     unsigned input_instances{0};
+    const sanafe_desc *desc{nullptr}; // borrowed: the caller keeps the desc alive with the chip
     Timestep last;
 
     const std::string &str(int32_t id) const
@@ -764,13 +767,13 @@ struct oracle_chip
     }
 
     // src/models.cpp:933-967 (+ the HH plugin by model name)
-    std::unique_ptr<Unit> make_unit(const std::string &model)
+    std::unique_ptr<Unit> make_unit(const std::string &model, unsigned input_seed = 0)
     {
         if (model == "current_based") return std::make_unique<CurrentBasedSynapse>();
         if (model == "accumulator") return std::make_unique<Accumulator>();
         if (model == "accumulator_with_delay") return std::make_unique<AccumulatorWithDelay>();
         if (model == "taps") return std::make_unique<MultiTap>();
-        if (model == "input") return std::make_unique<InputModel>(++input_instances);
+        if (model == "input") return std::make_unique<InputModel>(input_seed ? input_seed : ++input_instances);
         if (model == "leaky_integrate_fire") return std::make_unique<LoihiLif>();
         if (model == "truenorth") return std::make_unique<TrueNorth>();
         if (model == "hodgkin_huxley") return std::make_unique<HodgkinHuxley>();
@@ -780,6 +783,7 @@ struct oracle_chip
     // SpikingChip::SpikingChip, src/chip.cpp:61-104; Core::create_pipeline_unit src/core.cpp:196-231
     void build_arch(const sanafe_desc &d)
     {
+        desc = &d;
         noc_w = d.noc_width;
         noc_h = d.noc_height;
         noc_buf = d.noc_buffer_size;
@@ -808,30 +812,25 @@ struct oracle_chip
             core.buffer_pos = d.core_buffer_pos[c];
             core.max_neurons = d.core_max_neurons[c];
             core.buffer.resize(core.max_neurons);
-            for (int i = d.core_axon_in_ptr[c]; i < d.core_axon_in_ptr[c + 1]; i++)
+            core.tmpl = d.core_template[c];
+            const int tm = core.tmpl;
+            for (int i = d.tmpl_axon_in_ptr[tm]; i < d.tmpl_axon_in_ptr[tm + 1]; i++)
             {
                 AxonInUnit u;
                 u.energy_msg = d.axon_in_energy[i];
                 u.latency_msg = d.axon_in_latency[i];
                 core.axon_in_hw.push_back(u);
             }
-            for (int u = d.core_unit_ptr[c]; u < d.core_unit_ptr[c + 1]; u++)
-            {
-                std::unique_ptr<Unit> unit = make_unit(str(d.unit_model[u]));
-                unit->name = str(d.unit_name[u]);
-                unit->model = str(d.unit_model[u]);
-                unit->log_energy = d.unit_flags[u] & SANAFE_UNIT_LOG_ENERGY;
-                unit->log_latency = d.unit_flags[u] & SANAFE_UNIT_LOG_LATENCY;
-                unit->update_every_timestep = d.unit_flags[u] & SANAFE_UNIT_UPDATE_EVERY_TIMESTEP;
-                unit->set_attributes_hw(read_attrs(*this, d.unit_attrs, d.unit_attr_ptr[u], d.unit_attr_ptr[u + 1]));
-                const bool s = d.unit_implements[u] & SANAFE_IMPL_SYNAPSE;
-                const bool de = d.unit_implements[u] & SANAFE_IMPL_DENDRITE;
-                const bool so = d.unit_implements[u] & SANAFE_IMPL_SOMA;
-                if (s != unit->impl_syn || de != unit->impl_dend || so != unit->impl_soma)
-                    throw std::runtime_error("Unit '" + unit->name + "' is listed in a section it does not implement");
-                core.pipeline_hw.push_back(std::move(unit));
-            }
-            for (int i = d.core_axon_out_ptr[c]; i < d.core_axon_out_ptr[c + 1]; i++)
+            // The reference instantiates every unit of every core up front
+            // (src/chip.cpp:83-87).  A loihi_large chip has 4096 x 1031 units, so the
+            // oracle instantiates a unit on first use instead; the only creation-order
+            // side effect, InputModel's seed counter (src/models.hpp:347, 366), is
+            // reproduced arithmetically through input_seed_base.
+            core.input_seed_base = input_instances;
+            core.pipeline_hw.resize(d.tmpl_unit_ptr[tm + 1] - d.tmpl_unit_ptr[tm]);
+            for (int u = d.tmpl_unit_ptr[tm]; u < d.tmpl_unit_ptr[tm + 1]; u++)
+                if (str(d.unit_model[u]) == "input") ++input_instances;
+            for (int i = d.tmpl_axon_out_ptr[tm]; i < d.tmpl_axon_out_ptr[tm + 1]; i++)
             {
                 AxonOutUnit u;
                 u.energy_access = d.axon_out_energy[i];
@@ -842,13 +841,47 @@ struct oracle_chip
         for (const Tile &t : tiles) max_cores_per_tile = std::max(max_cores_per_tile, t.cores.size());
     }
 
-    // Core::get_hw, src/core.cpp:61-97
-    static Unit *get_hw(Core &core, const std::string &name, bool syn, bool dend, bool soma)
+    // Core::create_pipeline_unit, src/core.cpp:196-231 (performed on first use, see build_arch)
+    Unit *instantiate(Core &core, int slot)
     {
-        for (auto &hw : core.pipeline_hw)
+        if (core.pipeline_hw[slot]) return core.pipeline_hw[slot].get();
+        const sanafe_desc &d = *desc;
+        const int u = d.tmpl_unit_ptr[core.tmpl] + slot;
+        unsigned seed = 0;
+        if (str(d.unit_model[u]) == "input")
         {
-            if ((syn && !hw->impl_syn) || (dend && !hw->impl_dend) || (soma && !hw->impl_soma)) continue;
-            if (name.empty() || name == hw->name) return hw.get();
+            seed = core.input_seed_base + 1;
+            for (int k = d.tmpl_unit_ptr[core.tmpl]; k < u; k++)
+                if (str(d.unit_model[k]) == "input") ++seed;
+        }
+        std::unique_ptr<Unit> unit = make_unit(str(d.unit_model[u]), seed);
+        unit->name = str(d.unit_name[u]);
+        unit->model = str(d.unit_model[u]);
+        unit->log_energy = d.unit_flags[u] & SANAFE_UNIT_LOG_ENERGY;
+        unit->log_latency = d.unit_flags[u] & SANAFE_UNIT_LOG_LATENCY;
+        unit->update_every_timestep = d.unit_flags[u] & SANAFE_UNIT_UPDATE_EVERY_TIMESTEP;
+        unit->set_attributes_hw(read_attrs(*this, d.unit_attrs, d.unit_attr_ptr[u], d.unit_attr_ptr[u + 1]));
+        const bool sy = d.unit_implements[u] & SANAFE_IMPL_SYNAPSE;
+        const bool de = d.unit_implements[u] & SANAFE_IMPL_DENDRITE;
+        const bool so = d.unit_implements[u] & SANAFE_IMPL_SOMA;
+        if (sy != unit->impl_syn || de != unit->impl_dend || so != unit->impl_soma)
+            throw std::runtime_error("Unit '" + unit->name + "' is listed in a section it does not implement");
+        core.pipeline_hw[slot] = std::move(unit);
+        return core.pipeline_hw[slot].get();
+    }
+
+    // Core::get_hw, src/core.cpp:61-97
+    Unit *get_hw(Core &core, const std::string &name, bool syn, bool dend, bool soma)
+    {
+        const sanafe_desc &d = *desc;
+        const int b = d.tmpl_unit_ptr[core.tmpl], e = d.tmpl_unit_ptr[core.tmpl + 1];
+        for (int u = b; u < e; u++)
+        {
+            const int impl = d.unit_implements[u];
+            if ((syn && !(impl & SANAFE_IMPL_SYNAPSE)) || (dend && !(impl & SANAFE_IMPL_DENDRITE)) ||
+                    (soma && !(impl & SANAFE_IMPL_SOMA)))
+                continue;
+            if (name.empty() || name == str(d.unit_name[u])) return instantiate(core, u - b);
         }
         throw std::runtime_error("Could not find h/w (with name:" + name + ")");
     }
@@ -1055,7 +1088,7 @@ struct oracle_chip
         {
             c.in_use.clear();
             for (auto &hw : c.pipeline_hw)
-                if (hw->is_used) c.in_use.push_back(hw.get());
+                if (hw && hw->is_used) c.in_use.push_back(hw.get());
         }
     }
 
@@ -1693,7 +1726,8 @@ extern "C" void oracle_reset(oracle_chip *chip) // src/chip.cpp:576-600
     for (Core &c : chip->cores)
     {
         std::fill(c.buffer.begin(), c.buffer.end(), Result{});
-        for (auto &hw : c.pipeline_hw) hw->reset();
+        for (auto &hw : c.pipeline_hw)
+            if (hw) hw->reset();
         for (MappedNeuron &n : c.neurons) n.status = UNSET;
     }
 }
@@ -1721,3 +1755,113 @@ extern "C" int oracle_set_neuron_attr(oracle_chip *chip, int64_t neuron, const c
 }
 
 extern "C" int64_t oracle_mapped_tiles(const oracle_chip *chip) { return chip->mapped_tiles; }
+
+// ---------------------------------------------------------------------------
+// Unit-level hooks: drive one restated model directly, with the same call
+// shapes as oracle/ref_models_driver.cpp drives the reference's model, so the
+// tests can compare them call by call.
+// ---------------------------------------------------------------------------
+struct oracle_unit
+{
+    std::unique_ptr<Unit> hw;
+};
+struct oracle_unit_result
+{
+    int has_current;
+    double current;
+    int status;
+    int has_energy;
+    double energy;
+    int has_latency;
+    double latency;
+};
+static void fill_result(oracle_unit_result *out, const Result &r)
+{
+    out->has_current = r.current.has;
+    out->current = r.current.value_or(0.0);
+    out->status = r.status;
+    out->has_energy = r.energy.has;
+    out->energy = r.energy.value_or(0.0);
+    out->has_latency = r.latency.has;
+    out->latency = r.latency.value_or(0.0);
+}
+static Attr mk_attr(const char *key, int type, double num, const char *str, const double *list, long n)
+{
+    Attr a;
+    a.key = key;
+    a.type = type;
+    a.num = num;
+    if (str) a.str = str;
+    if (list) a.list.assign(list, list + n);
+    return a;
+}
+#define OGUARD(body)                        \
+    try                                     \
+    {                                       \
+        body;                               \
+        return 0;                           \
+    }                                       \
+    catch (const std::exception &e)         \
+    {                                       \
+        set_err(err, errlen, e.what());     \
+        return -1;                          \
+    }
+static unsigned g_unit_input_instances = 0;
+extern "C" oracle_unit *oracle_unit_create(const char *model, char *err, int errlen)
+{
+    try
+    {
+        oracle_chip tmp;
+        tmp.input_instances = g_unit_input_instances;
+        auto u = std::make_unique<oracle_unit>();
+        u->hw = tmp.make_unit(model);
+        g_unit_input_instances = tmp.input_instances;
+        return u.release();
+    }
+    catch (const std::exception &e)
+    {
+        set_err(err, errlen, e.what());
+        return nullptr;
+    }
+}
+extern "C" void oracle_unit_destroy(oracle_unit *u) { delete u; }
+extern "C" int oracle_unit_set_attr_hw(oracle_unit *u, const char *key, int type, double num, const char *str,
+        const double *list, long n, char *err, int errlen)
+{
+    OGUARD(u->hw->set_attr_hw(mk_attr(key, type, num, str, list, n)))
+}
+extern "C" int oracle_unit_set_attr_neuron(oracle_unit *u, long addr, const char *key, int type, double num,
+        const char *str, const double *list, long n, char *err, int errlen)
+{
+    OGUARD(u->hw->set_attr_neuron(addr, mk_attr(key, type, num, str, list, n)))
+}
+extern "C" int oracle_unit_set_attr_edge(oracle_unit *u, long addr, const char *key, int type, double num,
+        const char *str, const double *list, long n, char *err, int errlen)
+{
+    OGUARD(u->hw->set_attr_edge(addr, mk_attr(key, type, num, str, list, n)))
+}
+extern "C" int oracle_unit_update_syn(oracle_unit *u, long addr, int read, long t, oracle_unit_result *out, char *err,
+        int errlen)
+{
+    OGUARD(fill_result(out, u->hw->update_syn(addr, read != 0, t)))
+}
+extern "C" int oracle_unit_update_dend(oracle_unit *u, long naddr, int has_cur, double cur, int has_syn, long syn,
+        long t, oracle_unit_result *out, char *err, int errlen)
+{
+    OGUARD(fill_result(out, u->hw->update_dend(naddr, has_cur ? Opt(cur) : Opt(), has_syn != 0, syn, t)))
+}
+extern "C" int oracle_unit_update_soma(oracle_unit *u, long naddr, int has_cur, double cur, long t,
+        oracle_unit_result *out, char *err, int errlen)
+{
+    OGUARD(fill_result(out, u->hw->update_soma(naddr, has_cur ? Opt(cur) : Opt(), t)))
+}
+extern "C" double oracle_unit_get_potential(oracle_unit *u, long addr) { return u->hw->get_potential(addr); }
+extern "C" int oracle_unit_get_trace(oracle_unit *u, long addr, const char *name, double *out)
+{
+    auto tr = u->hw->get_traces(addr);
+    auto it = tr.find(name);
+    if (it == tr.end()) return 0;
+    *out = it->second;
+    return 1;
+}
+extern "C" void oracle_unit_reset(oracle_unit *u) { u->hw->reset(); }

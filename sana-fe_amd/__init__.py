@@ -6,3 +6,4 @@ The directory is called ``sana-fe_amd`` (not importable by name); load it with
 from .description import (Architecture, Network, NeuronGroup, Neuron, Tile, Core, HardwareMappingError,  # noqa: F401
                           to_desc)
 from .yaml_io import load_arch, load_net  # noqa: F401
+from . import description, presets, yaml_io  # noqa: F401

@@ -59,11 +59,13 @@ class Desc(C.Structure):
         ("n_cores", C.c_int32), ("core_name", C.POINTER(C.c_int32)), ("core_tile", C.POINTER(C.c_int32)),
         ("core_buffer_pos", C.POINTER(C.c_int32)), ("core_max_neurons", C.POINTER(C.c_int64)),
         ("core_log_energy", C.POINTER(C.c_uint8)),
-        ("core_axon_in_ptr", C.POINTER(C.c_int32)), ("axon_in_energy", C.POINTER(C.c_double)),
+        ("core_template", C.POINTER(C.c_int32)),
+        ("n_templates", C.c_int32),
+        ("tmpl_axon_in_ptr", C.POINTER(C.c_int32)), ("axon_in_energy", C.POINTER(C.c_double)),
         ("axon_in_latency", C.POINTER(C.c_double)),
-        ("core_axon_out_ptr", C.POINTER(C.c_int32)), ("axon_out_energy", C.POINTER(C.c_double)),
+        ("tmpl_axon_out_ptr", C.POINTER(C.c_int32)), ("axon_out_energy", C.POINTER(C.c_double)),
         ("axon_out_latency", C.POINTER(C.c_double)),
-        ("core_unit_ptr", C.POINTER(C.c_int32)),
+        ("tmpl_unit_ptr", C.POINTER(C.c_int32)),
         ("n_units", C.c_int32), ("unit_name", C.POINTER(C.c_int32)), ("unit_model", C.POINTER(C.c_int32)),
         ("unit_plugin", C.POINTER(C.c_int32)), ("unit_implements", C.POINTER(C.c_uint8)),
         ("unit_flags", C.POINTER(C.c_uint8)), ("unit_attr_ptr", C.POINTER(C.c_int64)), ("unit_attrs", AttrTable),
@@ -195,14 +197,35 @@ class PipelineUnit:
         self.log_energy, self.log_latency, self.update_every_timestep = log_energy, log_latency, update_every_timestep
 
 
+class CoreTemplate:
+    """The axon units and pipeline units of a core.  Cores replicated from one
+    description entry share one template object (each core still gets its own
+    unit instances when a chip is built)."""
+
+    def __init__(self):
+        self.axon_in, self.units, self.axon_out = [], [], []
+
+
 class Core:
     """CoreConfiguration (src/arch.hpp:154-169)."""
 
     def __init__(self, name, parent_tile_id, offset_within_tile, core_id, buffer_position=BUF_BEFORE_SOMA,
-                 max_neurons_supported=1024, log_energy=False):
+                 max_neurons_supported=1024, log_energy=False, template=None):
         self.name, self.parent_tile_id, self.offset_within_tile, self.id = name, parent_tile_id, offset_within_tile, core_id
         self.buffer_position, self.max_neurons_supported, self.log_energy = buffer_position, max_neurons_supported, log_energy
-        self.axon_in, self.units, self.axon_out = [], [], []
+        self.template = template if template is not None else CoreTemplate()
+
+    @property
+    def axon_in(self):
+        return self.template.axon_in
+
+    @property
+    def units(self):
+        return self.template.units
+
+    @property
+    def axon_out(self):
+        return self.template.axon_out
 
     def create_axon_in(self, name, energy_message_in=0.0, latency_message_in=0.0):
         self.axon_in.append((name, float(energy_message_in), float(latency_message_in)))
@@ -270,11 +293,12 @@ class Architecture:
         return t
 
     def create_core(self, name, parent_tile_id, buffer_position=BUF_BEFORE_SOMA, buffer_inside_unit=False,
-                    max_neurons_supported=1024, log_energy=False):
+                    max_neurons_supported=1024, log_energy=False, template=None):
         if isinstance(buffer_position, str):
             buffer_position = parse_buffer_position(buffer_position, buffer_inside_unit)
         tile = self.tiles[parent_tile_id]
-        core = Core(name, parent_tile_id, len(tile.cores), len(self._cores), buffer_position, max_neurons_supported, log_energy)
+        core = Core(name, parent_tile_id, len(tile.cores), len(self._cores), buffer_position, max_neurons_supported,
+                    log_energy, template)
         tile.cores.append(core)
         self._cores.append(core)
         return core
@@ -678,33 +702,42 @@ def to_desc(arch: Architecture, net: Network) -> BuiltDesc:
     ain_ptr, ain_e, ain_l, aout_ptr, aout_e, aout_l, unit_ptr = [0], [], [], [0], [], [], [0]
     u_name, u_model, u_plugin, u_impl, u_flags, u_attr_ptr = [], [], [], [], [], [0]
     rows = _AttrRows(s)
+    tmpl_index = {}
+    core_tmpl = []
     for c in cores:
-        for (_, e, l) in c.axon_in:
-            ain_e.append(e)
-            ain_l.append(l)
-        ain_ptr.append(len(ain_e))
-        for (_, e, l) in c.axon_out:
-            aout_e.append(e)
-            aout_l.append(l)
-        aout_ptr.append(len(aout_e))
-        for u in c.units:
-            u_name.append(s(u.name))
-            u_model.append(s(u.model))
-            u_plugin.append(s(u.plugin) if u.plugin else -1)
-            u_impl.append(u.implements)
-            u_flags.append((UNIT_LOG_ENERGY if u.log_energy else 0) | (UNIT_LOG_LATENCY if u.log_latency else 0)
-                           | (UNIT_UPDATE_EVERY_TIMESTEP if u.update_every_timestep else 0))
-            for k in sorted(u.attributes):
-                rows.add(k, u.attributes[k])
-            u_attr_ptr.append(len(rows))
-        unit_ptr.append(len(u_name))
-    d.core_axon_in_ptr = _ptr(arr(ain_ptr, np.int32))
+        tid = tmpl_index.get(id(c.template))
+        if tid is None:
+            tid = len(tmpl_index)
+            tmpl_index[id(c.template)] = tid
+            for (_, e, l) in c.axon_in:
+                ain_e.append(e)
+                ain_l.append(l)
+            ain_ptr.append(len(ain_e))
+            for (_, e, l) in c.axon_out:
+                aout_e.append(e)
+                aout_l.append(l)
+            aout_ptr.append(len(aout_e))
+            for u in c.units:
+                u_name.append(s(u.name))
+                u_model.append(s(u.model))
+                u_plugin.append(s(u.plugin) if u.plugin else -1)
+                u_impl.append(u.implements)
+                u_flags.append((UNIT_LOG_ENERGY if u.log_energy else 0) | (UNIT_LOG_LATENCY if u.log_latency else 0)
+                               | (UNIT_UPDATE_EVERY_TIMESTEP if u.update_every_timestep else 0))
+                for k in sorted(u.attributes):
+                    rows.add(k, u.attributes[k])
+                u_attr_ptr.append(len(rows))
+            unit_ptr.append(len(u_name))
+        core_tmpl.append(tid)
+    d.core_template = _ptr(arr(core_tmpl, np.int32))
+    d.n_templates = len(tmpl_index)
+    d.tmpl_axon_in_ptr = _ptr(arr(ain_ptr, np.int32))
     d.axon_in_energy = _ptr(arr(ain_e, np.float64))
     d.axon_in_latency = _ptr(arr(ain_l, np.float64))
-    d.core_axon_out_ptr = _ptr(arr(aout_ptr, np.int32))
+    d.tmpl_axon_out_ptr = _ptr(arr(aout_ptr, np.int32))
     d.axon_out_energy = _ptr(arr(aout_e, np.float64))
     d.axon_out_latency = _ptr(arr(aout_l, np.float64))
-    d.core_unit_ptr = _ptr(arr(unit_ptr, np.int32))
+    d.tmpl_unit_ptr = _ptr(arr(unit_ptr, np.int32))
     d.n_units = len(u_name)
     d.unit_name = _ptr(arr(u_name, np.int32))
     d.unit_model = _ptr(arr(u_model, np.int32))
@@ -767,3 +800,58 @@ def to_desc(arch: Architecture, net: Network) -> BuiltDesc:
     d.n_strings = len(enc)
     d.strings = C.cast(sarr, C.POINTER(C.c_char_p))
     return BuiltDesc(d, keep, arch, net)
+
+
+def describe(built: BuiltDesc):
+    """Expand a built desc into plain Python data with names resolved (for comparisons in tests)."""
+    d = built.desc
+    strings = [d.strings[i].decode() for i in range(d.n_strings)]
+
+    def name(i):
+        return "" if i < 0 else strings[i]
+
+    def attrs(table, lo, hi):
+        out = {}
+        for i in range(lo, hi):
+            t = table.type[i]
+            if t == ATTR_STRING:
+                v = name(table.str[i])
+            elif t == ATTR_LIST:
+                v = [table.list_num[j] for j in range(table.list_ptr[i], table.list_ptr[i + 1])]
+            else:
+                v = table.num[i]
+            out[name(table.key[i])] = (int(t), v, int(table.fwd[i]))
+        return out
+
+    tiles = [dict(name=name(d.tile_name[t]), e=[d.tile_hop_energy[4 * t + k] for k in range(4)],
+                  l=[d.tile_hop_latency[4 * t + k] for k in range(4)], log=int(d.tile_log_energy[t]))
+             for t in range(d.n_tiles)]
+    cores = []
+    for c in range(d.n_cores):
+        units = []
+        tm = d.core_template[c]
+        for u in range(d.tmpl_unit_ptr[tm], d.tmpl_unit_ptr[tm + 1]):
+            units.append(dict(name=name(d.unit_name[u]), model=name(d.unit_model[u]), plugin=name(d.unit_plugin[u]),
+                              impl=int(d.unit_implements[u]), flags=int(d.unit_flags[u]),
+                              attrs=attrs(d.unit_attrs, d.unit_attr_ptr[u], d.unit_attr_ptr[u + 1])))
+        cores.append(dict(name=name(d.core_name[c]), tile=int(d.core_tile[c]), buf=int(d.core_buffer_pos[c]),
+                          max_neurons=int(d.core_max_neurons[c]), log=int(d.core_log_energy[c]),
+                          axon_in=[(d.axon_in_energy[i], d.axon_in_latency[i])
+                                   for i in range(d.tmpl_axon_in_ptr[tm], d.tmpl_axon_in_ptr[tm + 1])],
+                          axon_out=[(d.axon_out_energy[i], d.axon_out_latency[i])
+                                    for i in range(d.tmpl_axon_out_ptr[tm], d.tmpl_axon_out_ptr[tm + 1])],
+                          units=units))
+    groups = []
+    for g in range(d.n_groups):
+        ns = []
+        for n in range(d.group_ptr[g], d.group_ptr[g + 1]):
+            ns.append(dict(core=int(d.neuron_core[n]), order=int(d.neuron_map_order[n]), soma=name(d.neuron_soma_hw[n]),
+                           dendrite=name(d.neuron_dendrite_hw[n]), synapse=name(d.neuron_synapse_hw[n]),
+                           log_spikes=int(d.neuron_log_spikes[n]), log_potential=int(d.neuron_log_potential[n]),
+                           attrs=attrs(d.neuron_attrs, d.neuron_attr_ptr[n], d.neuron_attr_ptr[n + 1])))
+        groups.append(dict(name=name(d.group_name[g]), neurons=ns))
+    edges = [(int(d.edge_src[e]), int(d.edge_dst[e]), name(d.edge_synapse_hw[e]), d.edge_weight[e],
+              int(d.edge_delay[e]) if d.edge_delay else -1) for e in range(d.n_edges)]
+    return dict(noc=(d.noc_width, d.noc_height, d.noc_buffer_size),
+                sync={int(d.sync_key[i]): d.sync_val[i] for i in range(d.n_sync)},
+                tiles=tiles, cores=cores, groups=groups, edges=edges)

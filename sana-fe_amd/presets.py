@@ -1,0 +1,137 @@
+"""Programmatic architecture presets.
+
+``/root/reference`` does not travel to the GPU box, so the architectures the
+benchmark configs name are restated here through the description API.  The
+numeric constants are the ones the reference's architecture descriptions give
+(cited per preset); tests/test_presets.py checks each preset against the
+reference YAML whenever the reference is present.
+"""
+from . import description as D
+
+# arch/loihi.yaml:19-27, arch/loihi_large.yaml:12-20 -- Loihi hop costs (Davies et al. 2018)
+_LOIHI_TILE = dict(energy_north_hop=4.2e-12, latency_north_hop=6.5e-9, energy_east_hop=3.0e-12, latency_east_hop=4.1e-9,
+                   energy_south_hop=4.2e-12, latency_south_hop=6.5e-9, energy_west_hop=3.0e-12, latency_west_hop=4.1e-9)
+_LOIHI_SYNC = {1: 0.6e-6, 2: 1.0e-6, 4: 1.4e-6, 29: 1.8e-6}  # arch/loihi.yaml:16
+
+
+def _f(**kw):
+    return {k: (D.ATTR_DOUBLE, float(v), None, None) for k, v in kw.items()}
+
+
+def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared, n_inputs=1024):
+    core = arch.create_core("loihi_core[%d]" % idx, tile_id, buffer_position, buffer_inside_unit, 1024,
+                            template=shared.get("t"))
+    if "t" in shared:
+        return core
+    shared["t"] = core.template
+    core.create_axon_in("loihi_in", 0.0e-12, 16.0e-9)
+    # unit sections are always visited synapse, dendrite, soma (src/yaml_arch.cpp:260-266);
+    # inside a section the file order is kept, which differs between loihi.yaml and loihi_large.yaml
+    core.create_synapse("loihi_dense_synapse", "current_based", _f(energy_process_spike=35.5e-12, latency_process_spike=3.8e-9))
+    core.create_synapse("loihi_sparse_synapse", "current_based", _f(energy_process_spike=33.6e-12, latency_process_spike=4.7e-9))
+    core.create_synapse("loihi_conv_synapse", "current_based", _f(latency_process_spike=3.1e-9, energy_process_spike=24.0e-12))
+    core.create_dendrite("loihi_dendrites", "accumulator", _f(energy_update=0.0, latency_update=0.0))
+    core.create_dendrite("loihi_dendrites_delay", "accumulator_with_delay", _f(energy_update=0.0, latency_update=0.0))
+    core.create_soma("loihi_lif", "leaky_integrate_fire",
+                     _f(energy_access_neuron=51.2e-12, latency_access_neuron=6.0e-9, energy_update_neuron=21.6e-12,
+                        latency_update_neuron=3.7e-9, energy_spike_out=69.3e-12, latency_spike_out=30.0e-9))
+    zero = _f(energy_access_neuron=0.0, latency_access_neuron=0.0, energy_update_neuron=0.0, latency_update_neuron=0.0,
+              energy_spike_out=0.0, latency_spike_out=0.0)
+    for i in range(n_inputs):
+        core.create_soma("loihi_inputs[%d]" % i, "input", zero)
+    core.create_axon_out("loihi_out", 111.0e-12, 5.1e-9)
+    return core
+
+
+def loihi(n_inputs=1024):
+    """arch/loihi.yaml: 8x4 mesh, 32 tiles x 4 cores, buffer before soma."""
+    arch = D.Architecture("loihi_chip", 8, 4, 16, _LOIHI_SYNC)
+    shared = {}
+    for t in range(32):
+        tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
+        for c in range(4):
+            _loihi_core(arch, tile.id, c, "soma", False, shared, n_inputs)
+    return arch
+
+
+def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128):
+    """arch/loihi_large.yaml: 256x128 mesh, 1024 tiles x 4 cores, buffer inside the dendrite unit."""
+    arch = D.Architecture("loihi_chip", width, height, 16, _LOIHI_SYNC)
+    shared = {}
+    for t in range(n_tiles):
+        tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
+        for c in range(4):
+            _loihi_core(arch, tile.id, c, "dendrite", True, shared, n_inputs)
+    return arch
+
+
+def truenorth(n_tiles=4096, width=64, height=64):
+    """arch/truenorth.yaml: 64x64 mesh, one 256-neuron core per tile, all costs zero."""
+    arch = D.Architecture("truenorth_chip", width, height, 1, {0: 0.0})
+    tmpl = None
+    for t in range(n_tiles):
+        tile = arch.create_tile("truenorth_tile[%d]" % t)
+        core = arch.create_core("truenorth_core[0]", tile.id, "soma", False, 256, template=tmpl)
+        if tmpl is not None:
+            continue
+        tmpl = core.template
+        core.create_axon_in("core_in", 0.0, 0.0)
+        core.create_synapse("core_synapses", "current_based", _f(energy_process_spike=0.0, latency_process_spike=0.0))
+        core.create_dendrite("core_dendrites", "accumulator", _f(energy_update=0.0, latency_update=0.0))
+        core.create_soma("core_soma", "truenorth",
+                         _f(energy_access_neuron=0.0, latency_access_neuron=0.0, energy_update_neuron=0.0,
+                            latency_update_neuron=0.0, energy_spike_out=0.0, latency_spike_out=0.0))
+        core.create_axon_out("core_out", 0.0, 0.0)
+    return arch
+
+
+def example_chip():
+    """arch/example_chip.yaml: 2 tiles x 4 cores demo chip."""
+    arch = D.Architecture("demo", 2, 1, 4, {0: 0.0})
+    tmpl = None
+    for t in range(2):
+        tile = arch.create_tile("demo_tile[%d]" % t, energy_north_hop=2.0e-12, latency_north_hop=1.4e-9,
+                                energy_east_hop=2.5e-12, latency_east_hop=1.2e-9, energy_south_hop=2.0e-12,
+                                latency_south_hop=1.5e-9, energy_west_hop=1.8e-12, latency_west_hop=2.0e-9)
+        for c in range(4):
+            core = arch.create_core("demo_core[%d]" % c, tile.id, "soma", False, 100, template=tmpl)
+            if tmpl is not None:
+                continue
+            tmpl = core.template
+            core.create_axon_in("demo_in", 0.0, 0.0)
+            core.create_synapse("demo_synapse", "current_based", _f(energy_process_spike=20.0e-12, latency_process_spike=3.0e-9))
+            core.create_dendrite("demo_dendrite", "accumulator", _f(energy_update=0.0, latency_update=0.0),
+                                 update_every_timestep=True)
+            core.create_soma("demo_soma_default", "leaky_integrate_fire",
+                             _f(energy_access_neuron=20.0e-12, latency_access_neuron=3.0e-9, energy_update_neuron=10.0e-12,
+                                latency_update_neuron=1.0e-9, energy_spike_out=60.0e-12, latency_spike_out=30.0e-9))
+            core.create_soma("demo_soma_alt", "leaky_integrate_fire",
+                             _f(energy_access_neuron=50.0e-12, latency_access_neuron=5.0e-9, energy_update_neuron=60.0e-12,
+                                latency_update_neuron=10.0e-9, energy_spike_out=30.0e-12, latency_spike_out=3.0e-9))
+            core.create_soma("demo_input", "input",
+                             _f(energy_access_neuron=0.0, latency_access_neuron=0.0, energy_update_neuron=0.0,
+                                latency_update_neuron=0.0, energy_spike_out=0.0, latency_spike_out=0.0))
+            core.create_axon_out("demo_out", 100.0e-12, 5.0e-9)
+    return arch
+
+
+def example_snn(arch):
+    """snn/example_snn.yaml restated through the API (4 neurons, 5 synapses)."""
+    net = D.Network("example_snn")
+    gin = net.create_neuron_group("in", 2, log_spikes=True)
+    gin.apply_config(0, 1, log_spikes=False)
+    gin.set_attribute("spikes", (D.ATTR_LIST, 0.0, None, [1, 0, 1]), D.FWD_ALL, 1, 2)
+    gout = net.create_neuron_group("out", 2)
+    gout.apply_config(0, 2, log_potential=True,
+                      attrs={"threshold": ((D.ATTR_INT, 2.0, None, None), D.FWD_SOMA),
+                             "log_u": ((D.ATTR_BOOL, 1.0, None, None), D.FWD_ALL)})
+    import numpy as np
+    net._add_edges(np.array([gout.base + 1]), np.array([gout.base + 1]), np.array([-4.0]))
+    gin.connect_neurons_dense(gout, {"weight": np.array([-1.0, 2.0, 1.0, 3.0])}, narrow_float=False)
+    cores = arch.tiles[0].cores
+    gin.apply_config(0, 1, soma_hw_name="demo_input")
+    gin.map_to_core(cores[0], 0, 1)
+    gin.apply_config(1, 2, soma_hw_name="demo_input")
+    gin.map_to_core(cores[1], 1, 2)
+    gout.map_to_core(cores[0])
+    return net

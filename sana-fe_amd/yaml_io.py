@@ -142,6 +142,7 @@ def load_arch(path) -> D.Architecture:
     arch = D.Architecture(name, int(att["width"]), int(att["height"]), int(att["link_buffer_size"]), table)
     if "tile" not in a:
         raise ValueError("No tile section defined")
+    templates = {}  # one CoreTemplate per description entry, shared by its replicas
     for tile_node in _seq(a["tile"]):
         tname = str(tile_node["name"])
         lo, hi = _parse_range(tname) if ".." in tname else (0, 0)
@@ -158,14 +159,18 @@ def load_arch(path) -> D.Architecture:
                 cname = str(core_node["name"])
                 clo, chi = _parse_range(cname) if ".." in cname else (0, 0)
                 for c in range(clo, chi + 1):
-                    _parse_core(arch, tile.id, core_node, "%s[%d]" % (cname.split("[")[0], c))
+                    _parse_core(arch, tile.id, core_node, "%s[%d]" % (cname.split("[")[0], c), templates)
     return arch
 
 
-def _parse_core(arch, tile_id, node, name):
+def _parse_core(arch, tile_id, node, name, templates):
     ca = node["attributes"]
+    shared = templates.get(id(node))
     core = arch.create_core(name, tile_id, str(ca["buffer_position"]), _as_bool(ca.get("buffer_inside_unit", "false")),
-                            int(ca["max_neurons_supported"]), _as_bool(ca.get("log_energy", "false")))
+                            int(ca["max_neurons_supported"]), _as_bool(ca.get("log_energy", "false")), shared)
+    if shared is not None:
+        return
+    templates[id(node)] = core.template
     for section in ("axon_in", "synapse", "dendrite", "soma", "axon_out"):
         if section not in node or node[section] is None:
             raise ValueError("No %s section defined" % section)

@@ -1,0 +1,91 @@
+"""Chip-level pins of the oracle against outputs the REFERENCE itself holds."""
+import numpy as np
+import pytest
+
+import nets
+from oracle.oracle import OracleChip
+
+
+def run(chip, steps, timing):
+    tot = {}
+    for _ in range(steps):
+        r = chip.step(timing)
+        for k, v in r.items():
+            tot[k] = tot.get(k, 0) + v
+    return tot
+
+
+def test_example_chip_probe(S):
+    """the compiled reference on example_chip + example_snn, 10 steps, detailed timing,
+    printed `spikes=5 packets=3 updated=20 fired=3 energy=1.04e-09 sim_time=1.24e-07`, spikes.csv =
+    in.1@1, out.1@2, in.1@3 and potentials 1:0,0 2:1,0 3:1,-4 4:2,-1."""
+    arch, net = nets.example(S)
+    chip = OracleChip(S.to_desc(arch, net))
+    fired, pots, tot = [], [], {}
+    for t in range(1, 11):
+        r = chip.step("detailed")
+        for k, v in r.items():
+            tot[k] = tot.get(k, 0) + v
+        st = chip.status()
+        fired += [(int(i), t) for i in np.nonzero(st == 3)[0]]
+        pots.append(tuple(chip.potentials()[2:4]))
+    assert (tot["spike_count"], tot["packets_sent"], tot["neurons_updated"], tot["neurons_fired"]) == (5, 3, 20, 3)
+    assert tot["total_energy"] == pytest.approx(1.04e-09, rel=5e-3)
+    assert tot["sim_time"] == pytest.approx(1.24e-07, rel=5e-3)
+    assert fired == [(1, 1), (3, 2), (1, 3)]  # in.1, out.1, in.1 (global ids: in=0..1, out=2..3)
+    assert pots[:4] == [(0.0, 0.0), (1.0, 0.0), (1.0, -4.0), (2.0, -1.0)]
+
+
+def test_example_chip_simple_equals_detailed_functionally(S):
+    arch, net = nets.example(S)
+    a, b = OracleChip(S.to_desc(arch, net)), OracleChip(S.to_desc(*nets.example(S)))
+    ta, tb = run(a, 100, "simple"), run(b, 100, "detailed")
+    for k in ("spike_count", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
+        assert ta[k] == tb[k]
+    assert ta["total_energy"] == tb["total_energy"]
+
+
+@pytest.mark.slow
+def test_tutorial5_dvs_golden(S):
+    """tutorial/tutorial_5_dvs.ipynb: `expected_firing_neurons = 365277` after chip.sim(1000)."""
+    arch, net = nets.tutorial5_dvs(S)
+    assert (net.neuron_count, net.edge_count) == (18678, 3564441)
+    chip = OracleChip(S.to_desc(arch, net))
+    tot = run(chip, 1000, "simple")
+    assert tot["neurons_fired"] == 365277
+
+
+@pytest.mark.slow
+def test_tutorial5_mapping_independent(S):
+    """Spike counts do not depend on the mapping (integer weights): another core split, same count."""
+    arch, net = nets.tutorial5_dvs(S, core_counts=(1, 4, 8, 8, 2, 1))
+    chip = OracleChip(S.to_desc(arch, net))
+    tot = run(chip, 200, "simple")
+    arch2, net2 = nets.tutorial5_dvs(S)
+    tot2 = run(OracleChip(S.to_desc(arch2, net2)), 200, "simple")
+    assert tot["neurons_fired"] == tot2["neurons_fired"] > 0
+    assert tot["spike_count"] == tot2["spike_count"]
+
+
+def test_dvs_yaml_fixture_matches_reference_file(S):
+    """tests/golden/dvs_yaml.npz must rebuild exactly what the YAML front-end reads from snn/dvs.yaml."""
+    from conftest import REFERENCE, have_reference
+    if not have_reference():
+        pytest.skip("reference not present")
+    arch, net = nets.dvs_yaml(S)
+    arch2 = S.load_arch(REFERENCE + "/arch/loihi.yaml")
+    net2 = S.load_net(REFERENCE + "/snn/dvs.yaml", arch2)
+    ba, bb = S.to_desc(arch, net), S.to_desc(arch2, net2)  # keep the owners of the buffers alive
+    a, b = ba.desc, bb.desc
+    assert (a.n_neurons, a.n_edges) == (b.n_neurons, b.n_edges) == (18678, 3564441)
+    n, e = a.n_neurons, a.n_edges
+    for f, cnt in (("neuron_core", n), ("neuron_map_order", n), ("edge_src", e), ("edge_dst", e), ("edge_weight", e)):
+        x = np.ctypeslib.as_array(getattr(a, f), shape=(cnt,))
+        y = np.ctypeslib.as_array(getattr(b, f), shape=(cnt,))
+        assert np.array_equal(x, y), f
+    # attribute tables: compare a sample of neurons from every group
+    ga = S.description.describe(ba)["groups"]
+    gb = S.description.describe(bb)["groups"]
+    assert [g["name"] for g in ga] == [g["name"] for g in gb]
+    for x, y in zip(ga, gb):
+        assert x["neurons"][::97] == y["neurons"][::97]
