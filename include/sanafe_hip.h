@@ -1,0 +1,224 @@
+/* sanafe_hip.h -- C ABI of libsanafe_hip.so: SANA-FE's per-timestep simulation
+ * loop on one MI355X (gfx950).  Plain pointers and sizes only; no torch, no C++
+ * types.  This is the boundary a SANA-FE maintainer binds (INTEGRATION.md shows
+ * the stub): `SpikingChip::load()` lowers the mapped network to a
+ * `sanafe_hip_image` once, then every entry point below replaces one piece of
+ * the reference's CPU loop:
+ *
+ *   sanafe_hip_chip_create   <- SpikingChip::load / map_neurons / map_connections /
+ *                               map_axons            (src/chip.cpp:129-408, 1263-1391)
+ *   sanafe_hip_step          <- SpikingChip::step -> sim_hw_timestep: reset measurements,
+ *                               process_neurons, process_messages, forced_updates,
+ *                               energy + counters, simple timing model
+ *                               (src/chip.cpp:549-560, 624-764, 1028-1108, 1171-1261,
+ *                               1393-1445; src/schedule.cpp:61-102)
+ *   sanafe_hip_read_*        <- get_spikes / get_potentials / get_traces
+ *                               (src/chip.cpp:1766-1831), RunData (src/chip.hpp:215-233)
+ *   sanafe_hip_write_*       <- MappedNeuron::set_attributes between sim() calls
+ *                               (src/mapped.cpp:113-166)
+ *   sanafe_hip_reset         <- SpikingChip::reset (src/chip.cpp:576-600)
+ *   sanafe_hip_{export,import}_spikes
+ *                            <- the inter-tile message exchange when tiles are sharded
+ *                               over GPUs (no reference equivalent)
+ *
+ * Every function returns 0 on success, a negative sanafe_hip_status otherwise;
+ * sanafe_hip_last_error() gives the text.  Nothing here falls back to the CPU:
+ * without a gfx950 device the calls fail.
+ *
+ * ---------------------------------------------------------------------------
+ * Index spaces
+ *   neuron slot g : cores are laid out back to back, each padded to a multiple of
+ *                   64 slots (one wavefront handles 64 consecutive slots of ONE
+ *                   core): g = core_nbase[c] + offset_within_core.
+ *   axon a        : inbound axons of all cores, concatenated in destination-core
+ *                   order; inside a core in the reference's delivery order
+ *                   (source core id, source neuron order) -- src/chip.cpp:661-690.
+ *   synapse s     : synapses of an axon are contiguous, in connection order
+ *                   (src/chip.cpp:748-761), axons in axon order.
+ * ---------------------------------------------------------------------------
+ */
+#ifndef SANAFE_HIP_H
+#define SANAFE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum sanafe_hip_status
+{
+    SANAFE_HIP_OK = 0,
+    SANAFE_HIP_ERR_NO_DEVICE = -1,
+    SANAFE_HIP_ERR_INVALID = -2,
+    SANAFE_HIP_ERR_HIP = -3,
+    SANAFE_HIP_ERR_UNSUPPORTED = -4
+} sanafe_hip_status;
+
+/* soma models (src/models.cpp:933-967) */
+enum { SANAFE_SOMA_NONE = 0, SANAFE_SOMA_LIF = 1, SANAFE_SOMA_TRUENORTH = 2,
+       SANAFE_SOMA_INPUT = 3, SANAFE_SOMA_HOST = 4 };
+/* how a neuron's synaptic input reaches its soma */
+enum {
+    SANAFE_IN_BUFFERED = 0,   /* accumulator + kernel time-step buffer, or delay line: read slot t % ring_slots */
+    SANAFE_IN_ZERO = 1        /* `accumulator` with the buffer inside the unit: always 0.0 */
+};
+/* NeuronResetModes (src/arch.hpp:61-68) */
+enum { SANAFE_RESET_NONE = 0, SANAFE_RESET_SOFT = 1, SANAFE_RESET_HARD = 2, SANAFE_RESET_SATURATE = 3 };
+
+/* Soma parameter class: neurons with identical parameters share one entry
+ * (LoihiCompartment src/models.hpp:222-241, TrueNorthNeuron :307-322). */
+typedef struct sanafe_hip_soma_class
+{
+    double threshold, reverse_threshold, reset, reverse_reset;
+    double leak_decay;      /* LIF; TrueNorth: additive `leak` */
+    double input_decay;     /* LIF only */
+    int32_t refractory_delay;
+    uint8_t reset_mode, reverse_reset_mode;
+    uint8_t force_update;
+    uint8_t leak_towards_zero; /* TrueNorth only */
+} sanafe_hip_soma_class;
+
+/* Cost class: default energy/latency of the neuron-processing pipeline
+ * (src/pipeline.hpp:574-714).  Index 0/1/2 = idle / updated / fired. */
+typedef struct sanafe_hip_cost_class
+{
+    double soma_energy[3], soma_latency[3];
+    double dendrite_energy, dendrite_latency; /* 0 when the dendrite is not in the neuron pipeline */
+} sanafe_hip_cost_class;
+
+typedef struct sanafe_hip_image
+{
+    /* ---- sizes ---- */
+    uint32_t n_cores;
+    uint32_t n_slots;        /* padded neuron slots, multiple of 64 */
+    uint32_t n_soma_classes, n_cost_classes;
+    uint32_t ring_slots;     /* 1 without synaptic delays, 6 with (max_delay 5, src/models.hpp:158) */
+    uint32_t n_slices;       /* delivery work items, >= number of cores with inbound axons */
+    uint64_t n_axons, n_synapses;
+    uint32_t n_input;        /* input-model neurons */
+    uint64_t n_train_words;  /* 32-bit words of packed input spike trains */
+    uint32_t slot_offset;    /* multi-GPU: first GLOBAL slot held by this chip (0 on one GPU) */
+    uint32_t n_global_slots; /* multi-GPU: slots of the whole chip; == n_slots on one GPU */
+    double sync_delay;       /* ts_sync_delay_table.get(mapped_tiles), src/chip.cpp:562-574 */
+
+    /* ---- per core [n_cores] ---- */
+    const uint32_t *core_nbase;   /* first slot, multiple of 64 (local) */
+    const uint32_t *core_ncount;  /* mapped neurons */
+    const double *core_axon_out_latency; /* AxonOutUnit::latency_access of unit 0 */
+
+    /* ---- class tables ---- */
+    const sanafe_hip_soma_class *soma_classes;
+    const sanafe_hip_cost_class *cost_classes;
+
+    /* ---- per slot [n_slots] ---- */
+    const uint32_t *slot_cls;     /* soma model (3b) | input kind (3b) << 3 | cost class (10b) << 6 | soma class (16b) << 16 */
+    const double *slot_bias;
+    const double *slot_v0;        /* initial potential */
+    const uint32_t *slot_aux;     /* input-model neurons: index into in_*; others: 0 */
+    /* static per-neuron totals of everything one spike of this neuron causes
+     * (its messages, their hops, the synaptic events behind them) */
+    const uint32_t *slot_packets; /* out-axons = messages per spike */
+    const uint32_t *slot_hops;    /* sum of hops of those messages */
+    const uint32_t *slot_events;  /* sum of synaptic events (Message::spikes) */
+    const double *slot_e_net;     /* axon-out + hop + axon-in energy */
+    const double *slot_e_syn;     /* synapse energy of the events */
+    const double *slot_e_dend;    /* message-side dendrite energy of the events */
+
+    /* ---- input model [n_input] (src/models.cpp:863-903) ---- */
+    const uint32_t *in_train_beg; /* first bit of the spike train in in_train_bits */
+    const uint32_t *in_train_len; /* bits */
+    const int64_t *in_rate_period;/* (long)(1.0/rate), 0 = no rate input */
+    const uint32_t *in_train_bits;/* [n_train_words] packed LSB first */
+
+    /* ---- delivery slices [n_slices] ---- */
+    const uint32_t *slice_core;   /* destination core (local) */
+    const uint64_t *slice_axon_beg, *slice_axon_end; /* axon range */
+    const uint64_t *core_syn_base;/* [n_cores] first synapse of the core */
+    const double *core_axon_in_latency; /* [n_cores] AxonInUnit::latency_spike_message of unit 0 */
+
+    /* ---- per axon [n_axons] ---- */
+    const uint32_t *ax_pre;       /* GLOBAL slot of the pre-synaptic neuron */
+    const uint32_t *ax_syn_beg;   /* first synapse, relative to core_syn_base[dest core] */
+    const uint32_t *ax_nsyn;      /* synapses behind the axon (Message::spikes) */
+    const double *ax_proc_delay;  /* processing delay of the message, src/chip.cpp:738-764 */
+
+    /* ---- per synapse [n_synapses] ---- */
+    const uint32_t *syn_meta;     /* post-neuron offset in core (16b) | delay (3b) << 16 | drop (1b) << 19 */
+    const double *syn_weight;
+} sanafe_hip_image;
+
+/* Totals of one timestep / of a run: `Timestep` (src/timestep.hpp:21-46),
+ * `RunData` (src/chip.hpp:215-233). */
+typedef struct sanafe_hip_totals
+{
+    int64_t timesteps;
+    int64_t spikes;          /* synaptic events */
+    int64_t packets_sent, neurons_updated, neurons_fired, total_hops;
+    double total_energy, synapse_energy, dendrite_energy, soma_energy, network_energy;
+    double sim_time;         /* simple timing model; 0 when timing is left to the host scheduler */
+} sanafe_hip_totals;
+
+typedef struct sanafe_hip_chip sanafe_hip_chip;
+
+const char *sanafe_hip_last_error(void);
+int sanafe_hip_device_count(void);
+
+/* Uploads the image to `device` and allocates all run-time state there. */
+int sanafe_hip_chip_create(const sanafe_hip_image *image, int device, sanafe_hip_chip **out);
+void sanafe_hip_chip_destroy(sanafe_hip_chip *chip);
+
+/* Runs `n_steps` timesteps back to back on the chip's stream (asynchronous).
+ * `record` != 0 keeps a per-step record (totals + spike bitmap) for
+ * sanafe_hip_read_step_*; `simple_timing` != 0 evaluates the simple timing
+ * model on the device (src/schedule.cpp:61-102). */
+int sanafe_hip_step(sanafe_hip_chip *chip, int64_t n_steps, int simple_timing, int record);
+int sanafe_hip_synchronize(sanafe_hip_chip *chip);
+
+/* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)
+ * soma units: neurons -> [exchange spike bitmaps] -> deliver. */
+int sanafe_hip_step_neurons(sanafe_hip_chip *chip);
+int sanafe_hip_step_deliver(sanafe_hip_chip *chip, int simple_timing, int record);
+/* Device pointer + size (bytes) of this chip's local spike bitmap and of the
+ * global bitmap the delivery kernel reads; the caller moves bytes between
+ * them (on one GPU they alias).  RCCL all-gather runs directly on these. */
+int sanafe_hip_spike_buffers(sanafe_hip_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
+        uint64_t *global_bytes);
+void *sanafe_hip_stream(sanafe_hip_chip *chip); /* hipStream_t the kernels run on */
+
+/* Run totals since create/reset_totals, and per-step records of the last sim. */
+int sanafe_hip_read_totals(sanafe_hip_chip *chip, sanafe_hip_totals *out);
+int sanafe_hip_reset_totals(sanafe_hip_chip *chip);
+int sanafe_hip_read_step_totals(sanafe_hip_chip *chip, int64_t first, int64_t count, sanafe_hip_totals *out);
+/* Spike bitmap (1 bit per local slot, LSB first) of recorded step `index`. */
+int sanafe_hip_read_step_spikes(sanafe_hip_chip *chip, int64_t index, uint32_t *bits_out);
+/* NeuronStatus (0..3) per local slot after the last step. */
+int sanafe_hip_read_status(sanafe_hip_chip *chip, uint8_t *out);
+int sanafe_hip_read_potentials(sanafe_hip_chip *chip, double *out);
+int sanafe_hip_read_input_current(sanafe_hip_chip *chip, double *out); /* LIF `u` trace */
+/* Per-core sums of the last step: generation-delay sum and processing-delay sum. */
+int sanafe_hip_read_core_delays(sanafe_hip_chip *chip, double *gen_sum, double *proc_sum);
+
+/* Parameter patches between sim() calls (slot-indexed, local). */
+int sanafe_hip_write_bias(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const double *bias);
+int sanafe_hip_write_potential(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const double *v);
+int sanafe_hip_write_slot_class(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const uint32_t *cls);
+int sanafe_hip_write_soma_classes(sanafe_hip_chip *chip, uint32_t n, const sanafe_hip_soma_class *classes);
+/* Host-evaluated soma units: status (0..3) of SANAFE_SOMA_HOST slots for the
+ * step in flight, written between step_neurons and step_deliver. */
+int sanafe_hip_write_host_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status);
+
+/* SpikingChip::reset: potentials, input currents and buffers to zero. */
+int sanafe_hip_reset(sanafe_hip_chip *chip);
+
+/* Name and launch statistics of the kernels, for bench.py's roofline block:
+ * event-timed average duration (ms) of the delivery kernel over the last
+ * sanafe_hip_step call with `timed` set (see sanafe_hip_set_timing). */
+int sanafe_hip_set_timing(sanafe_hip_chip *chip, int enabled);
+int sanafe_hip_read_timing(sanafe_hip_chip *chip, double *neuron_ms, double *deliver_ms, double *reduce_ms,
+        int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SANAFE_HIP_H */

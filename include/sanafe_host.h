@@ -1,0 +1,88 @@
+/* sanafe_host.h -- C API of libsanafe_host.so: the host side of the MI355X path.
+ *
+ * Mirrors the reference's SpikingChip surface (src/chip.hpp:56-107) over a
+ * `sanafe_desc`: create = SpikingChip(arch) + load(net); sim = SpikingChip::sim;
+ * the getters = get_spikes / get_potentials / get_traces / RunData.  The host
+ * library maps the network (src/chip.cpp:129-408), lowers it to the device
+ * image of sanafe_hip.h, drives libsanafe_hip.so and runs the `detailed`
+ * NoC timing model (src/schedule.cpp:208-620) on the CPU, as the reference does.
+ * All per-neuron outputs are indexed by the neuron's global id in desc order.
+ */
+#ifndef SANAFE_HOST_H
+#define SANAFE_HOST_H
+
+#include <stdint.h>
+#include "sanafe_desc.h"
+#include "sanafe_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sanafe_chip sanafe_chip;
+
+enum { SANAFE_TIMING_SIMPLE = 0, SANAFE_TIMING_DETAILED = 1, SANAFE_TIMING_CYCLE = 2 };
+
+typedef struct sanafe_chip_info
+{
+    uint32_t n_cores, n_local_cores, n_slots, n_global_slots, ring_slots, n_slices;
+    uint64_t n_neurons, n_axons, n_synapses, mapped_tiles, mapped_cores;
+    uint32_t n_soma_classes, n_cost_classes;
+    double sync_delay;
+    uint64_t image_bytes;
+} sanafe_chip_info;
+
+/* One spike message, the fields of `Message` that the traces print (src/message.hpp:19-62). */
+typedef struct sanafe_message
+{
+    int64_t timestep, mid;
+    int64_t src_neuron;       /* global neuron id (desc order) */
+    int64_t src_tile, src_core_offset, src_core_id;
+    int64_t dest_tile, dest_core_offset, dest_core_id, dest_axon_id;
+    int64_t hops, spikes, placeholder;
+    double generation_delay, processing_delay, network_delay, blocking_delay,
+            min_hop_delay, sent_timestamp, received_timestamp,
+            processed_timestamp, messages_along_route;
+} sanafe_message;
+
+const char *sanafe_last_error(void);
+/* SpikingChip(arch) + load(net).  rank / n_ranks: tile-sharded multi-GPU runs (one process per GPU). */
+int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ranks, int rank, sanafe_chip **out);
+void sanafe_chip_destroy(sanafe_chip *chip);
+int sanafe_chip_get_info(sanafe_chip *chip, sanafe_chip_info *out);
+sanafe_hip_chip *sanafe_chip_device(sanafe_chip *chip);
+/* The lowered device image (host pointers, valid while the chip lives) and the
+ * neuron -> global slot map; with device < 0 at create the chip is mapped only. */
+int sanafe_chip_get_image(sanafe_chip *chip, sanafe_hip_image *out);
+int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron);
+
+/* SpikingChip::sim(timesteps, timing_model): returns the RunData of this call.
+ * record != 0 keeps per-step totals / spike lists / (detailed) messages for the getters. */
+int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *run_data);
+int sanafe_chip_reset(sanafe_chip *chip);
+double sanafe_chip_get_power(sanafe_chip *chip);
+
+int sanafe_chip_get_status(sanafe_chip *chip, uint8_t *out);      /* [n_neurons] NeuronStatus */
+int sanafe_chip_get_potentials(sanafe_chip *chip, double *out);   /* [n_neurons] */
+int sanafe_chip_get_input_current(sanafe_chip *chip, double *out);/* [n_neurons] LIF trace "u" */
+int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int64_t count, sanafe_hip_totals *out);
+/* fired flag per neuron (desc order) of recorded step `index` of the last sim */
+int sanafe_chip_get_step_fired(sanafe_chip *chip, int64_t index, uint8_t *out);
+/* messages of recorded step `index` (detailed timing + record only), per-source-core order */
+int64_t sanafe_chip_get_step_messages(sanafe_chip *chip, int64_t index, sanafe_message *out, int64_t cap);
+
+/* MappedNeuron::set_attributes between sim() calls (src/mapped.cpp:113-166): bias and potential */
+int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int64_t *neurons, const double *bias);
+
+/* Split step for multi-GPU runs; the caller exchanges the spike bitmaps (RCCL all-gather). */
+int sanafe_chip_step_neurons(sanafe_chip *chip);
+int sanafe_chip_step_deliver(sanafe_chip *chip, int timing_model);
+int sanafe_chip_spike_buffers(sanafe_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
+        uint64_t *global_bytes, uint64_t *local_offset_bytes);
+int sanafe_chip_synchronize(sanafe_chip *chip);
+int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

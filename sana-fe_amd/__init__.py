@@ -7,3 +7,5 @@ from .description import (Architecture, Network, NeuronGroup, Neuron, Tile, Core
                           to_desc)
 from .yaml_io import load_arch, load_net  # noqa: F401
 from . import description, presets, yaml_io  # noqa: F401
+from .chip import SpikingChip, BackendMissingError, map_only  # noqa: F401,E402
+from . import chip  # noqa: F401,E402

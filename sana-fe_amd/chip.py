@@ -1,0 +1,517 @@
+"""``SpikingChip``: the reference's Python entry point for the simulation loop
+(``sanafe.SpikingChip``, src/pymodule.cpp:1170-1212) on top of the MI355X host
+library (include/sanafe_host.h).
+
+There is no CPU fallback: constructing a chip without the built HIP libraries
+or without a gfx950 device raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import description as D
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+class Totals(C.Structure):
+    """sanafe_hip_totals (include/sanafe_hip.h)."""
+    _fields_ = [(n, C.c_int64) for n in ("timesteps", "spikes", "packets_sent", "neurons_updated", "neurons_fired",
+                                         "total_hops")] + \
+               [(n, C.c_double) for n in ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy",
+                                          "network_energy", "sim_time")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+TOTALS_DTYPE = np.dtype([(n, np.int64) for n in ("timesteps", "spikes", "packets_sent", "neurons_updated",
+                                                 "neurons_fired", "total_hops")] +
+                        [(n, np.float64) for n in ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy",
+                                                   "network_energy", "sim_time")])
+
+
+class ChipInfo(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_cores", "n_local_cores", "n_slots", "n_global_slots", "ring_slots",
+                                          "n_slices")] + \
+               [(n, C.c_uint64) for n in ("n_neurons", "n_axons", "n_synapses", "mapped_tiles", "mapped_cores")] + \
+               [("n_soma_classes", C.c_uint32), ("n_cost_classes", C.c_uint32), ("sync_delay", C.c_double),
+                ("image_bytes", C.c_uint64)]
+
+
+MSG_INT = ("timestep", "mid", "src_neuron", "src_tile", "src_core_offset", "src_core_id", "dest_tile",
+           "dest_core_offset", "dest_core_id", "dest_axon_id", "hops", "spikes", "placeholder")
+MSG_DBL = ("generation_delay", "processing_delay", "network_delay", "blocking_delay", "min_hop_delay",
+           "sent_timestamp", "received_timestamp", "processed_timestamp", "messages_along_route")
+MSG_DTYPE = np.dtype([(n, np.int64) for n in MSG_INT] + [(n, np.float64) for n in MSG_DBL])
+
+_lib = None
+
+
+class BackendMissingError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads host/libsanafe_host.so (which loads csrc/libsanafe_hip.so); never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = os.path.join(HERE, "host", "libsanafe_host.so")
+    hip = os.path.join(HERE, "csrc", "libsanafe_hip.so")
+    for p in (hip, path):
+        if not os.path.exists(p):
+            raise BackendMissingError("%s is missing: build it with `make -C sana-fe_amd` "
+                                      "(or __graft_entry__.build()); there is no CPU fallback" % p)
+    C.CDLL(hip, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path)
+    L.sanafe_last_error.restype = C.c_char_p
+    L.sanafe_chip_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.sanafe_chip_destroy.argtypes = [C.c_void_p]
+    L.sanafe_chip_get_info.argtypes = [C.c_void_p, C.POINTER(ChipInfo)]
+    L.sanafe_chip_device.argtypes = [C.c_void_p]
+    L.sanafe_chip_device.restype = C.c_void_p
+    L.sanafe_chip_sim.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(Totals)]
+    L.sanafe_chip_reset.argtypes = [C.c_void_p]
+    L.sanafe_chip_get_power.argtypes = [C.c_void_p]
+    L.sanafe_chip_get_power.restype = C.c_double
+    for n in ("sanafe_chip_get_status", "sanafe_chip_get_potentials", "sanafe_chip_get_input_current"):
+        getattr(L, n).argtypes = [C.c_void_p, C.c_void_p]
+    L.sanafe_chip_get_step_totals.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.sanafe_chip_get_step_fired.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+    L.sanafe_chip_get_step_messages.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64]
+    L.sanafe_chip_get_step_messages.restype = C.c_int64
+    L.sanafe_chip_set_bias.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
+    L.sanafe_chip_step_neurons.argtypes = [C.c_void_p]
+    L.sanafe_chip_step_deliver.argtypes = [C.c_void_p, C.c_int]
+    L.sanafe_chip_spike_buffers.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64),
+                                            C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.sanafe_chip_synchronize.argtypes = [C.c_void_p]
+    L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
+    _lib = L
+    return L
+
+
+def hip_lib():
+    """The device C ABI (include/sanafe_hip.h), for callers that drive it directly."""
+    lib()
+    L = C.CDLL(os.path.join(HERE, "csrc", "libsanafe_hip.so"))
+    L.sanafe_hip_last_error.restype = C.c_char_p
+    L.sanafe_hip_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.sanafe_hip_read_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.sanafe_hip_step.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int]
+    L.sanafe_hip_synchronize.argtypes = [C.c_void_p]
+    L.sanafe_hip_stream.argtypes = [C.c_void_p]
+    L.sanafe_hip_stream.restype = C.c_void_p
+    L.sanafe_hip_read_core_delays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    return L
+
+
+TIMING = {"simple": 0, "detailed": 1, "cycle": 2}
+
+
+class MappedNeuronRef:
+    """``chip.mapped_neuron_groups[name][i]`` (src/pymodule.cpp:1174-1192)."""
+
+    def __init__(self, chip, gid):
+        self._chip, self._gid = chip, gid
+
+    def set_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None, log_spikes=None):
+        attrs = dict(model_attributes or {})
+        attrs.update(soma_attributes or {})
+        extra = set(attrs) - {"bias"}
+        if extra or dendrite_attributes:
+            raise NotImplementedError("only `bias` can be changed on a mapped neuron on the MI355X backend for now: %s"
+                                      % sorted(extra))
+        if "bias" in attrs:
+            self._chip._set_bias([self._gid], [D.py_to_attr(attrs["bias"])[1]])
+        if log_spikes is not None:
+            self._chip._log_spikes[self._gid] = bool(log_spikes)
+
+
+class SpikingChip:
+    """Drop-in for ``sanafe.SpikingChip`` on one MI355X (or one rank of a tile-sharded run)."""
+
+    def __init__(self, arch: D.Architecture, device=0, n_ranks=1, rank=0):
+        self._L = lib()
+        self.arch = arch
+        self._device, self._n_ranks, self._rank = device, n_ranks, rank
+        self._h = None
+        self._net = None
+        self._built = None
+        self.total_timesteps = 0
+
+    # -- SpikingChip::load (src/chip.cpp:129-138); Python default overwrite=False ---------------
+    def load(self, net: D.Network, overwrite=False):
+        if self._h is not None and not overwrite:
+            raise NotImplementedError("loading a second network into a programmed chip is not supported; "
+                                      "use load(net, overwrite=True)")
+        self._free()
+        self._net = net
+        self._built = D.to_desc(self.arch, net)
+        h = C.c_void_p()
+        rc = self._L.sanafe_chip_create(C.addressof(self._built.desc), self._device, self._n_ranks, self._rank,
+                                        C.byref(h))
+        if rc != 0:
+            msg = self._L.sanafe_last_error().decode()
+            if msg.startswith("HardwareMappingError"):
+                raise D.HardwareMappingError(msg)
+            if msg.startswith("UnsupportedError"):
+                raise NotImplementedError(msg)
+            raise RuntimeError(msg)
+        self._h = h
+        self.n_neurons = int(self._built.desc.n_neurons)
+        self._log_spikes = np.concatenate([g.log_spikes for g in net._order]).astype(bool) if net._order else np.zeros(0, bool)
+        self._log_potential = np.concatenate([g.log_potential for g in net._order]).astype(bool) if net._order else np.zeros(0, bool)
+        # trace order: groups lexicographically by name, neurons by offset (std::map, src/chip.cpp:1616-1629)
+        order = []
+        for name in sorted(net.groups):
+            g = net.groups[name]
+            order.append(np.arange(g.base, g.base + g.count))
+        self._trace_order = np.concatenate(order) if order else np.zeros(0, np.int64)
+        self._gid_label = {}
+        self.total_timesteps = 0
+
+    @property
+    def mapped_neuron_groups(self):
+        return {name: [MappedNeuronRef(self, g.base + i) for i in range(g.count)] for name, g in self._net.groups.items()}
+
+    def info(self):
+        i = ChipInfo()
+        self._check(self._L.sanafe_chip_get_info(self._h, C.byref(i)))
+        return {n: getattr(i, n) for n, _ in i._fields_}
+
+    def _check(self, rc):
+        if rc != 0:
+            msg = self._L.sanafe_last_error().decode()
+            if msg.startswith("UnsupportedError"):
+                raise NotImplementedError(msg)
+            raise RuntimeError(msg)
+
+    def _free(self):
+        if self._h is not None:
+            self._L.sanafe_chip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self._free()
+        except Exception:
+            pass
+
+    def _set_bias(self, gids, values):
+        g = np.ascontiguousarray(gids, dtype=np.int64)
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self._L.sanafe_chip_set_bias(self._h, len(g), g.ctypes.data, v.ctypes.data))
+
+    def set_bias(self, group, values):
+        """Vectorised MappedNeuron.set_attributes(model_attributes={'bias': b}) for a whole group (DVS frames)."""
+        g = self._net.groups[str(group)]
+        self._set_bias(np.arange(g.base, g.base + g.count), np.asarray(values, dtype=np.float64))
+
+    # -- raw accessors (desc order) ------------------------------------------------------------
+    def status(self):
+        out = np.zeros(self.n_neurons, dtype=np.uint8)
+        self._check(self._L.sanafe_chip_get_status(self._h, out.ctypes.data))
+        return out
+
+    def potentials(self):
+        out = np.zeros(self.n_neurons, dtype=np.float64)
+        self._check(self._L.sanafe_chip_get_potentials(self._h, out.ctypes.data))
+        return out
+
+    def input_currents(self):
+        out = np.zeros(self.n_neurons, dtype=np.float64)
+        self._check(self._L.sanafe_chip_get_input_current(self._h, out.ctypes.data))
+        return out
+
+    def step_totals(self, first, count):
+        out = np.zeros(count, dtype=TOTALS_DTYPE)
+        self._check(self._L.sanafe_chip_get_step_totals(self._h, first, count, out.ctypes.data))
+        return out
+
+    def step_fired(self, index):
+        out = np.zeros(self.n_neurons, dtype=np.uint8)
+        self._check(self._L.sanafe_chip_get_step_fired(self._h, index, out.ctypes.data))
+        return out
+
+    def step_messages(self, index):
+        n = self._L.sanafe_chip_get_step_messages(self._h, index, None, 0)
+        if n < 0:
+            raise RuntimeError("messages of step %d were not recorded (detailed timing + traces only)" % index)
+        out = np.zeros(n, dtype=MSG_DTYPE)
+        if n:
+            self._L.sanafe_chip_get_step_messages(self._h, index, out.ctypes.data, n)
+        return out
+
+    def run(self, timesteps, timing_model="simple", record=False):
+        """One sanafe_chip_sim call; returns the raw totals dict."""
+        t = Totals()
+        self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], int(bool(record)), C.byref(t)))
+        self.total_timesteps += int(timesteps)
+        return t.as_dict()
+
+    # -- SpikingChip.sim (src/pymodule.cpp:549-706, 1198-1208) ---------------------------------
+    def sim(self, timesteps=1, timing_model="detailed", processing_threads=0, scheduler_threads=0, spike_trace=None,
+            potential_trace=None, neuron_trace=None, perf_trace=None, message_trace=None, write_trace_headers=True):
+        if self._h is None:
+            raise RuntimeError("no network loaded")
+        if timing_model not in TIMING:
+            timing_model = "detailed"  # parse_timing_model falls back to detailed, src/chip.cpp:1833-1858
+        start = self.total_timesteps + 1
+        want_steps = any(t is not None and t is not False for t in (spike_trace, perf_trace, message_trace))
+        want_state = any(t is not None and t is not False for t in (potential_trace, neuron_trace))
+        spikes, pots, ntraces, perf, msgs = [], [], {}, None, []
+        if not want_state:
+            tot = self.run(timesteps, timing_model, record=want_steps)
+            steps = self.step_totals(0, timesteps) if want_steps and timesteps > 0 else None
+            fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
+            if message_trace:
+                if timing_model != "detailed":
+                    raise NotImplementedError("message traces need timing_model='detailed' on the MI355X backend")
+                msgs = [self.step_messages(i) for i in range(timesteps)]
+        else:
+            # potentials / model traces are sampled after every step (src/pytrace.cpp:190-222)
+            tot = None
+            steps_l, fired = [], []
+            for _ in range(timesteps):
+                r = self.run(1, timing_model, record=True)
+                tot = r if tot is None else {k: tot[k] + r[k] for k in r}
+                steps_l.append(self.step_totals(0, 1)[0])
+                fired.append(self.step_fired(0))
+                if message_trace:
+                    msgs.append(self.step_messages(0))
+                if potential_trace:
+                    v = self.potentials()
+                    sel = self._trace_order[self._log_potential[self._trace_order]]
+                    pots.append([float(x) for x in v[sel]])
+                if neuron_trace:
+                    u = self.input_currents()
+                    ntraces.setdefault("u", []).append([float(x) for x in u[self._trace_order]])
+            steps = np.array(steps_l, dtype=TOTALS_DTYPE) if steps_l else None
+            if tot is None:
+                tot = Totals().as_dict()
+        result = {
+            "timestep_start": start, "timesteps_executed": timesteps,
+            "energy": {"total": tot["total_energy"], "synapse": tot["synapse_energy"], "dendrite": tot["dendrite_energy"],
+                       "soma": tot["soma_energy"], "network": tot["network_energy"]},
+            "sim_time": tot["sim_time"], "spikes": tot["spikes"], "packets_sent": tot["packets_sent"],
+            "neurons_updated": tot["neurons_updated"], "neurons_fired": tot["neurons_fired"],
+        }
+        if spike_trace:
+            names = self._labels()
+            for f in fired:
+                sel = self._trace_order[(f[self._trace_order] != 0) & self._log_spikes[self._trace_order]]
+                spikes.append([names[int(g)] for g in sel])
+        if perf_trace and steps is not None:
+            perf = {"timestep": [int(start + i) for i in range(timesteps)],
+                    "fired": steps["neurons_fired"].tolist(), "updated": steps["neurons_updated"].tolist(),
+                    "packets": steps["packets_sent"].tolist(), "hops": steps["total_hops"].tolist(),
+                    "spikes": steps["spikes"].tolist(), "sim_time": steps["sim_time"].tolist(),
+                    "synapse_energy": steps["synapse_energy"].tolist(), "dendrite_energy": steps["dendrite_energy"].tolist(),
+                    "soma_energy": steps["soma_energy"].tolist(), "network_energy": steps["network_energy"].tolist(),
+                    "total_energy": steps["total_energy"].tolist()}
+        result["spike_trace"] = spikes if spike_trace else None
+        result["potential_trace"] = pots if potential_trace else None
+        result["neuron_trace"] = ntraces if neuron_trace else None
+        result["perf_trace"] = perf
+        result["message_trace"] = [self._message_dicts(m) for m in msgs] if message_trace else None
+        for tr, key in ((spike_trace, "spike_trace"), (potential_trace, "potential_trace"), (perf_trace, "perf_trace"),
+                        (message_trace, "message_trace")):
+            if isinstance(tr, str) or hasattr(tr, "write"):
+                self._write_trace(tr, key, result[key], start, write_trace_headers)
+                result[key] = None
+        return result
+
+    def _labels(self):
+        if not self._gid_label:
+            for name, g in self._net.groups.items():
+                for i in range(g.count):
+                    self._gid_label[g.base + i] = (name, i)  # NeuronAddress(group_name, neuron_offset)
+        return self._gid_label
+
+    def _message_dicts(self, arr):
+        """Python in-memory message trace rows, sorted by mid: placeholders (-1) first (src/pytrace.hpp:336-339)."""
+        labels = self._labels()
+        rows = []
+        for m in np.sort(arr, order="mid", kind="stable"):
+            g, o = labels.get(int(m["src_neuron"]), ("invalid", 0))
+            row = {"timestep": int(m["timestep"]), "mid": int(m["mid"]), "src_neuron": "%s.%d" % (g, o),
+                   "src_hw": "%d.%d" % (m["src_tile"], m["src_core_offset"]),
+                   "dest_hw": "x.x" if m["placeholder"] else "%d.%d" % (m["dest_tile"], m["dest_core_offset"]),
+                   "hops": int(m["hops"]), "spikes": int(m["spikes"])}
+            for k in MSG_DBL:
+                row[{"sent_timestamp": "send_timestamp"}.get(k, k)] = float(m[k])
+            rows.append(row)
+        return rows
+
+    def _write_trace(self, target, key, data, start, headers):
+        """CSV traces with the reference's column layout (src/chip.cpp:1447-1764)."""
+        close = False
+        f = target
+        if isinstance(target, str):
+            f = open(target, "w" if headers else "a")
+            close = True
+        try:
+            names = self._labels()
+            if key == "spike_trace":
+                if headers:
+                    f.write("neuron,timestep\n")
+                for i, row in enumerate(data or []):
+                    for (g, o) in row:
+                        f.write("%s.%d,%d\n" % (g, o, start + i))
+            elif key == "potential_trace":
+                sel = self._trace_order[self._log_potential[self._trace_order]]
+                if headers:
+                    f.write("timestep," + "".join("neuron %s.%d," % names[int(g)] for g in sel) + "\n")
+                for i, row in enumerate(data or []):
+                    if row:
+                        f.write("%d," % (start + i) + "".join("%g," % v for v in row) + "\n")
+            elif key == "perf_trace":
+                cols = ["timestep", "fired", "updated", "packets", "hops", "spikes", "sim_time", "synapse_energy",
+                        "dendrite_energy", "soma_energy", "network_energy", "total_energy"]
+                if headers:
+                    f.write(",".join(cols) + "\n")
+                for i in range(len(data["timestep"]) if data else 0):
+                    f.write(",".join(("%d" % data[c][i]) if c in cols[:6] else ("%e" % data[c][i]) for c in cols) + "\n")
+            elif key == "message_trace":
+                cols = ["timestep", "mid", "src_neuron", "src_hw", "dest_hw", "hops", "spikes", "send_timestamp",
+                        "received_timestamp", "processed_timestamp", "generation_delay", "processing_delay",
+                        "network_delay", "blocking_delay", "min_hop_delay", "messages_along_route"]
+                if headers:
+                    f.write(",".join(cols) + "\n")
+                for step in data or []:
+                    # the CSV writer sorts by mid with placeholders LAST (src/message.cpp:70-91)
+                    rows = sorted(step, key=lambda r: (r["mid"] < 0, r["mid"]))
+                    for r in rows:
+                        f.write(",".join(("%g" % r[c]) if isinstance(r[c], float) else str(r[c]) for c in cols) + "\n")
+        finally:
+            if close:
+                f.close()
+
+    def reset(self):
+        self._check(self._L.sanafe_chip_reset(self._h))
+
+    def get_power(self):
+        return self._L.sanafe_chip_get_power(self._h)
+
+    # -- multi-GPU split step ------------------------------------------------------------------
+    def step_neurons(self):
+        self._check(self._L.sanafe_chip_step_neurons(self._h))
+
+    def step_deliver(self, timing_model="simple"):
+        self._check(self._L.sanafe_chip_step_deliver(self._h, TIMING[timing_model]))
+        self.total_timesteps += 1
+
+    def spike_buffers(self):
+        lp, gp = C.c_void_p(), C.c_void_p()
+        lb, gb, off = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._L.sanafe_chip_spike_buffers(self._h, C.byref(lp), C.byref(lb), C.byref(gp), C.byref(gb),
+                                                      C.byref(off)))
+        return dict(local_ptr=lp.value, local_bytes=lb.value, global_ptr=gp.value, global_bytes=gb.value,
+                    local_offset_bytes=off.value)
+
+    def synchronize(self):
+        self._check(self._L.sanafe_chip_synchronize(self._h))
+
+    def read_totals(self):
+        t = Totals()
+        self._check(self._L.sanafe_chip_read_totals(self._h, C.byref(t)))
+        return t.as_dict()
+
+    def device_handle(self):
+        return self._L.sanafe_chip_device(self._h)
+
+
+# --------------------------------------------------------------------------------------------
+# The lowered device image (include/sanafe_hip.h), for inspection and host-side checks
+# --------------------------------------------------------------------------------------------
+class SomaClass(C.Structure):
+    _fields_ = [("threshold", C.c_double), ("reverse_threshold", C.c_double), ("reset", C.c_double),
+                ("reverse_reset", C.c_double), ("leak_decay", C.c_double), ("input_decay", C.c_double),
+                ("refractory_delay", C.c_int32), ("reset_mode", C.c_uint8), ("reverse_reset_mode", C.c_uint8),
+                ("force_update", C.c_uint8), ("leak_towards_zero", C.c_uint8)]
+
+
+class CostClass(C.Structure):
+    _fields_ = [("soma_energy", C.c_double * 3), ("soma_latency", C.c_double * 3), ("dendrite_energy", C.c_double),
+                ("dendrite_latency", C.c_double)]
+
+
+def _p(t):
+    return C.POINTER(t)
+
+
+class HipImage(C.Structure):
+    _fields_ = [
+        ("n_cores", C.c_uint32), ("n_slots", C.c_uint32), ("n_soma_classes", C.c_uint32), ("n_cost_classes", C.c_uint32),
+        ("ring_slots", C.c_uint32), ("n_slices", C.c_uint32), ("n_axons", C.c_uint64), ("n_synapses", C.c_uint64),
+        ("n_input", C.c_uint32), ("n_train_words", C.c_uint64), ("slot_offset", C.c_uint32),
+        ("n_global_slots", C.c_uint32), ("sync_delay", C.c_double),
+        ("core_nbase", _p(C.c_uint32)), ("core_ncount", _p(C.c_uint32)), ("core_axon_out_latency", _p(C.c_double)),
+        ("soma_classes", _p(SomaClass)), ("cost_classes", _p(CostClass)),
+        ("slot_cls", _p(C.c_uint32)), ("slot_bias", _p(C.c_double)), ("slot_v0", _p(C.c_double)),
+        ("slot_aux", _p(C.c_uint32)), ("slot_packets", _p(C.c_uint32)), ("slot_hops", _p(C.c_uint32)),
+        ("slot_events", _p(C.c_uint32)), ("slot_e_net", _p(C.c_double)), ("slot_e_syn", _p(C.c_double)),
+        ("slot_e_dend", _p(C.c_double)),
+        ("in_train_beg", _p(C.c_uint32)), ("in_train_len", _p(C.c_uint32)), ("in_rate_period", _p(C.c_int64)),
+        ("in_train_bits", _p(C.c_uint32)),
+        ("slice_core", _p(C.c_uint32)), ("slice_axon_beg", _p(C.c_uint64)), ("slice_axon_end", _p(C.c_uint64)),
+        ("core_syn_base", _p(C.c_uint64)), ("core_axon_in_latency", _p(C.c_double)),
+        ("ax_pre", _p(C.c_uint32)), ("ax_syn_beg", _p(C.c_uint32)), ("ax_nsyn", _p(C.c_uint32)),
+        ("ax_proc_delay", _p(C.c_double)),
+        ("syn_meta", _p(C.c_uint32)), ("syn_weight", _p(C.c_double)),
+    ]
+
+
+def map_only(arch, net, n_ranks=1, rank=0):
+    """Maps and lowers without touching a device; returns (image dict of numpy arrays, slot_of_neuron).
+    The arrays are copies, so they outlive the temporary chip."""
+    L = lib()
+    L.sanafe_chip_get_image.argtypes = [C.c_void_p, C.POINTER(HipImage)]
+    L.sanafe_chip_get_slot_map.argtypes = [C.c_void_p, C.c_void_p]
+    built = D.to_desc(arch, net)
+    h = C.c_void_p()
+    if L.sanafe_chip_create(C.addressof(built.desc), -1, n_ranks, rank, C.byref(h)) != 0:
+        msg = L.sanafe_last_error().decode()
+        if msg.startswith("HardwareMappingError"):
+            raise D.HardwareMappingError(msg)
+        if msg.startswith("UnsupportedError"):
+            raise NotImplementedError(msg)
+        raise RuntimeError(msg)
+    try:
+        im = HipImage()
+        if L.sanafe_chip_get_image(h, C.byref(im)) != 0:
+            raise RuntimeError(L.sanafe_last_error().decode())
+        counts = {"core_nbase": im.n_cores, "core_ncount": im.n_cores, "core_axon_out_latency": im.n_cores,
+                  "core_syn_base": im.n_cores, "core_axon_in_latency": im.n_cores,
+                  "slice_core": im.n_slices, "slice_axon_beg": im.n_slices, "slice_axon_end": im.n_slices,
+                  "ax_pre": im.n_axons, "ax_syn_beg": im.n_axons, "ax_nsyn": im.n_axons, "ax_proc_delay": im.n_axons,
+                  "syn_meta": im.n_synapses, "syn_weight": im.n_synapses,
+                  "in_train_beg": im.n_input, "in_train_len": im.n_input, "in_rate_period": im.n_input,
+                  "in_train_bits": im.n_train_words}
+        for n in ("slot_cls", "slot_bias", "slot_v0", "slot_aux", "slot_packets", "slot_hops", "slot_events",
+                  "slot_e_net", "slot_e_syn", "slot_e_dend"):
+            counts[n] = im.n_slots
+        out = {}
+        for n, _t in HipImage._fields_:
+            v = getattr(im, n)
+            if n in counts:
+                out[n] = np.ctypeslib.as_array(v, shape=(counts[n],)).copy() if counts[n] else np.zeros(0)
+            elif n == "soma_classes":
+                out[n] = [{f: getattr(v[i], f) for f, _ in SomaClass._fields_} for i in range(im.n_soma_classes)]
+            elif n == "cost_classes":
+                out[n] = [dict(soma_energy=list(v[i].soma_energy), soma_latency=list(v[i].soma_latency),
+                               dendrite_energy=v[i].dendrite_energy, dendrite_latency=v[i].dendrite_latency)
+                          for i in range(im.n_cost_classes)]
+            else:
+                out[n] = v
+        slot_of = np.zeros(int(built.desc.n_neurons), dtype=np.uint32)
+        L.sanafe_chip_get_slot_map(h, slot_of.ctypes.data)
+        return out, slot_of
+    finally:
+        L.sanafe_chip_destroy(h)

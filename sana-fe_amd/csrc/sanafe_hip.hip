@@ -1,0 +1,1157 @@
+// sanafe_hip.hip -- SANA-FE's per-timestep simulation loop for MI355X (gfx950, CDNA4).
+//
+// Implements the C ABI of include/sanafe_hip.h.  Three kernels per timestep, all on one
+// HIP stream, no host round trip between steps (the timestep counter lives on the device):
+//
+//   K1 neuron_kernel   one 64-lane wavefront per simulated core; SoA neuron state, coalesced
+//                      8-byte loads; soma update (LIF / TrueNorth / input); wave ballot ->
+//                      spike bitmap; per-core cost/counter sums by wave reduction.
+//                      Reference: process_neurons / process_neuron / execute_pipeline,
+//                      src/chip.cpp:624-654, 710-736, 766-789; models src/models.cpp:441-903;
+//                      default costing src/pipeline.hpp:631-731.
+//   K2 deliver_kernel  one 256-thread workgroup per delivery slice of a destination core:
+//                      scans the core's static inbound-axon list against the spike bitmap
+//                      (pull, so the order is the reference's delivery order), compacts the
+//                      active axons with ballot + prefix sums, expands them to synaptic
+//                      events load-balanced over the workgroup, and accumulates weights in
+//                      LDS (per-core accumulators + delay ring) before one write-back.
+//                      Reference: process_messages / process_message, src/chip.cpp:656-764;
+//                      AccumulatorModel / AccumulatorWithDelayModel src/models.cpp:71-131.
+//   K3 reduce_kernel   fixed-order reduction of the per-core partials into the timestep
+//                      totals, simple timing model, run totals, t += 1.
+//                      Reference: sim_calculate_ts_energy, sim_update_ts_counters,
+//                      schedule_messages_timestep_simple, src/chip.cpp:1028-1051, 1171-1261;
+//                      src/schedule.cpp:61-102.
+//
+// No MFMA: the path is HBM-bound pointwise work plus an irregular gather.
+// Compile with -ffp-contract=off: the membrane arithmetic must round exactly like the
+// reference's scalar C++ (no fused multiply-add).
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/sanafe_hip.h"
+
+namespace
+{
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+    do                                                                                        \
+    {                                                                                         \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return fail(SANAFE_HIP_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, \
+                    __LINE__);                                                                \
+    } while (0)
+
+constexpr int WAVE = 64;
+constexpr int NEURON_BLOCK = 256;   // 4 wavefronts = 4 simulated cores per workgroup
+constexpr int DELIVER_BLOCK = 256;
+constexpr int AX_PER_THREAD = 4;    // one 16-byte load of ax_pre per lane
+constexpr int DELIVER_BATCH = DELIVER_BLOCK * AX_PER_THREAD;
+constexpr int REDUCE_BLOCK = 256;
+
+// Per-core partial sums written by K1 (one record per core, one writer).
+struct CorePart
+{
+    double e_soma, e_dend, e_syn, e_net, gen_sum;
+    long long updated, fired, packets, hops, events;
+};
+
+struct DevImage
+{
+    uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots;
+    double sync_delay;
+    const uint32_t *core_nbase, *core_ncount;
+    const double *core_axon_out_latency, *core_axon_in_latency;
+    const sanafe_hip_soma_class *soma_classes;
+    const sanafe_hip_cost_class *cost_classes;
+    const uint32_t *slot_cls, *slot_aux, *slot_packets, *slot_hops, *slot_events;
+    const double *slot_bias, *slot_e_net, *slot_e_syn, *slot_e_dend;
+    const uint32_t *in_train_beg, *in_train_len, *in_train_bits;
+    const long long *in_rate_period;
+    const uint32_t *slice_core;
+    const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
+    const uint32_t *core_slice_beg; // [n_cores+1]
+    const uint32_t *ax_pre, *ax_syn_beg, *ax_nsyn;
+    const double *ax_proc_delay;
+    const uint32_t *syn_meta;
+    const double *syn_weight;
+};
+
+struct DevState
+{
+    double *v, *icur;
+    int *refrac;
+    uint8_t *status;
+    uint32_t *in_pos;
+    double *ring;          // [ring_slots][n_slots]
+    uint8_t *ring_valid;   // [ring_slots][n_slots]
+    uint32_t *bits_local;  // [n_slots/32]
+    uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
+    CorePart *core_part;   // [n_cores]
+    double *slice_proc;    // [n_slices]
+    double *core_proc;     // [n_cores]
+    long long *t;          // timesteps simulated so far
+    long long *rec;        // records written so far in this sim
+    sanafe_hip_totals *run;       // run totals
+    sanafe_hip_totals *step_log;  // [log_cap]
+    uint32_t *spike_log;          // [log_cap][n_slots/32]
+    long long log_cap;
+};
+
+__device__ __forceinline__ double wave_sum(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+    return x;
+}
+__device__ __forceinline__ long long wave_sum(long long x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
+    return x;
+}
+
+// static_cast<int>(double) as x86-64 performs it (cvttsd2si): out-of-range and NaN give INT_MIN.
+// The reference quantises with it (src/models.cpp:447-455).
+__device__ __forceinline__ int cvt_int_x86(double x)
+{
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int) 0x80000000;
+    return (int) x;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: neuron update.  grid = ceil(n_cores / 4), block = 256 (wave w <-> core 4*blockIdx+w)
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t core = blockIdx.x * (NEURON_BLOCK / WAVE) + (threadIdx.x >> 6);
+    if (core >= im.n_cores) return;
+    const long long done = *st.t;      // steps simulated before this one
+    const long long t = done + 1;      // Timestep::timestep of this step
+    const uint32_t nbase = im.core_nbase[core];
+    const uint32_t ncount = im.core_ncount[core];
+    const uint32_t rslot = (uint32_t) (t % im.ring_slots);
+    double *ring = st.ring + (size_t) rslot * im.n_slots;
+    uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
+    const long long rec = record ? *st.rec : 0;
+    uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
+
+    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
+    long long n_upd = 0, n_fire = 0, n_pack = 0, n_hops = 0, n_ev = 0;
+
+    for (uint32_t off = 0; off < ncount; off += WAVE)
+    {
+        const uint32_t g = nbase + off + lane;
+        const bool live = (off + lane) < ncount;
+        uint32_t cls = live ? im.slot_cls[g] : 0u;
+        const uint32_t model = cls & 7u;
+        int status = 0;
+        if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
+        {
+            const uint32_t inkind = (cls >> 3) & 7u;
+            const sanafe_hip_cost_class &cc = im.cost_classes[(cls >> 6) & 1023u];
+            // ---- synaptic input from the time-step buffer / delay ring (read, then clear) ----
+            bool has_in;
+            double cur;
+            if (inkind == SANAFE_IN_ZERO)
+            {
+                has_in = true;
+                cur = 0.0;
+            }
+            else
+            {
+                has_in = rvalid[g] != 0;
+                cur = 0.0;
+                if (has_in)
+                {
+                    cur = ring[g];
+                    ring[g] = 0.0;
+                    rvalid[g] = 0;
+                }
+            }
+            const double bias = im.slot_bias[g];
+            if (model == SANAFE_SOMA_LIF)
+            {
+                // LoihiLifModel::update, src/models.cpp:497-567
+                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
+                double v = st.v[g];
+                double ic = st.icur[g];
+                int rc = st.refrac[g];
+                status = 1;
+                if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
+                if (done > 0)
+                {
+                    ic *= p.input_decay;
+                    v *= p.leak_decay;
+                }
+                v = (double) cvt_int_x86(v * 64.0) / 64.0;
+                if (!(rc > 0))
+                {
+                    v += bias;
+                    ic += has_in ? cur : 0.0;
+                    v += ic;
+                    bool fired = false;
+                    if (v > p.threshold)
+                    {
+                        if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
+                        else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
+                        rc = p.refractory_delay;
+                        fired = true;
+                    }
+                    if (v < p.reverse_threshold)
+                    {
+                        if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v -= p.reverse_threshold;
+                        else if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
+                        else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
+                    }
+                    if (fired) status = 3;
+                }
+                rc = rc - 1 > 0 ? rc - 1 : 0;
+                st.v[g] = v;
+                st.icur[g] = ic;
+                st.refrac[g] = rc;
+            }
+            else if (model == SANAFE_SOMA_TRUENORTH)
+            {
+                // TrueNorthModel::update, src/models.cpp:724-830 (random_range_mask == 0)
+                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
+                double v = st.v[g];
+                status = 1;
+                if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
+                if (p.leak_towards_zero)
+                {
+                    if (v > 0.0) v -= p.leak_decay;
+                    else if (v < 0.0) v += p.leak_decay;
+                }
+                else
+                {
+                    v += p.leak_decay;
+                }
+                v += bias;
+                if (has_in) v += cur;
+                if (v >= p.threshold)
+                {
+                    if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
+                    else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
+                    else if (p.reset_mode == SANAFE_RESET_SATURATE) v = p.threshold;
+                    status = 3;
+                }
+                else if (v <= p.reverse_threshold)
+                {
+                    if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
+                    else if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v += p.reverse_threshold;
+                    else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
+                }
+                st.v[g] = v;
+            }
+            else // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903 (poisson == 0)
+            {
+                const uint32_t a = im.slot_aux[g];
+                const uint32_t pos = st.in_pos[a];
+                bool send = false;
+                if (pos < im.in_train_len[a])
+                {
+                    const uint32_t b = im.in_train_beg[a] + pos;
+                    send = (im.in_train_bits[b >> 5] >> (b & 31u)) & 1u;
+                    st.in_pos[a] = pos + 1;
+                }
+                const long long period = im.in_rate_period[a];
+                if (period > 0 && (t % period) == 0) send = true;
+                status = send ? 3 : 1;
+            }
+            // ---- default costing, src/pipeline.hpp:574-731; sums as in execute_pipeline ----
+            e_dend += cc.dendrite_energy;
+            e_soma += cc.soma_energy[status - 1];
+            lat += (0.0 + cc.dendrite_latency) + cc.soma_latency[status - 1];
+            n_upd += status >= 2;
+            if (status == 3)
+            {
+                // everything this spike causes downstream is static per neuron
+                // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
+                n_fire += 1;
+                n_pack += im.slot_packets[g];
+                n_hops += im.slot_hops[g];
+                n_ev += im.slot_events[g];
+                e_net += im.slot_e_net[g];
+                e_syn += im.slot_e_syn[g];
+                e_dend += im.slot_e_dend[g];
+            }
+        }
+        // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
+        // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
+        if (live && model != SANAFE_SOMA_HOST) st.status[g] = (uint8_t) status;
+        const unsigned long long fired_mask = __ballot(status == 3);
+        if (lane == 0)
+        {
+            const uint32_t w = (nbase + off) >> 5;
+            st.bits_local[w] = (uint32_t) fired_mask;
+            st.bits_local[w + 1] = (uint32_t) (fired_mask >> 32);
+            if (record)
+            {
+                slog[w] = (uint32_t) fired_mask;
+                slog[w + 1] = (uint32_t) (fired_mask >> 32);
+            }
+        }
+    }
+    e_soma = wave_sum(e_soma);
+    e_dend = wave_sum(e_dend);
+    e_syn = wave_sum(e_syn);
+    e_net = wave_sum(e_net);
+    lat = wave_sum(lat);
+    n_upd = wave_sum(n_upd);
+    n_fire = wave_sum(n_fire);
+    n_pack = wave_sum(n_pack);
+    n_hops = wave_sum(n_hops);
+    n_ev = wave_sum(n_ev);
+    if (lane == 0)
+    {
+        CorePart cp;
+        cp.e_soma = e_soma;
+        cp.e_dend = e_dend;
+        cp.e_syn = e_syn;
+        cp.e_net = e_net;
+        // sum of Message::generation_delay over the core's messages incl. the placeholder
+        // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81)
+        cp.gen_sum = lat + (double) n_pack * im.core_axon_out_latency[core];
+        cp.updated = n_upd;
+        cp.fired = n_fire;
+        cp.packets = n_pack;
+        cp.hops = n_hops;
+        cp.events = n_ev;
+        st.core_part[core] = cp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: spike delivery.  grid = n_slices, block = 256, dynamic LDS = accumulators
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *wave_tot, uint32_t &total)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    uint32_t incl = x;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1)
+    {
+        const uint32_t y = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += y;
+    }
+    if (lane == WAVE - 1) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    total = 0;
+#pragma unroll
+    for (int w = 0; w < DELIVER_BLOCK / WAVE; w++)
+    {
+        const uint32_t c = wave_tot[w];
+        if (w < wave) base += c;
+        total += c;
+    }
+    __syncthreads();
+    return base + incl - x;
+}
+
+extern __shared__ __align__(16) unsigned char deliver_lds[];
+
+__global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
+{
+    __shared__ uint32_t s_beg[DELIVER_BATCH];      // first synapse of each active axon
+    __shared__ uint32_t s_pref[DELIVER_BATCH + 1]; // exclusive prefix of their synapse counts
+    __shared__ uint32_t s_wave[DELIVER_BLOCK / WAVE];
+    __shared__ double s_red[DELIVER_BLOCK / WAVE];
+
+    const uint32_t slice = blockIdx.x;
+    const uint32_t core = im.slice_core[slice];
+    const uint32_t ncount = im.core_ncount[core];
+    const uint32_t npad = (ncount + 63u) & ~63u;
+    const uint32_t nbase = im.core_nbase[core];
+    const uint32_t R = im.ring_slots;
+    const long long t = *st.t + 1;
+    const unsigned long long a_beg = im.slice_axon_beg[slice], a_end = im.slice_axon_end[slice];
+    const unsigned long long syn_base = im.core_syn_base[core];
+    double *acc = reinterpret_cast<double *>(deliver_lds);                      // [R][npad]
+    uint8_t *touched = deliver_lds + (size_t) im.ring_slots * im.max_core_slots * sizeof(double); // [R][npad]
+
+    for (uint32_t i = threadIdx.x; i < R * npad; i += DELIVER_BLOCK)
+    {
+        acc[i] = 0.0;
+        touched[i] = 0;
+    }
+    __syncthreads();
+
+    double proc = 0.0;
+    const uint32_t *bits = st.bits_global;
+    for (unsigned long long b0 = a_beg; b0 < a_end; b0 += DELIVER_BATCH)
+    {
+        // ---- scan: which of my 4 consecutive inbound axons carry a spike this step? ----
+        const unsigned long long a0 = b0 + (unsigned long long) threadIdx.x * AX_PER_THREAD;
+        uint32_t pre[AX_PER_THREAD];
+        uint32_t amask = 0;
+        if (a0 + AX_PER_THREAD <= a_end && ((a0 & 3ull) == 0))
+        {
+            const uint4 p4 = *reinterpret_cast<const uint4 *>(im.ax_pre + a0);
+            pre[0] = p4.x;
+            pre[1] = p4.y;
+            pre[2] = p4.z;
+            pre[3] = p4.w;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++) amask |= ((bits[pre[k] >> 5] >> (pre[k] & 31u)) & 1u) << k;
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+                if (a0 + k < a_end)
+                {
+                    pre[k] = im.ax_pre[a0 + k];
+                    amask |= ((bits[pre[k] >> 5] >> (pre[k] & 31u)) & 1u) << k;
+                }
+        }
+        uint32_t n_act;
+        uint32_t pos = block_exclusive_scan((uint32_t) __popc(amask), s_wave, n_act);
+        if (n_act == 0) continue; // uniform across the workgroup
+        // ---- compact the active axons, in axon (= reference delivery) order ----
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++)
+            if (amask & (1u << k))
+            {
+                const unsigned long long a = a0 + k;
+                s_beg[pos] = im.ax_syn_beg[a];
+                s_pref[pos] = im.ax_nsyn[a];
+                proc += im.ax_proc_delay[a];
+                pos++;
+            }
+        __syncthreads();
+        // ---- exclusive prefix of synapse counts over the compacted list ----
+        uint32_t cnt[AX_PER_THREAD];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++)
+        {
+            const uint32_t i = threadIdx.x * AX_PER_THREAD + k;
+            cnt[k] = i < n_act ? s_pref[i] : 0u;
+            mine += cnt[k];
+        }
+        uint32_t n_ev;
+        uint32_t run = block_exclusive_scan(mine, s_wave, n_ev);
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++)
+        {
+            const uint32_t i = threadIdx.x * AX_PER_THREAD + k;
+            if (i < n_act) s_pref[i] = run;
+            run += cnt[k];
+        }
+        if (threadIdx.x == 0) s_pref[n_act] = n_ev;
+        __syncthreads();
+        // ---- expand to synaptic events, load-balanced: thread e handles event e ----
+        for (uint32_t e = threadIdx.x; e < n_ev; e += DELIVER_BLOCK)
+        {
+            uint32_t lo = 0, hi = n_act; // largest lo with s_pref[lo] <= e
+            while (hi - lo > 1)
+            {
+                const uint32_t mid = (lo + hi) >> 1;
+                if (s_pref[mid] <= e) lo = mid;
+                else hi = mid;
+            }
+            const unsigned long long s = syn_base + s_beg[lo] + (e - s_pref[lo]);
+            const uint32_t meta = im.syn_meta[s];
+            const double w = im.syn_weight[s];
+            if (!((meta >> 19) & 1u))
+            {
+                const uint32_t post = meta & 0xffffu;
+                const uint32_t d = (meta >> 16) & 7u;
+                const uint32_t wslot = (uint32_t) ((t + 1 + d) % R);
+                const uint32_t idx = wslot * npad + post;
+                atomicAdd(&acc[idx], w); // ds_add_f64
+                touched[idx] = 1;
+            }
+        }
+        __syncthreads();
+    }
+    // ---- write the accumulated charge back (one RMW per touched neuron and slot) ----
+    const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
+    for (uint32_t i = threadIdx.x; i < R * npad; i += DELIVER_BLOCK)
+    {
+        if (!touched[i]) continue;
+        const uint32_t wslot = i / npad, n = i - wslot * npad;
+        const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
+        if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
+        else st.ring[gi] += acc[i];
+        st.ring_valid[gi] = 1;
+    }
+    // ---- processing-delay sum of this slice (simple timing model) ----
+    proc = wave_sum(proc);
+    if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x >> 6] = proc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double p = 0.0;
+        for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
+        st.slice_proc[slice] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: per-step reduction.  one workgroup of 1024 threads, fixed summation order
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ T block_sum(T x, T *scratch)
+{
+    x = wave_sum(x);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = x;
+    __syncthreads();
+    T r = 0;
+    for (int w = 0; w < REDUCE_BLOCK / WAVE; w++) r += scratch[w];
+    return r;
+}
+__device__ double block_max(double x, double *scratch)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, WAVE));
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = x;
+    __syncthreads();
+    double r = scratch[0];
+    for (int w = 1; w < REDUCE_BLOCK / WAVE; w++) r = fmax(r, scratch[w]);
+    return r;
+}
+
+__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, int simple_timing, int record)
+{
+    __shared__ double sd[REDUCE_BLOCK / WAVE];
+    __shared__ long long sl[REDUCE_BLOCK / WAVE];
+    double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
+    long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
+    for (uint32_t c = threadIdx.x; c < im.n_cores; c += REDUCE_BLOCK)
+    {
+        const CorePart cp = st.core_part[c];
+        e_soma += cp.e_soma;
+        e_dend += cp.e_dend;
+        e_syn += cp.e_syn;
+        e_net += cp.e_net;
+        upd += cp.updated;
+        fired += cp.fired;
+        packets += cp.packets;
+        hops += cp.hops;
+        events += cp.events;
+        gmax = fmax(gmax, cp.gen_sum);
+        double p = 0.0;
+        for (uint32_t s = im.core_slice_beg[c]; s < im.core_slice_beg[c + 1]; s++) p += st.slice_proc[s];
+        st.core_proc[c] = p;
+        pmax = fmax(pmax, p);
+    }
+    e_soma = block_sum(e_soma, sd);
+    e_dend = block_sum(e_dend, sd);
+    e_syn = block_sum(e_syn, sd);
+    e_net = block_sum(e_net, sd);
+    upd = block_sum(upd, sl);
+    fired = block_sum(fired, sl);
+    packets = block_sum(packets, sl);
+    hops = block_sum(hops, sl);
+    events = block_sum(events, sl);
+    gmax = block_max(gmax, sd);
+    pmax = block_max(pmax, sd);
+    if (threadIdx.x == 0)
+    {
+        sanafe_hip_totals ts;
+        ts.timesteps = 1;
+        ts.spikes = events;
+        ts.packets_sent = packets;
+        ts.neurons_updated = upd;
+        ts.neurons_fired = fired;
+        ts.total_hops = hops;
+        ts.synapse_energy = e_syn;
+        ts.dendrite_energy = e_dend;
+        ts.soma_energy = e_soma;
+        ts.network_energy = e_net;
+        ts.total_energy = ((e_net + e_syn) + e_dend) + e_soma;
+        ts.sim_time = simple_timing ? fmax(pmax, gmax) + im.sync_delay : 0.0;
+        sanafe_hip_totals r = *st.run; // update_run_data, src/chip.cpp:462-475
+        r.timesteps += 1;
+        r.spikes += ts.spikes;
+        r.packets_sent += ts.packets_sent;
+        r.neurons_updated += ts.neurons_updated;
+        r.neurons_fired += ts.neurons_fired;
+        r.total_hops += ts.total_hops;
+        r.total_energy += ts.total_energy;
+        r.synapse_energy += ts.synapse_energy;
+        r.dendrite_energy += ts.dendrite_energy;
+        r.soma_energy += ts.soma_energy;
+        r.network_energy += ts.network_energy;
+        r.sim_time += ts.sim_time;
+        *st.run = r;
+        if (record)
+        {
+            const long long rec = *st.rec;
+            ts.timesteps = *st.t + 1; // the record carries the timestep number
+            st.step_log[rec % st.log_cap] = ts;
+            *st.rec = rec + 1;
+        }
+        *st.t = *st.t + 1;
+    }
+}
+
+__global__ void fill_double(double *p, size_t n, double v)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// Host-evaluated soma units (plugins): apply the statuses the host computed for this step.
+__global__ void host_status_kernel(DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t g = slots[i];
+    st.status[g] = status[i];
+    if (status[i] == 3) atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
+}
+} // namespace
+
+// ---------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ---------------------------------------------------------------------------------------
+struct sanafe_hip_chip
+{
+    int device{0};
+    hipStream_t stream{nullptr};
+    DevImage im{};
+    DevState st{};
+    std::vector<void *> allocs;
+    size_t deliver_lds{0};
+    uint32_t neuron_grid{0};
+    long long rec_host{0};
+    bool timing{false};
+    double t_neuron{0}, t_deliver{0}, t_reduce{0};
+    long long t_launches{0};
+    std::vector<double> v0;
+    uint32_t *d_host_slots{nullptr};
+    uint8_t *d_host_status{nullptr};
+    uint32_t host_cap{0};
+};
+
+namespace
+{
+template <typename T> int upload(sanafe_hip_chip *c, const T *src, size_t n, const T **dst)
+{
+    *dst = nullptr;
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (n > 0)
+    {
+        if (src == nullptr) return fail(SANAFE_HIP_ERR_INVALID, "image array is NULL but its count is %zu", n);
+        HIPCHK(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice));
+    }
+    *dst = static_cast<const T *>(p);
+    return 0;
+}
+template <typename T> int dalloc(sanafe_hip_chip *c, size_t n, T **dst, bool zero = true)
+{
+    const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, bytes));
+    c->allocs.push_back(p);
+    if (zero) HIPCHK(hipMemset(p, 0, bytes));
+    *dst = static_cast<T *>(p);
+    return 0;
+}
+#define TRY(expr)            \
+    do                       \
+    {                        \
+        int rc_ = (expr);    \
+        if (rc_ != 0) return rc_; \
+    } while (0)
+
+int validate(const sanafe_hip_image *im)
+{
+    if (im->n_cores == 0) return fail(SANAFE_HIP_ERR_INVALID, "image has no cores");
+    if (im->n_slots % 64 != 0) return fail(SANAFE_HIP_ERR_INVALID, "n_slots must be a multiple of 64");
+    if (im->ring_slots < 1 || im->ring_slots > 8) return fail(SANAFE_HIP_ERR_INVALID, "ring_slots out of range");
+    if (im->n_cost_classes == 0 || im->n_cost_classes > 1024)
+        return fail(SANAFE_HIP_ERR_INVALID, "cost classes must be 1..1024");
+    if (im->n_soma_classes == 0 || im->n_soma_classes > 65536)
+        return fail(SANAFE_HIP_ERR_INVALID, "soma classes must be 1..65536");
+    if (im->n_global_slots % 64 != 0 || im->slot_offset % 64 != 0 ||
+            (uint64_t) im->slot_offset + im->n_slots > im->n_global_slots)
+        return fail(SANAFE_HIP_ERR_INVALID, "bad global slot window");
+    uint64_t next = 0;
+    for (uint32_t c = 0; c < im->n_cores; c++)
+    {
+        if (im->core_nbase[c] % 64 != 0 || im->core_nbase[c] < next)
+            return fail(SANAFE_HIP_ERR_INVALID, "core %u: slots must be 64-aligned and ascending", c);
+        next = (uint64_t) im->core_nbase[c] + ((im->core_ncount[c] + 63u) & ~63u);
+        if (next > im->n_slots) return fail(SANAFE_HIP_ERR_INVALID, "core %u overruns n_slots", c);
+        if (im->core_ncount[c] > 65536) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "core %u has more than 65536 neurons", c);
+    }
+    for (uint32_t s = 0; s < im->n_slices; s++)
+    {
+        if (im->slice_core[s] >= im->n_cores) return fail(SANAFE_HIP_ERR_INVALID, "slice %u: bad core", s);
+        if (s > 0 && im->slice_core[s] < im->slice_core[s - 1])
+            return fail(SANAFE_HIP_ERR_INVALID, "slices must be sorted by core");
+        if (im->slice_axon_beg[s] > im->slice_axon_end[s] || im->slice_axon_end[s] > im->n_axons)
+            return fail(SANAFE_HIP_ERR_INVALID, "slice %u: bad axon range", s);
+    }
+    // Bounds of every index the kernels dereference: a bad image must fail here, not fault on the GPU.
+    for (uint64_t s = 0; s < im->n_slices; s++)
+    {
+        const uint32_t core = im->slice_core[s];
+        const uint64_t core_syn_end = (core + 1 < im->n_cores) ? im->core_syn_base[core + 1] : im->n_synapses;
+        for (uint64_t a = im->slice_axon_beg[s]; a < im->slice_axon_end[s]; a++)
+        {
+            if (im->ax_pre[a] >= im->n_global_slots) return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: bad pre slot", (unsigned long long) a);
+            if (im->core_syn_base[core] + im->ax_syn_beg[a] + im->ax_nsyn[a] > core_syn_end)
+                return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: synapse range leaves its core", (unsigned long long) a);
+            const uint64_t sb = im->core_syn_base[core] + im->ax_syn_beg[a];
+            for (uint32_t k = 0; k < im->ax_nsyn[a]; k++)
+                if ((im->syn_meta[sb + k] & 0xffffu) >= im->core_ncount[core])
+                    return fail(SANAFE_HIP_ERR_INVALID, "synapse %llu: post neuron outside its core", (unsigned long long) (sb + k));
+        }
+    }
+    for (uint32_t g = 0; g < im->n_slots; g++)
+    {
+        const uint32_t cls = im->slot_cls[g], model = cls & 7u;
+        if (model > SANAFE_SOMA_HOST) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma model", g);
+        if (model == SANAFE_SOMA_NONE) continue;
+        if (((cls >> 6) & 1023u) >= im->n_cost_classes) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad cost class", g);
+        if ((model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH) && (cls >> 16) >= im->n_soma_classes)
+            return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
+        if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
+            return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
+    }
+    for (uint32_t i = 0; i < im->n_input; i++)
+        if ((uint64_t) im->in_train_beg[i] + im->in_train_len[i] > im->n_train_words * 32ull)
+            return fail(SANAFE_HIP_ERR_INVALID, "input %u: spike train outside in_train_bits", i);
+    return 0;
+}
+} // namespace
+
+extern "C" const char *sanafe_hip_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sanafe_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device, sanafe_hip_chip **out)
+{
+    if (!image || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (sanafe_hip_device_count() <= device)
+        return fail(SANAFE_HIP_ERR_NO_DEVICE, "no HIP device %d (libsanafe_hip has no CPU fallback)", device);
+    TRY(validate(image));
+    auto *c = new sanafe_hip_chip();
+    c->device = device;
+    auto bail = [&](int rc) {
+        sanafe_hip_chip_destroy(c);
+        return rc;
+    };
+#define TRYC(expr)                    \
+    do                                \
+    {                                 \
+        int rc2_ = (expr);            \
+        if (rc2_ != 0) return bail(rc2_); \
+    } while (0)
+#define HIPC(expr)                                                                                       \
+    do                                                                                                   \
+    {                                                                                                    \
+        hipError_t e2_ = (expr);                                                                         \
+        if (e2_ != hipSuccess)                                                                           \
+            return bail(fail(SANAFE_HIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e2_)));       \
+    } while (0)
+    HIPC(hipSetDevice(device));
+    HIPC(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    const sanafe_hip_image &h = *image;
+    DevImage &im = c->im;
+    im.n_cores = h.n_cores;
+    im.n_slots = h.n_slots;
+    im.ring_slots = h.ring_slots;
+    im.n_slices = h.n_slices;
+    im.n_input = h.n_input;
+    im.slot_offset = h.slot_offset;
+    im.n_global_slots = h.n_global_slots;
+    im.sync_delay = h.sync_delay;
+    uint32_t max_pad = 64;
+    for (uint32_t k = 0; k < h.n_cores; k++) max_pad = std::max(max_pad, (h.core_ncount[k] + 63u) & ~63u);
+    im.max_core_slots = max_pad;
+    TRYC(upload(c, h.core_nbase, h.n_cores, &im.core_nbase));
+    TRYC(upload(c, h.core_ncount, h.n_cores, &im.core_ncount));
+    TRYC(upload(c, h.core_axon_out_latency, h.n_cores, &im.core_axon_out_latency));
+    TRYC(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_axon_in_latency));
+    TRYC(upload(c, h.soma_classes, h.n_soma_classes, &im.soma_classes));
+    TRYC(upload(c, h.cost_classes, h.n_cost_classes, &im.cost_classes));
+    TRYC(upload(c, h.slot_cls, h.n_slots, &im.slot_cls));
+    TRYC(upload(c, h.slot_bias, h.n_slots, &im.slot_bias));
+    TRYC(upload(c, h.slot_aux, h.n_slots, &im.slot_aux));
+    TRYC(upload(c, h.slot_packets, h.n_slots, &im.slot_packets));
+    TRYC(upload(c, h.slot_hops, h.n_slots, &im.slot_hops));
+    TRYC(upload(c, h.slot_events, h.n_slots, &im.slot_events));
+    TRYC(upload(c, h.slot_e_net, h.n_slots, &im.slot_e_net));
+    TRYC(upload(c, h.slot_e_syn, h.n_slots, &im.slot_e_syn));
+    TRYC(upload(c, h.slot_e_dend, h.n_slots, &im.slot_e_dend));
+    TRYC(upload(c, h.in_train_beg, h.n_input, &im.in_train_beg));
+    TRYC(upload(c, h.in_train_len, h.n_input, &im.in_train_len));
+    TRYC(upload(c, reinterpret_cast<const long long *>(h.in_rate_period), h.n_input, &im.in_rate_period));
+    TRYC(upload(c, h.in_train_bits, h.n_train_words, &im.in_train_bits));
+    TRYC(upload(c, h.slice_core, h.n_slices, &im.slice_core));
+    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_beg), h.n_slices, &im.slice_axon_beg));
+    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_end), h.n_slices, &im.slice_axon_end));
+    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.core_syn_base), h.n_cores, &im.core_syn_base));
+    TRYC(upload(c, h.ax_pre, h.n_axons, &im.ax_pre));
+    TRYC(upload(c, h.ax_syn_beg, h.n_axons, &im.ax_syn_beg));
+    TRYC(upload(c, h.ax_nsyn, h.n_axons, &im.ax_nsyn));
+    TRYC(upload(c, h.ax_proc_delay, h.n_axons, &im.ax_proc_delay));
+    TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
+    TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
+    {
+        std::vector<uint32_t> beg(h.n_cores + 1, 0);
+        for (uint32_t s = 0; s < h.n_slices; s++) beg[h.slice_core[s] + 1]++;
+        for (uint32_t k = 0; k < h.n_cores; k++) beg[k + 1] += beg[k];
+        TRYC(upload(c, beg.data(), beg.size(), &im.core_slice_beg));
+    }
+    DevState &st = c->st;
+    TRYC(dalloc(c, h.n_slots, &st.v));
+    TRYC(dalloc(c, h.n_slots, &st.icur));
+    TRYC(dalloc(c, h.n_slots, &st.refrac));
+    TRYC(dalloc(c, h.n_slots, &st.status));
+    TRYC(dalloc(c, h.n_input, &st.in_pos));
+    TRYC(dalloc(c, (size_t) h.ring_slots * h.n_slots, &st.ring));
+    TRYC(dalloc(c, (size_t) h.ring_slots * h.n_slots, &st.ring_valid));
+    TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
+    if (h.n_global_slots == h.n_slots) st.bits_global = st.bits_local;
+    else TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
+    TRYC(dalloc(c, h.n_cores, &st.core_part));
+    TRYC(dalloc(c, h.n_slices, &st.slice_proc));
+    TRYC(dalloc(c, h.n_cores, &st.core_proc));
+    TRYC(dalloc(c, 1, &st.t));
+    TRYC(dalloc(c, 1, &st.rec));
+    TRYC(dalloc(c, 1, &st.run));
+    st.step_log = nullptr;
+    st.spike_log = nullptr;
+    st.log_cap = 1;
+    if (h.slot_v0)
+    {
+        c->v0.assign(h.slot_v0, h.slot_v0 + h.n_slots);
+        HIPC(hipMemcpy(st.v, h.slot_v0, (size_t) h.n_slots * sizeof(double), hipMemcpyHostToDevice));
+    }
+    c->neuron_grid = (h.n_cores + (NEURON_BLOCK / WAVE) - 1) / (NEURON_BLOCK / WAVE);
+    c->deliver_lds = (size_t) h.ring_slots * max_pad * (sizeof(double) + 1);
+    if (c->deliver_lds + 9 * 1024 > 160 * 1024)
+        return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay slots needs %zu B of LDS (> 160 KiB)",
+                max_pad, h.ring_slots, c->deliver_lds));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (int) c->deliver_lds));
+    HIPC(hipDeviceSynchronize());
+    *out = c;
+    return 0;
+}
+
+extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
+{
+    if (!c) return;
+    (void) hipSetDevice(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    for (void *p : c->allocs) (void) hipFree(p);
+    if (c->st.step_log) (void) hipFree(c->st.step_log);
+    if (c->st.spike_log) (void) hipFree(c->st.spike_log);
+    if (c->d_host_slots) (void) hipFree(c->d_host_slots);
+    if (c->d_host_status) (void) hipFree(c->d_host_status);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static int ensure_log(sanafe_hip_chip *c, long long steps)
+{
+    if (c->st.step_log && c->st.log_cap >= steps) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->st.step_log) HIPCHK(hipFree(c->st.step_log));
+    if (c->st.spike_log) HIPCHK(hipFree(c->st.spike_log));
+    c->st.step_log = nullptr;
+    c->st.spike_log = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.step_log), (size_t) steps * sizeof(sanafe_hip_totals)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.spike_log), (size_t) steps * (c->im.n_slots / 32) * sizeof(uint32_t)));
+    c->st.log_cap = steps;
+    return 0;
+}
+
+static int launch_neurons(sanafe_hip_chip *c, int record)
+{
+    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+static int launch_deliver(sanafe_hip_chip *c)
+{
+    if (c->im.n_slices > 0)
+    {
+        hipLaunchKernelGGL(deliver_kernel, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+static int launch_reduce(sanafe_hip_chip *c, int simple_timing, int record)
+{
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(REDUCE_BLOCK), 0, c->stream, c->im, c->st, simple_timing, record);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_timing, int record)
+{
+    if (!c || n_steps < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    if (record)
+    {
+        TRY(ensure_log(c, n_steps));
+        HIPCHK(hipMemsetAsync(c->st.rec, 0, sizeof(long long), c->stream));
+    }
+    if (!c->timing)
+    {
+        for (int64_t s = 0; s < n_steps; s++)
+        {
+            TRY(launch_neurons(c, record));
+            TRY(launch_deliver(c));
+            TRY(launch_reduce(c, simple_timing, record));
+        }
+        return 0;
+    }
+    // Timed mode (bench.py roofline block): HIP events on the kernels' own stream.
+    std::vector<hipEvent_t> ev((size_t) n_steps * 4);
+    for (auto &e : ev) HIPCHK(hipEventCreate(&e));
+    for (int64_t s = 0; s < n_steps; s++)
+    {
+        HIPCHK(hipEventRecord(ev[s * 4 + 0], c->stream));
+        TRY(launch_neurons(c, record));
+        HIPCHK(hipEventRecord(ev[s * 4 + 1], c->stream));
+        TRY(launch_deliver(c));
+        HIPCHK(hipEventRecord(ev[s * 4 + 2], c->stream));
+        TRY(launch_reduce(c, simple_timing, record));
+        HIPCHK(hipEventRecord(ev[s * 4 + 3], c->stream));
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (int64_t s = 0; s < n_steps; s++)
+    {
+        float a = 0, b = 0, d = 0;
+        HIPCHK(hipEventElapsedTime(&a, ev[s * 4 + 0], ev[s * 4 + 1]));
+        HIPCHK(hipEventElapsedTime(&b, ev[s * 4 + 1], ev[s * 4 + 2]));
+        HIPCHK(hipEventElapsedTime(&d, ev[s * 4 + 2], ev[s * 4 + 3]));
+        c->t_neuron += a;
+        c->t_deliver += b;
+        c->t_reduce += d;
+    }
+    c->t_launches += n_steps;
+    for (auto &e : ev) (void) hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int sanafe_hip_synchronize(sanafe_hip_chip *c)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_step_neurons(sanafe_hip_chip *c)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    return launch_neurons(c, 0);
+}
+
+extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, int record)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    if (record) TRY(ensure_log(c, 1));
+    TRY(launch_deliver(c));
+    return launch_reduce(c, simple_timing, 0);
+}
+
+extern "C" int sanafe_hip_spike_buffers(sanafe_hip_chip *c, void **local_bits, uint64_t *local_bytes, void **global_bits,
+        uint64_t *global_bytes)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (local_bits) *local_bits = c->st.bits_local;
+    if (local_bytes) *local_bytes = (uint64_t) c->im.n_slots / 8;
+    if (global_bits) *global_bits = c->st.bits_global;
+    if (global_bytes) *global_bytes = (uint64_t) c->im.n_global_slots / 8;
+    return 0;
+}
+
+extern "C" void *sanafe_hip_stream(sanafe_hip_chip *c) { return c ? c->stream : nullptr; }
+
+template <typename T> static int d2h(sanafe_hip_chip *c, T *dst, const T *src, size_t n)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(dst, src, n * sizeof(T), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+template <typename T> static int h2d(sanafe_hip_chip *c, T *dst, const T *src, size_t n)
+{
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int sanafe_hip_read_totals(sanafe_hip_chip *c, sanafe_hip_totals *out)
+{
+    if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return d2h(c, out, c->st.run, 1);
+}
+extern "C" int sanafe_hip_reset_totals(sanafe_hip_chip *c)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->st.run, 0, sizeof(sanafe_hip_totals), c->stream));
+    return 0;
+}
+extern "C" int sanafe_hip_read_step_totals(sanafe_hip_chip *c, int64_t first, int64_t count, sanafe_hip_totals *out)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.step_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "step records [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    return d2h(c, out, c->st.step_log + first, (size_t) count);
+}
+extern "C" int sanafe_hip_read_step_spikes(sanafe_hip_chip *c, int64_t index, uint32_t *bits_out)
+{
+    if (!c || !bits_out || index < 0 || index >= c->st.log_cap || !c->st.spike_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "spike record %lld not available", (long long) index);
+    const size_t words = c->im.n_slots / 32;
+    return d2h(c, bits_out, c->st.spike_log + (size_t) index * words, words);
+}
+extern "C" int sanafe_hip_read_status(sanafe_hip_chip *c, uint8_t *out)
+{
+    if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return d2h(c, out, c->st.status, c->im.n_slots);
+}
+extern "C" int sanafe_hip_read_potentials(sanafe_hip_chip *c, double *out)
+{
+    if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return d2h(c, out, c->st.v, c->im.n_slots);
+}
+extern "C" int sanafe_hip_read_input_current(sanafe_hip_chip *c, double *out)
+{
+    if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return d2h(c, out, c->st.icur, c->im.n_slots);
+}
+extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, double *proc_sum)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (gen_sum)
+    {
+        std::vector<CorePart> cp(c->im.n_cores);
+        TRY(d2h(c, cp.data(), c->st.core_part, cp.size()));
+        for (uint32_t k = 0; k < c->im.n_cores; k++) gen_sum[k] = cp[k].gen_sum;
+    }
+    if (proc_sum) TRY(d2h(c, proc_sum, c->st.core_proc, c->im.n_cores));
+    return 0;
+}
+
+extern "C" int sanafe_hip_write_bias(sanafe_hip_chip *c, uint32_t first, uint32_t count, const double *bias)
+{
+    if (!c || !bias || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
+    return h2d(c, const_cast<double *>(c->im.slot_bias) + first, bias, count);
+}
+extern "C" int sanafe_hip_write_potential(sanafe_hip_chip *c, uint32_t first, uint32_t count, const double *v)
+{
+    if (!c || !v || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
+    return h2d(c, c->st.v + first, v, count);
+}
+extern "C" int sanafe_hip_write_slot_class(sanafe_hip_chip *c, uint32_t first, uint32_t count, const uint32_t *cls)
+{
+    if (!c || !cls || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
+    return h2d(c, const_cast<uint32_t *>(c->im.slot_cls) + first, cls, count);
+}
+extern "C" int sanafe_hip_write_soma_classes(sanafe_hip_chip *c, uint32_t n, const sanafe_hip_soma_class *classes)
+{
+    if (!c || !classes || n == 0 || n > 65536) return fail(SANAFE_HIP_ERR_INVALID, "bad class table");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    void *p = nullptr;
+    HIPCHK(hipMalloc(&p, (size_t) n * sizeof(sanafe_hip_soma_class)));
+    c->allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, classes, (size_t) n * sizeof(sanafe_hip_soma_class), hipMemcpyHostToDevice));
+    c->im.soma_classes = static_cast<const sanafe_hip_soma_class *>(p);
+    return 0;
+}
+extern "C" int sanafe_hip_write_host_status(sanafe_hip_chip *c, uint32_t count, const uint32_t *slots, const uint8_t *status)
+{
+    if (!c || (count > 0 && (!slots || !status))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++)
+        if (slots[i] >= c->im.n_slots || status[i] > 3) return fail(SANAFE_HIP_ERR_INVALID, "bad host status entry %u", i);
+    if (c->host_cap < count)
+    {
+        if (c->d_host_slots) HIPCHK(hipFree(c->d_host_slots));
+        if (c->d_host_status) HIPCHK(hipFree(c->d_host_status));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_slots), (size_t) count * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_status), (size_t) count));
+        c->host_cap = count;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_host_slots, slots, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_host_status, status, (size_t) count, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->st, count, c->d_host_slots,
+            c->d_host_status);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    const size_t n = c->im.n_slots;
+    HIPCHK(hipMemsetAsync(c->st.v, 0, n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->st.icur, 0, n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->st.status, 0, n, c->stream));
+    HIPCHK(hipMemsetAsync(c->st.ring, 0, (size_t) c->im.ring_slots * n * sizeof(double), c->stream));
+    HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_set_timing(sanafe_hip_chip *c, int enabled)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    c->timing = enabled != 0;
+    c->t_neuron = c->t_deliver = c->t_reduce = 0.0;
+    c->t_launches = 0;
+    return 0;
+}
+extern "C" int sanafe_hip_read_timing(sanafe_hip_chip *c, double *neuron_ms, double *deliver_ms, double *reduce_ms,
+        int64_t *launches)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    const double n = c->t_launches > 0 ? (double) c->t_launches : 1.0;
+    if (neuron_ms) *neuron_ms = c->t_neuron / n;
+    if (deliver_ms) *deliver_ms = c->t_deliver / n;
+    if (reduce_ms) *reduce_ms = c->t_reduce / n;
+    if (launches) *launches = c->t_launches;
+    return 0;
+}

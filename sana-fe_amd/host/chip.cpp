@@ -1,0 +1,595 @@
+// chip.cpp -- host runtime of the MI355X path: implements include/sanafe_host.h.
+//
+// Owns the mapped network, the device chip (libsanafe_hip.so) and the host-side
+// timing models.  Mirrors SpikingChip::sim / step / reset / get_* (src/chip.cpp:477-621,
+// 1766-1831) and, for `detailed` timing, schedule_messages_timestep_detailed
+// (src/schedule.cpp:208-620), which is an inherently serial discrete-event simulation the
+// reference also runs on the CPU.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <list>
+#include <memory>
+#include <queue>
+#include <string>
+#include <vector>
+
+#include "../../include/sanafe_host.h"
+#include "mapper.hpp"
+
+using sanafe_amd::MappedChip;
+
+namespace
+{
+thread_local std::string g_err;
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+#define DEV(expr)                                                       \
+    do                                                                  \
+    {                                                                   \
+        int rc_ = (expr);                                               \
+        if (rc_ != 0) return fail(rc_, sanafe_hip_last_error());        \
+    } while (0)
+
+constexpr double NEG_INF = -std::numeric_limits<double>::infinity();
+
+struct Msg : sanafe_message
+{
+    bool in_noc{false};
+    int64_t src_x{0}, src_y{0}, dest_x{0}, dest_y{0};
+};
+} // namespace
+
+struct sanafe_chip
+{
+    MappedChip mc;
+    sanafe_hip_chip *dev{nullptr};
+    int64_t n_neurons{0};
+    int64_t total_timesteps{0};
+    int64_t total_messages_sent{0};
+    double total_energy{0.0}, total_sim_time{0.0};
+    // records of the last sim()
+    bool have_records{false};
+    int64_t rec_first_timestep{0}, rec_count{0};
+    std::vector<sanafe_hip_totals> rec_totals;
+    std::vector<std::vector<Msg>> rec_messages; // per recorded step, per-source-core order
+    std::vector<std::vector<uint32_t>> rec_spike_bits;
+    // host copies of the per-slot cost classes (for generation delays)
+    std::vector<double> slot_lat[3];
+
+    // ------------------------------------------------------------------------------
+    // Rebuild one timestep's messages from the spike bitmap + per-slot status.
+    // process_neurons / pipeline_process_axon_out / receive_message, src/chip.cpp:624-654,
+    // 694-708, 802-834: per core, neurons in mapped order; latencies accumulate into
+    // next_message_generation_delay; the first message of a firing neuron carries it.
+    // ------------------------------------------------------------------------------
+    void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<Msg>> &per_core)
+    {
+        per_core.assign(mc.n_cores, {});
+        for (uint32_t c = 0; c < mc.n_cores; c++)
+        {
+            double next_delay = 0.0;
+            const uint32_t base = mc.core_nbase[c];
+            const uint32_t st = mc.core_tile[c];
+            const double lat_access = mc.core_axon_out_latency[c];
+            int64_t last_gid = -1;
+            for (uint32_t k = 0; k < mc.core_ncount[c]; k++)
+            {
+                const uint32_t s = base + k;
+                const uint8_t stat = status[s];
+                if (stat == 0) continue;
+                last_gid = mc.gid_of_slot[s];
+                next_delay += slot_lat[stat - 1][s];
+                if (stat != 3) continue;
+                for (uint64_t o = mc.out_ptr[s]; o < mc.out_ptr[s + 1]; o++)
+                {
+                    const uint64_t a = mc.out_axon[o];
+                    Msg m{};
+                    m.timestep = timestep;
+                    m.mid = total_messages_sent++;
+                    m.src_neuron = mc.gid_of_slot[s];
+                    m.src_tile = st;
+                    m.src_core_id = c;
+                    m.src_core_offset = mc.core_offset[c];
+                    m.src_x = mc.tile_x[st];
+                    m.src_y = mc.tile_y[st];
+                    const uint32_t dc = mc.ax_dest_core[a];
+                    const uint32_t dt = mc.core_tile[dc];
+                    m.dest_tile = dt;
+                    m.dest_core_id = dc;
+                    m.dest_core_offset = mc.core_offset[dc];
+                    m.dest_x = mc.tile_x[dt];
+                    m.dest_y = mc.tile_y[dt];
+                    m.dest_axon_id = mc.ax_dest_axon_id[a];
+                    m.hops = mc.ax_hops[a];
+                    m.spikes = mc.ax_nsyn[a];
+                    m.placeholder = 0;
+                    m.generation_delay = next_delay + lat_access;
+                    next_delay = 0.0;
+                    m.processing_delay = mc.ax_proc_delay[a];
+                    m.min_hop_delay = mc.ax_min_hop_delay[a];
+                    m.sent_timestamp = m.received_timestamp = m.processed_timestamp = NEG_INF;
+                    per_core[c].push_back(m);
+                }
+            }
+            if (next_delay != 0.0) // placeholder, src/chip.cpp:640-652
+            {
+                Msg m{};
+                m.timestep = timestep;
+                m.mid = -1;
+                m.src_neuron = last_gid;
+                m.src_tile = st;
+                m.src_core_id = c;
+                m.src_core_offset = mc.core_offset[c];
+                m.src_x = mc.tile_x[st];
+                m.src_y = mc.tile_y[st];
+                m.placeholder = 1;
+                m.generation_delay = next_delay;
+                m.sent_timestamp = m.received_timestamp = m.processed_timestamp = NEG_INF;
+                per_core[c].push_back(m);
+            }
+        }
+    }
+
+    // ---- detailed timing model: src/schedule.cpp:208-620 ----
+    struct Noc
+    {
+        std::vector<std::list<Msg>> received;
+        size_t w, h, max_cpt;
+        std::vector<double> density, core_finished;
+        double mean_delay{0.0};
+        long in_noc{0};
+        size_t idx(size_t x, size_t y, size_t link) const
+        {
+            const size_t lpr = max_cpt + 4; // src/schedule.hpp:190-195
+            return (x * h * lpr) + (y * lpr) + link;
+        }
+    };
+    template <typename F> static void walk_route(const Noc &noc, const Msg &m, F &&visit)
+    {
+        // dimension-order route; NocInfo::update_message_density / calculate_route_congestion,
+        // src/schedule.cpp:478-611 (directions: north 0, east 1, south 2, west 3)
+        const int xi = (m.src_x < m.dest_x) ? 1 : -1, yi = (m.src_y < m.dest_y) ? 1 : -1;
+        const size_t own = 4 + m.src_core_offset;
+        size_t prev = own;
+        for (int64_t x = m.src_x; x != m.dest_x; x += xi)
+        {
+            const size_t dir = (xi > 0) ? 1 : 3;
+            visit(noc.idx(x, m.src_y, x == m.src_x ? own : dir));
+            prev = dir;
+        }
+        for (int64_t y = m.src_y; y != m.dest_y; y += yi)
+        {
+            const size_t dir = (yi > 0) ? 0 : 2;
+            visit(noc.idx(m.dest_x, y, (m.src_x == m.dest_x && y == m.src_y) ? own : prev));
+            prev = dir;
+        }
+        visit(noc.idx(m.dest_x, m.dest_y, (m.src_x == m.dest_x && m.src_y == m.dest_y) ? own : prev));
+    }
+    static void track(Noc &noc, const Msg &m, bool entering)
+    {
+        if (static_cast<size_t>(m.src_x) > noc.w || static_cast<size_t>(m.dest_x) > noc.w)
+            throw std::runtime_error("Message x > NoC width");
+        if (static_cast<size_t>(m.src_y) > noc.h || static_cast<size_t>(m.dest_y) > noc.h)
+            throw std::runtime_error("Message y > NoC height");
+        double adjust = 1.0 / (2.0 + static_cast<double>(m.hops));
+        if (!entering) adjust *= -1.0;
+        walk_route(noc, m, [&](size_t i) { noc.density[i] += adjust; });
+        if (entering) // update_rolling_averages, src/schedule.cpp:449-476
+        {
+            noc.mean_delay += (m.processing_delay - noc.mean_delay) / (static_cast<double>(noc.in_noc) + 1.0);
+            noc.in_noc++;
+        }
+        else
+        {
+            if (noc.in_noc > 1) noc.mean_delay += (noc.mean_delay - m.processing_delay) / (static_cast<double>(noc.in_noc) - 1.0);
+            else noc.mean_delay = 0.0;
+            noc.in_noc--;
+        }
+    }
+    struct BySent
+    {
+        bool operator()(const Msg &a, const Msg &b) const noexcept { return a.sent_timestamp > b.sent_timestamp; }
+    };
+    double schedule_detailed(std::vector<std::vector<Msg>> &per_core)
+    {
+        Noc noc;
+        noc.w = mc.noc_width;
+        noc.h = mc.noc_height;
+        noc.max_cpt = mc.max_cores_per_tile;
+        noc.received.resize(mc.n_cores);
+        noc.core_finished.assign(mc.n_cores, 0.0);
+        noc.density.assign(static_cast<size_t>(mc.noc_height) * mc.noc_width * (4 + mc.max_cores_per_tile), 0.0);
+        std::vector<size_t> head(mc.n_cores, 0);
+        std::vector<std::vector<Msg>> scheduled(mc.n_cores);
+        std::priority_queue<Msg, std::vector<Msg>, BySent> pq;
+        for (uint32_t c = 0; c < mc.n_cores; c++)
+            if (!per_core[c].empty())
+            {
+                Msg m = per_core[c][head[c]++];
+                m.sent_timestamp = m.generation_delay;
+                pq.push(m);
+            }
+        double last = 0.0;
+        while (!pq.empty())
+        {
+            Msg m = pq.top();
+            pq.pop();
+            last = std::max(last, m.sent_timestamp);
+            const double tnow = m.sent_timestamp;
+            for (auto &q : noc.received) // noc_update_all_tracked_messages
+                q.remove_if([&](Msg &r) {
+                    if (r.in_noc && tnow >= r.received_timestamp)
+                    {
+                        r.in_noc = false;
+                        track(noc, r, false);
+                        return true;
+                    }
+                    return false;
+                });
+            if (!m.placeholder) // schedule_handle_message
+            {
+                const size_t dc = m.dest_core_id;
+                double flow = 0.0;
+                walk_route(noc, m, [&](size_t i) { flow += noc.density[i]; });
+                m.messages_along_route = flow;
+                const double cap = static_cast<double>((m.hops + 1UL) * mc.noc_buffer);
+                if (m.messages_along_route > cap)
+                {
+                    m.blocking_delay = (m.messages_along_route - cap) * noc.mean_delay;
+                    m.sent_timestamp += m.blocking_delay;
+                }
+                else
+                {
+                    m.blocking_delay = 0.0;
+                }
+                const double congestion = m.messages_along_route * noc.mean_delay / (static_cast<double>(m.hops) + 1.0);
+                m.network_delay = std::max(m.min_hop_delay, congestion);
+                const double earliest = m.sent_timestamp + m.network_delay;
+                m.received_timestamp = std::max(noc.core_finished[dc], earliest);
+                noc.core_finished[dc] = std::max(noc.core_finished[dc] + m.processing_delay, earliest + m.processing_delay);
+                m.processed_timestamp = noc.core_finished[dc];
+                m.in_noc = true;
+                noc.received[dc].push_back(m);
+                track(noc, m, true);
+                last = std::max(last, m.processed_timestamp);
+            }
+            const size_t sc = m.src_core_id;
+            if (head[sc] < per_core[sc].size()) // schedule_push_next_message
+            {
+                Msg nx = per_core[sc][head[sc]++];
+                nx.sent_timestamp = m.sent_timestamp + nx.generation_delay;
+                pq.push(nx);
+                last = std::max(last, nx.sent_timestamp);
+            }
+            scheduled[sc].push_back(m);
+        }
+        per_core.swap(scheduled);
+        return last + mc.sync_delay;
+    }
+};
+
+extern "C" const char *sanafe_last_error(void) { return g_err.c_str(); }
+
+extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ranks, int rank, sanafe_chip **out)
+{
+    if (!desc || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    *out = nullptr;
+    auto chip = std::make_unique<sanafe_chip>();
+    try
+    {
+        sanafe_amd::map_and_lower(*desc, n_ranks, rank, 2048, chip->mc);
+    }
+    catch (const sanafe_amd::UnsupportedError &e)
+    {
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, std::string("UnsupportedError: ") + e.what());
+    }
+    catch (const sanafe_amd::HardwareMappingError &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, std::string("HardwareMappingError: ") + e.what());
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    chip->n_neurons = desc->n_neurons;
+    const sanafe_hip_image im = chip->mc.image();
+    if (device >= 0) DEV(sanafe_hip_chip_create(&im, device, &chip->dev)); // device < 0: map only (CPU-side checks)
+    // per-slot neuron-pipeline latency by status, for the host-side generation delays
+    const MappedChip &mc = chip->mc;
+    if (n_ranks == 1)
+    {
+        for (int k = 0; k < 3; k++) chip->slot_lat[k].assign(mc.n_global_slots, 0.0);
+        for (uint32_t s = 0; s < mc.n_slots; s++)
+        {
+            const uint32_t cls = mc.slot_cls[s];
+            if ((cls & 7u) == SANAFE_SOMA_NONE) continue;
+            const sanafe_hip_cost_class &cc = mc.cost_classes[(cls >> 6) & 1023u];
+            for (int k = 0; k < 3; k++) chip->slot_lat[k][s] = (0.0 + cc.dendrite_latency) + cc.soma_latency[k];
+        }
+    }
+    *out = chip.release();
+    return 0;
+}
+
+extern "C" void sanafe_chip_destroy(sanafe_chip *chip)
+{
+    if (!chip) return;
+    sanafe_hip_chip_destroy(chip->dev);
+    delete chip;
+}
+
+extern "C" int sanafe_chip_get_info(sanafe_chip *chip, sanafe_chip_info *o)
+{
+    if (!chip || !o) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    const MappedChip &mc = chip->mc;
+    o->n_cores = mc.n_cores;
+    o->n_local_cores = mc.last_core - mc.first_core;
+    o->n_slots = mc.n_slots;
+    o->n_global_slots = mc.n_global_slots;
+    o->ring_slots = mc.ring_slots;
+    o->n_slices = static_cast<uint32_t>(mc.slice_core.size());
+    o->n_neurons = chip->n_neurons;
+    o->n_axons = mc.ax_pre.size();
+    o->n_synapses = mc.syn_meta.size();
+    o->mapped_tiles = mc.mapped_tiles;
+    o->mapped_cores = mc.mapped_cores;
+    o->n_soma_classes = static_cast<uint32_t>(mc.soma_classes.size());
+    o->n_cost_classes = static_cast<uint32_t>(mc.cost_classes.size());
+    o->sync_delay = mc.sync_delay;
+    o->image_bytes = mc.ax_pre.size() * 20ull + mc.syn_meta.size() * 12ull + static_cast<uint64_t>(mc.n_slots) * 80ull;
+    return 0;
+}
+
+extern "C" sanafe_hip_chip *sanafe_chip_device(sanafe_chip *chip) { return chip ? chip->dev : nullptr; }
+
+extern "C" int sanafe_chip_get_image(sanafe_chip *chip, sanafe_hip_image *out)
+{
+    if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    *out = chip->mc.image();
+    return 0;
+}
+extern "C" int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron)
+{
+    if (!chip || !slot_of_neuron) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    std::copy(chip->mc.slot_of_gid.begin(), chip->mc.slot_of_gid.end(), slot_of_neuron);
+    return 0;
+}
+
+static void add_totals(sanafe_hip_totals &a, const sanafe_hip_totals &b)
+{
+    a.timesteps += 1;
+    a.spikes += b.spikes;
+    a.packets_sent += b.packets_sent;
+    a.neurons_updated += b.neurons_updated;
+    a.neurons_fired += b.neurons_fired;
+    a.total_hops += b.total_hops;
+    a.total_energy += b.total_energy;
+    a.synapse_energy += b.synapse_energy;
+    a.dendrite_energy += b.dendrite_energy;
+    a.soma_energy += b.soma_energy;
+    a.network_energy += b.network_energy;
+    a.sim_time += b.sim_time;
+}
+
+extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *rd)
+{
+    if (!chip || timesteps < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    if (!chip->dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "chip was mapped without a device (device < 0); there is no CPU execution path");
+    if (timing_model == SANAFE_TIMING_CYCLE)
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope");
+    if (timing_model != SANAFE_TIMING_SIMPLE && timing_model != SANAFE_TIMING_DETAILED)
+        return fail(SANAFE_HIP_ERR_INVALID, "unknown timing model");
+    MappedChip &mc = chip->mc;
+    sanafe_hip_totals run{};
+    chip->have_records = false;
+    chip->rec_totals.clear();
+    chip->rec_messages.clear();
+    chip->rec_spike_bits.clear();
+    chip->rec_first_timestep = chip->total_timesteps + 1;
+    chip->rec_count = 0;
+    if (timing_model == SANAFE_TIMING_SIMPLE)
+    {
+        // Whole run stays on the device; nothing comes back per step unless recorded.
+        DEV(sanafe_hip_reset_totals(chip->dev));
+        DEV(sanafe_hip_step(chip->dev, timesteps, 1, record));
+        DEV(sanafe_hip_synchronize(chip->dev));
+        DEV(sanafe_hip_read_totals(chip->dev, &run));
+        if (record && timesteps > 0)
+        {
+            chip->rec_totals.resize(timesteps);
+            DEV(sanafe_hip_read_step_totals(chip->dev, 0, timesteps, chip->rec_totals.data()));
+            chip->rec_spike_bits.resize(timesteps);
+            for (int64_t s = 0; s < timesteps; s++)
+            {
+                chip->rec_spike_bits[s].resize(mc.n_slots / 32);
+                DEV(sanafe_hip_read_step_spikes(chip->dev, s, chip->rec_spike_bits[s].data()));
+            }
+            chip->have_records = true;
+            chip->rec_count = timesteps;
+        }
+        chip->total_timesteps += timesteps;
+    }
+    else
+    {
+        // `detailed`: functional step on the GPU, NoC discrete-event schedule on the host
+        // (serial by construction, src/schedule.cpp:234-281), one step at a time.
+        if (mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing needs a single-rank chip");
+        std::vector<uint8_t> status(mc.n_slots);
+        std::vector<std::vector<Msg>> per_core;
+        for (int64_t s = 0; s < timesteps; s++)
+        {
+            DEV(sanafe_hip_reset_totals(chip->dev));
+            DEV(sanafe_hip_step(chip->dev, 1, 0, 0));
+            sanafe_hip_totals ts{};
+            DEV(sanafe_hip_read_totals(chip->dev, &ts));
+            DEV(sanafe_hip_read_status(chip->dev, status.data()));
+            chip->total_timesteps += 1;
+            chip->build_messages(chip->total_timesteps, status, per_core);
+            try
+            {
+                ts.sim_time = chip->schedule_detailed(per_core);
+            }
+            catch (const std::exception &e)
+            {
+                return fail(SANAFE_HIP_ERR_INVALID, e.what());
+            }
+            ts.timesteps = chip->total_timesteps;
+            add_totals(run, ts);
+            if (record)
+            {
+                chip->rec_totals.push_back(ts);
+                std::vector<Msg> flat;
+                for (auto &q : per_core) flat.insert(flat.end(), q.begin(), q.end());
+                chip->rec_messages.push_back(std::move(flat));
+                std::vector<uint32_t> bits(mc.n_slots / 32, 0);
+                for (uint32_t k = 0; k < mc.n_slots; k++)
+                    if (status[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
+                chip->rec_spike_bits.push_back(std::move(bits));
+            }
+        }
+        if (record)
+        {
+            chip->have_records = true;
+            chip->rec_count = timesteps;
+        }
+    }
+    chip->total_energy += run.total_energy;
+    chip->total_sim_time += run.sim_time;
+    run.timesteps = timesteps;
+    if (rd) *rd = run;
+    return 0;
+}
+
+extern "C" int sanafe_chip_reset(sanafe_chip *chip)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    DEV(sanafe_hip_reset(chip->dev));
+    return 0;
+}
+
+extern "C" double sanafe_chip_get_power(sanafe_chip *chip) // src/chip.cpp:607-621
+{
+    if (!chip || !(chip->total_sim_time > 0.0)) return 0.0;
+    return chip->total_energy / chip->total_sim_time;
+}
+
+template <typename T, typename F> static int gather_by_gid(sanafe_chip *chip, T *out, F &&read)
+{
+    const MappedChip &mc = chip->mc;
+    std::vector<T> slots(mc.n_slots);
+    int rc = read(slots.data());
+    if (rc != 0) return fail(rc, sanafe_hip_last_error());
+    for (int64_t g = 0; g < chip->n_neurons; g++)
+    {
+        const uint32_t s = mc.slot_of_gid[g];
+        out[g] = (s >= mc.slot_offset && s < mc.slot_offset + mc.n_slots) ? slots[s - mc.slot_offset] : T(0);
+    }
+    return 0;
+}
+
+extern "C" int sanafe_chip_get_status(sanafe_chip *chip, uint8_t *out)
+{
+    if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return gather_by_gid(chip, out, [&](uint8_t *p) { return sanafe_hip_read_status(chip->dev, p); });
+}
+extern "C" int sanafe_chip_get_potentials(sanafe_chip *chip, double *out)
+{
+    if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return gather_by_gid(chip, out, [&](double *p) { return sanafe_hip_read_potentials(chip->dev, p); });
+}
+extern "C" int sanafe_chip_get_input_current(sanafe_chip *chip, double *out)
+{
+    if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return gather_by_gid(chip, out, [&](double *p) { return sanafe_hip_read_input_current(chip->dev, p); });
+}
+
+extern "C" int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int64_t count, sanafe_hip_totals *out)
+{
+    if (!chip || !out || !chip->have_records || first < 0 || count < 0 || first + count > chip->rec_count)
+        return fail(SANAFE_HIP_ERR_INVALID, "step records not available (sim with record=1)");
+    std::copy(chip->rec_totals.begin() + first, chip->rec_totals.begin() + first + count, out);
+    return 0;
+}
+
+extern "C" int sanafe_chip_get_step_fired(sanafe_chip *chip, int64_t index, uint8_t *out)
+{
+    if (!chip || !out || !chip->have_records || index < 0 || index >= chip->rec_count)
+        return fail(SANAFE_HIP_ERR_INVALID, "step records not available (sim with record=1)");
+    const MappedChip &mc = chip->mc;
+    const std::vector<uint32_t> &bits = chip->rec_spike_bits[index];
+    for (int64_t g = 0; g < chip->n_neurons; g++)
+    {
+        const uint32_t s = mc.slot_of_gid[g];
+        if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots)
+        {
+            out[g] = 0;
+            continue;
+        }
+        const uint32_t ls = s - mc.slot_offset;
+        out[g] = (bits[ls >> 5] >> (ls & 31u)) & 1u;
+    }
+    return 0;
+}
+
+extern "C" int64_t sanafe_chip_get_step_messages(sanafe_chip *chip, int64_t index, sanafe_message *out, int64_t cap)
+{
+    if (!chip || !chip->have_records || index < 0 || index >= static_cast<int64_t>(chip->rec_messages.size())) return -1;
+    const std::vector<Msg> &v = chip->rec_messages[index];
+    if (out)
+        for (int64_t i = 0; i < std::min<int64_t>(cap, v.size()); i++) out[i] = static_cast<const sanafe_message &>(v[i]);
+    return static_cast<int64_t>(v.size());
+}
+
+extern "C" int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int64_t *neurons, const double *bias)
+{
+    if (!chip || (count > 0 && (!neurons || !bias))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    const MappedChip &mc = chip->mc;
+    for (int64_t i = 0; i < count; i++)
+    {
+        if (neurons[i] < 0 || neurons[i] >= chip->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "neuron id out of range");
+        const uint32_t s = mc.slot_of_gid[neurons[i]];
+        if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots) continue;
+        DEV(sanafe_hip_write_bias(chip->dev, s - mc.slot_offset, 1, &bias[i]));
+    }
+    return 0;
+}
+
+extern "C" int sanafe_chip_step_neurons(sanafe_chip *chip)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    DEV(sanafe_hip_step_neurons(chip->dev));
+    return 0;
+}
+extern "C" int sanafe_chip_step_deliver(sanafe_chip *chip, int timing_model)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    DEV(sanafe_hip_step_deliver(chip->dev, timing_model == SANAFE_TIMING_SIMPLE, 0));
+    chip->total_timesteps += 1;
+    return 0;
+}
+extern "C" int sanafe_chip_spike_buffers(sanafe_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
+        uint64_t *global_bytes, uint64_t *local_offset_bytes)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    DEV(sanafe_hip_spike_buffers(chip->dev, local_bits, local_bytes, global_bits, global_bytes));
+    if (local_offset_bytes) *local_offset_bytes = chip->mc.slot_offset / 8;
+    return 0;
+}
+extern "C" int sanafe_chip_synchronize(sanafe_chip *chip)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    DEV(sanafe_hip_synchronize(chip->dev));
+    return 0;
+}
+extern "C" int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out)
+{
+    if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    DEV(sanafe_hip_read_totals(chip->dev, out));
+    return 0;
+}

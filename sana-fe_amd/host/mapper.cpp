@@ -1,0 +1,846 @@
+// mapper.cpp -- see mapper.hpp.
+#include "mapper.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <optional>
+#include <tuple>
+
+namespace sanafe_amd
+{
+namespace
+{
+struct Attr
+{
+    const sanafe_attr_table *t;
+    int64_t i;
+    const sanafe_desc *d;
+    std::string key() const { return str(t->key[i]); }
+    std::string str(int32_t id) const { return id < 0 ? std::string() : std::string(d->strings[id]); }
+    int type() const { return t->type[i]; }
+    int fwd() const { return t->fwd ? t->fwd[i] : 7; }
+    // ModelAttribute conversion operators, src/attribute.hpp:43-93
+    double as_double() const
+    {
+        if (type() == SANAFE_ATTR_DOUBLE || type() == SANAFE_ATTR_INT) return t->num[i];
+        throw std::runtime_error("Error: Attribute " + key() + " cannot be cast to a double");
+    }
+    int as_int() const
+    {
+        if (type() != SANAFE_ATTR_INT) throw std::runtime_error("Error: Attribute " + key() + " is not an integer");
+        return static_cast<int>(t->num[i]);
+    }
+    bool as_bool() const
+    {
+        if (type() == SANAFE_ATTR_BOOL || type() == SANAFE_ATTR_INT) return t->num[i] != 0.0;
+        throw std::runtime_error("Error: Attribute " + key() + " cannot be cast to a bool ()");
+    }
+    std::string as_string() const
+    {
+        if (type() != SANAFE_ATTR_STRING) throw std::runtime_error("Error: Attribute " + key() + " is not a string");
+        return str(t->str[i]);
+    }
+};
+
+uint8_t parse_reset_mode(const std::string &s) // src/models.cpp:905-931
+{
+    if (s == "none") return SANAFE_RESET_NONE;
+    if (s == "soft") return SANAFE_RESET_SOFT;
+    if (s == "hard") return SANAFE_RESET_HARD;
+    if (s == "saturate") return SANAFE_RESET_SATURATE;
+    throw std::invalid_argument("Reset mode not recognized");
+}
+
+enum Model { M_CURRENT_BASED, M_ACCUMULATOR, M_ACC_DELAY, M_TAPS, M_INPUT, M_LIF, M_TRUENORTH, M_PLUGIN };
+
+struct UnitInfo // one pipeline unit of a core template
+{
+    std::string name;
+    Model model{M_PLUGIN};
+    bool syn{false}, dend{false}, soma{false};
+    bool update_every_timestep{false}, log{false};
+    std::optional<double> e_spike, l_spike, e_update, l_update;
+    bool has_soma_e{false}, has_soma_l{false};
+    double se[3]{}, sl[3]{}; // access, update, spike_out
+    size_t capacity{SIZE_MAX};
+};
+
+struct Template
+{
+    std::vector<UnitInfo> units;
+    std::vector<double> ain_e, ain_l, aout_e, aout_l;
+};
+
+std::string S(const sanafe_desc &d, int32_t id) { return id < 0 ? std::string() : std::string(d.strings[id]); }
+
+Template read_template(const sanafe_desc &d, int tm)
+{
+    Template t;
+    for (int i = d.tmpl_axon_in_ptr[tm]; i < d.tmpl_axon_in_ptr[tm + 1]; i++)
+    {
+        t.ain_e.push_back(d.axon_in_energy[i]);
+        t.ain_l.push_back(d.axon_in_latency[i]);
+    }
+    for (int i = d.tmpl_axon_out_ptr[tm]; i < d.tmpl_axon_out_ptr[tm + 1]; i++)
+    {
+        t.aout_e.push_back(d.axon_out_energy[i]);
+        t.aout_l.push_back(d.axon_out_latency[i]);
+    }
+    for (int u = d.tmpl_unit_ptr[tm]; u < d.tmpl_unit_ptr[tm + 1]; u++)
+    {
+        UnitInfo ui;
+        ui.name = S(d, d.unit_name[u]);
+        const std::string model = S(d, d.unit_model[u]);
+        ui.syn = d.unit_implements[u] & SANAFE_IMPL_SYNAPSE;
+        ui.dend = d.unit_implements[u] & SANAFE_IMPL_DENDRITE;
+        ui.soma = d.unit_implements[u] & SANAFE_IMPL_SOMA;
+        ui.update_every_timestep = d.unit_flags[u] & SANAFE_UNIT_UPDATE_EVERY_TIMESTEP;
+        ui.log = d.unit_flags[u] & (SANAFE_UNIT_LOG_ENERGY | SANAFE_UNIT_LOG_LATENCY);
+        bool want_syn = false, want_dend = false, want_soma = false;
+        if (d.unit_plugin[u] >= 0) ui.model = M_PLUGIN;
+        else if (model == "current_based") ui.model = M_CURRENT_BASED, want_syn = true;
+        else if (model == "accumulator") ui.model = M_ACCUMULATOR, want_dend = true, ui.capacity = 1024;
+        else if (model == "accumulator_with_delay") ui.model = M_ACC_DELAY, want_dend = true, ui.capacity = 1024;
+        else if (model == "taps") ui.model = M_TAPS, want_dend = true, ui.capacity = 1;
+        else if (model == "input") ui.model = M_INPUT, want_soma = true, ui.capacity = 1;
+        else if (model == "leaky_integrate_fire") ui.model = M_LIF, want_soma = true, ui.capacity = 1024;
+        else if (model == "truenorth") ui.model = M_TRUENORTH, want_soma = true, ui.capacity = 4096;
+        else throw std::invalid_argument("Pipeline model not supported (" + model + ")\n"); // src/models.cpp:964-966
+        if (ui.model != M_PLUGIN && (want_syn != ui.syn || want_dend != ui.dend || want_soma != ui.soma))
+            throw std::runtime_error("Unit '" + ui.name + "' (" + model +
+                    ") is listed in a hardware section it does not implement"); // check_implemented, src/pipeline.cpp:20-57
+        // PipelineUnit::set_attributes_hw, src/pipeline.cpp:151-266
+        std::map<std::string, Attr> m;
+        for (int64_t i = d.unit_attr_ptr[u]; i < d.unit_attr_ptr[u + 1]; i++)
+        {
+            Attr a{&d.unit_attrs, i, &d};
+            m.emplace(a.key(), a);
+        }
+        auto has = [&](const char *k) { return m.count(k) > 0; };
+        auto num = [&](const char *k) { return m.at(k).as_double(); };
+        if (has("energy_process_spike")) ui.e_spike = num("energy_process_spike");
+        if (has("latency_process_spike")) ui.l_spike = num("latency_process_spike");
+        if (has("energy_update")) ui.e_update = num("energy_update");
+        if (has("latency_update")) ui.l_update = num("latency_update");
+        const char *en[3] = {"energy_access_neuron", "energy_update_neuron", "energy_spike_out"};
+        if (has(en[0]) || has(en[1]) || has(en[2]))
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                if (!has(en[k])) throw std::invalid_argument(std::string("Metric not defined: ") + en[k]);
+                ui.se[k] = num(en[k]);
+            }
+            ui.has_soma_e = true;
+        }
+        const char *ln[3] = {"latency_access_neuron", "latency_update_neuron", "latency_spike_out"};
+        if (has(ln[0]) || has(ln[1]) || has(ln[2]))
+        {
+            for (int k = 0; k < 3; k++)
+            {
+                if (!has(ln[k])) throw std::invalid_argument(std::string("Missing metric: ") + ln[k]);
+                ui.sl[k] = num(ln[k]);
+            }
+            ui.has_soma_l = true;
+        }
+        if (ui.model == M_LIF && (has("noise") || has("noise_bits")))
+            throw UnsupportedError("LIF file noise stream (unit '" + ui.name + "') is not implemented on the MI355X backend");
+        t.units.push_back(std::move(ui));
+    }
+    return t;
+}
+
+// Core::get_hw, src/core.cpp:61-97
+int find_unit(const Template &t, const std::string &name, bool syn, bool dend, bool soma)
+{
+    for (size_t i = 0; i < t.units.size(); i++)
+    {
+        const UnitInfo &u = t.units[i];
+        if ((syn && !u.syn) || (dend && !u.dend) || (soma && !u.soma)) continue;
+        if (name.empty() || name == u.name) return static_cast<int>(i);
+    }
+    throw HardwareMappingError("Could not find h/w (with name:" + name + ") that implements synapse:" +
+            std::to_string(int(syn)) + ", dendrite:" + std::to_string(int(dend)) + ", soma:" + std::to_string(int(soma)));
+}
+
+template <typename K> void counting_sort(std::vector<uint64_t> &order, const K &key_of, size_t n_keys, std::vector<uint64_t> &tmp)
+{
+    std::vector<uint64_t> count(n_keys + 1, 0);
+    for (uint64_t e : order) count[key_of(e) + 1]++;
+    for (size_t k = 0; k < n_keys; k++) count[k + 1] += count[k];
+    tmp.resize(order.size());
+    for (uint64_t e : order) tmp[count[key_of(e)]++] = e;
+    order.swap(tmp);
+}
+
+struct ClassKey
+{
+    unsigned char b[sizeof(sanafe_hip_soma_class)];
+    bool operator<(const ClassKey &o) const { return std::memcmp(b, o.b, sizeof(b)) < 0; }
+};
+struct CostKey
+{
+    unsigned char b[sizeof(sanafe_hip_cost_class)];
+    bool operator<(const CostKey &o) const { return std::memcmp(b, o.b, sizeof(b)) < 0; }
+};
+} // namespace
+
+sanafe_hip_image MappedChip::image() const
+{
+    sanafe_hip_image im{};
+    im.n_cores = static_cast<uint32_t>(l_core_nbase.size());
+    im.n_slots = n_slots;
+    im.n_soma_classes = static_cast<uint32_t>(soma_classes.size());
+    im.n_cost_classes = static_cast<uint32_t>(cost_classes.size());
+    im.ring_slots = ring_slots;
+    im.n_slices = static_cast<uint32_t>(slice_core.size());
+    im.n_axons = ax_pre.size();
+    im.n_synapses = syn_meta.size();
+    im.n_input = static_cast<uint32_t>(in_train_beg.size());
+    im.n_train_words = in_train_bits.size();
+    im.slot_offset = slot_offset;
+    im.n_global_slots = n_global_slots;
+    im.sync_delay = sync_delay;
+    im.core_nbase = l_core_nbase.data();
+    im.core_ncount = l_core_ncount.data();
+    im.core_axon_out_latency = core_axon_out_latency.data();
+    im.soma_classes = soma_classes.data();
+    im.cost_classes = cost_classes.data();
+    im.slot_cls = slot_cls.data();
+    im.slot_bias = slot_bias.data();
+    im.slot_v0 = slot_v0.data();
+    im.slot_aux = slot_aux.data();
+    im.slot_packets = slot_packets.data();
+    im.slot_hops = slot_hops.data();
+    im.slot_events = slot_events.data();
+    im.slot_e_net = slot_e_net.data();
+    im.slot_e_syn = slot_e_syn.data();
+    im.slot_e_dend = slot_e_dend.data();
+    im.in_train_beg = in_train_beg.data();
+    im.in_train_len = in_train_len.data();
+    im.in_rate_period = in_rate_period.data();
+    im.in_train_bits = in_train_bits.data();
+    im.slice_core = slice_core.data();
+    im.slice_axon_beg = slice_axon_beg.data();
+    im.slice_axon_end = slice_axon_end.data();
+    im.core_syn_base = core_syn_base.data();
+    im.core_axon_in_latency = core_axon_in_latency.data();
+    im.ax_pre = ax_pre.data();
+    im.ax_syn_beg = ax_syn_beg.data();
+    im.ax_nsyn = ax_nsyn.data();
+    im.ax_proc_delay = ax_proc_delay.data();
+    im.syn_meta = syn_meta.data();
+    im.syn_weight = syn_weight.data();
+    return im;
+}
+
+void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_slices, MappedChip &mc)
+{
+    if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+    // ------------------------------------------------------------------ architecture
+    mc.n_tiles = d.n_tiles;
+    mc.n_cores = d.n_cores;
+    mc.noc_width = d.noc_width;
+    mc.noc_height = d.noc_height;
+    mc.noc_buffer = d.noc_buffer_size;
+    mc.tile_x.resize(d.n_tiles);
+    mc.tile_y.resize(d.n_tiles);
+    for (int t = 0; t < d.n_tiles; t++)
+    {
+        mc.tile_x[t] = t / d.noc_height; // src/arch.cpp:78-88
+        mc.tile_y[t] = t % d.noc_height;
+    }
+    mc.core_tile.assign(d.core_tile, d.core_tile + d.n_cores);
+    mc.core_offset.resize(d.n_cores);
+    {
+        std::vector<uint32_t> per_tile(d.n_tiles, 0);
+        for (int c = 0; c < d.n_cores; c++)
+        {
+            if (c > 0 && d.core_tile[c] < d.core_tile[c - 1]) throw std::invalid_argument("cores must be listed in tile order");
+            mc.core_offset[c] = per_tile[d.core_tile[c]]++;
+        }
+        for (uint32_t n : per_tile) mc.max_cores_per_tile = std::max(mc.max_cores_per_tile, n);
+    }
+    std::vector<Template> templates;
+    for (int t = 0; t < d.n_templates; t++) templates.push_back(read_template(d, t));
+    auto tmpl_of = [&](uint32_t core) -> const Template & { return templates[d.core_template[core]]; };
+
+    // ------------------------------------------------------------------ groups
+    const int64_t N = d.n_neurons;
+    mc.group_ptr.assign(d.group_ptr, d.group_ptr + d.n_groups + 1);
+    mc.group_names.clear();
+    for (int g = 0; g < d.n_groups; g++) mc.group_names.push_back(S(d, d.group_name[g]));
+    mc.group_lex_order.resize(d.n_groups);
+    std::iota(mc.group_lex_order.begin(), mc.group_lex_order.end(), 0);
+    std::sort(mc.group_lex_order.begin(), mc.group_lex_order.end(),
+            [&](int a, int b) { return mc.group_names[a] < mc.group_names[b]; }); // std::map<std::string,...> order
+    std::vector<int> lex_rank(d.n_groups);
+    for (int i = 0; i < d.n_groups; i++) lex_rank[mc.group_lex_order[i]] = i;
+    std::vector<int32_t> group_of(N);
+    for (int g = 0; g < d.n_groups; g++)
+        for (int64_t n = d.group_ptr[g]; n < d.group_ptr[g + 1]; n++) group_of[n] = g;
+
+    // ------------------------------------------------------------------ map_neurons, src/chip.cpp:186-234
+    std::vector<int64_t> order;
+    order.reserve(N);
+    for (int g : mc.group_lex_order)
+        for (int64_t n = d.group_ptr[g]; n < d.group_ptr[g + 1]; n++) order.push_back(n);
+    std::stable_sort(order.begin(), order.end(),
+            [&](int64_t a, int64_t b) { return d.neuron_map_order[a] < d.neuron_map_order[b]; });
+    mc.core_ncount.assign(d.n_cores, 0);
+    std::vector<uint32_t> offset_in_core(N);
+    for (int64_t gid : order)
+    {
+        const int32_t c = d.neuron_core[gid];
+        if (c < 0 || c >= d.n_cores)
+            throw HardwareMappingError("Neuron: " + mc.group_names[group_of[gid]] + "." +
+                    std::to_string(gid - d.group_ptr[group_of[gid]]) + " not mapped.");
+        if (mc.core_ncount[c] >= static_cast<uint64_t>(d.core_max_neurons[c]))
+            throw HardwareMappingError("Error: Exceeded maximum neurons per core.");
+        offset_in_core[gid] = mc.core_ncount[c]++;
+    }
+    mc.core_nbase.resize(d.n_cores);
+    uint64_t slots = 0;
+    for (int c = 0; c < d.n_cores; c++)
+    {
+        mc.core_nbase[c] = static_cast<uint32_t>(slots);
+        slots += (mc.core_ncount[c] + 63u) & ~63u;
+        if (slots > 0xffffffc0ull) throw UnsupportedError("more than 2^32 neuron slots");
+    }
+    if (slots == 0) slots = 64;
+    mc.n_global_slots = static_cast<uint32_t>(slots);
+    mc.slot_of_gid.resize(N);
+    mc.gid_of_slot.assign(mc.n_global_slots, -1);
+    mc.core_of_slot.assign(mc.n_global_slots, 0);
+    for (int c = 0; c < d.n_cores; c++)
+        for (uint32_t k = 0; k < ((mc.core_ncount[c] + 63u) & ~63u); k++) mc.core_of_slot[mc.core_nbase[c] + k] = c;
+    for (int64_t gid = 0; gid < N; gid++)
+    {
+        const uint32_t s = mc.core_nbase[d.neuron_core[gid]] + offset_in_core[gid];
+        mc.slot_of_gid[gid] = s;
+        mc.gid_of_slot[s] = gid;
+    }
+    // track_mapped_tiles_and_cores, src/chip.cpp:283-306
+    {
+        std::vector<uint8_t> used(d.n_tiles, 0);
+        for (int c = 0; c < d.n_cores; c++)
+            if (mc.core_ncount[c] > 0)
+            {
+                used[d.core_tile[c]] = 1;
+                mc.mapped_cores++;
+            }
+        for (uint8_t u : used) mc.mapped_tiles += u;
+    }
+    // sim_timestep_sync, src/chip.cpp:562-574; LookupTable::get, src/utils.hpp:19-44
+    if (d.n_sync <= 0) throw std::runtime_error("Table is empty");
+    {
+        int k = 0;
+        while (k + 1 < d.n_sync && static_cast<uint64_t>(d.sync_key[k + 1]) <= mc.mapped_tiles) k++;
+        if (static_cast<uint64_t>(d.sync_key[0]) > mc.mapped_tiles) k = 0;
+        mc.sync_delay = d.sync_val[k];
+    }
+
+    // ------------------------------------------------------------------ rank window (tiles in contiguous blocks)
+    {
+        const uint32_t tpr = (d.n_tiles + n_ranks - 1) / n_ranks;
+        const uint32_t t0 = std::min<uint32_t>(d.n_tiles, rank * tpr), t1 = std::min<uint32_t>(d.n_tiles, (rank + 1) * tpr);
+        mc.first_core = d.n_cores;
+        mc.last_core = 0;
+        for (int c = 0; c < d.n_cores; c++)
+            if (static_cast<uint32_t>(d.core_tile[c]) >= t0 && static_cast<uint32_t>(d.core_tile[c]) < t1)
+            {
+                mc.first_core = std::min<uint32_t>(mc.first_core, c);
+                mc.last_core = std::max<uint32_t>(mc.last_core, c + 1);
+            }
+        if (mc.first_core >= mc.last_core) mc.first_core = mc.last_core = 0;
+        mc.slot_offset = mc.first_core < static_cast<uint32_t>(d.n_cores) && mc.last_core > mc.first_core ? mc.core_nbase[mc.first_core] : 0;
+        const uint32_t end_slot = mc.last_core > mc.first_core
+                ? (mc.last_core < static_cast<uint32_t>(d.n_cores) ? mc.core_nbase[mc.last_core] : mc.n_global_slots)
+                : mc.slot_offset;
+        mc.n_slots = std::max<uint32_t>(64, end_slot - mc.slot_offset);
+        if (mc.last_core == mc.first_core) throw UnsupportedError("rank " + std::to_string(rank) + " owns no tiles");
+    }
+    const uint32_t LC = mc.last_core - mc.first_core;
+    const uint32_t LS = mc.n_slots, SO = mc.slot_offset;
+
+    // ------------------------------------------------------------------ Core::map_neuron, src/core.cpp:116-168
+    std::vector<int32_t> dend_unit(N), soma_unit(N);
+    {
+        std::vector<std::vector<uint32_t>> used(d.n_cores); // neurons per (core, unit)
+        std::map<std::tuple<int32_t, int32_t, int>, int> memo; // (template, name, role) -> unit
+        auto lookup = [&](int32_t tm, int32_t name, bool dend) {
+            const auto key = std::make_tuple(tm, name, dend ? 1 : 0);
+            auto it = memo.find(key);
+            if (it == memo.end()) it = memo.emplace(key, find_unit(templates[tm], S(d, name), false, dend, !dend)).first;
+            return it->second;
+        };
+        for (int64_t gid : order)
+        {
+            const int32_t c = d.neuron_core[gid];
+            const Template &t = tmpl_of(c);
+            if (t.units.empty()) throw std::runtime_error("Error: No units defined");
+            const int du = lookup(d.core_template[c], d.neuron_dendrite_hw[gid], true);
+            const int su = lookup(d.core_template[c], d.neuron_soma_hw[gid], false);
+            if (t.aout_e.empty()) throw std::runtime_error("Error: No axon out units defined");
+            dend_unit[gid] = du;
+            soma_unit[gid] = su;
+            if (used[c].empty()) used[c].assign(t.units.size(), 0);
+            used[c][du]++;
+            if (su != du) used[c][su]++;
+            if (used[c][su] > t.units[su].capacity || used[c][du] > t.units[du].capacity)
+                throw HardwareMappingError("Too many neurons mapped to one h/w unit on core " + std::to_string(c) +
+                        " (model capacity: src/models.hpp:29, 284, 347)");
+        }
+    }
+
+    // ------------------------------------------------------------------ per-slot soma state (local slots)
+    mc.l_core_nbase.resize(LC);
+    mc.l_core_ncount.resize(LC);
+    mc.core_axon_out_latency.resize(LC);
+    mc.core_axon_in_latency.resize(LC);
+    for (uint32_t k = 0; k < LC; k++)
+    {
+        const uint32_t c = mc.first_core + k;
+        mc.l_core_nbase[k] = mc.core_nbase[c] - SO;
+        mc.l_core_ncount[k] = mc.core_ncount[c];
+        const Template &t = tmpl_of(c);
+        mc.core_axon_out_latency[k] = t.aout_l.empty() ? 0.0 : t.aout_l[0];
+        mc.core_axon_in_latency[k] = t.ain_l.empty() ? 0.0 : t.ain_l[0];
+    }
+    mc.slot_cls.assign(LS, 0);
+    mc.slot_aux.assign(LS, 0);
+    mc.slot_bias.assign(LS, 0.0);
+    mc.slot_v0.assign(LS, 0.0);
+    mc.slot_log_spikes.assign(LS, 0);
+    mc.slot_log_potential.assign(LS, 0);
+    mc.slot_model.assign(LS, SANAFE_SOMA_NONE);
+    std::map<ClassKey, uint32_t> class_ids;
+    std::map<CostKey, uint32_t> cost_ids;
+    bool any_delay_dendrite = false;
+    std::vector<uint8_t> neuron_dend_kind(N, 0); // 0 buffered accumulator, 1 zero, 2 delay line
+    for (int64_t gid = 0; gid < N; gid++)
+    {
+        const int32_t c = d.neuron_core[gid];
+        const Template &t = tmpl_of(c);
+        const UnitInfo &du = t.units[dend_unit[gid]];
+        const UnitInfo &su = t.units[soma_unit[gid]];
+        const int bp = d.core_buffer_pos[c];
+        if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE)
+            throw UnsupportedError("buffer position " + std::to_string(bp) +
+                    " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside)");
+        if (du.model == M_TAPS || du.model == M_PLUGIN)
+            throw UnsupportedError("dendrite model of unit '" + du.name + "' is not implemented on the MI355X backend");
+        if (du.log || su.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
+        uint8_t kind = SANAFE_IN_BUFFERED;
+        if (bp == SANAFE_BUF_INSIDE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_ZERO, neuron_dend_kind[gid] = 1;
+        if (du.model == M_ACC_DELAY)
+        {
+            if (bp != SANAFE_BUF_INSIDE_DENDRITE)
+                throw UnsupportedError("accumulator_with_delay with the buffer outside the dendrite unit is not implemented");
+            any_delay_dendrite = true;
+            neuron_dend_kind[gid] = 2;
+        }
+        const uint32_t s = mc.slot_of_gid[gid];
+        if (s < SO || s >= SO + LS) continue; // not ours
+        const uint32_t ls = s - SO;
+        // ---- cost class (src/pipeline.hpp:574-714) ----
+        sanafe_hip_cost_class cc{};
+        if (!su.has_soma_e) throw std::runtime_error("Soma unit does not simulate energy or provide default energy costs in the architecture description.");
+        if (!su.has_soma_l) throw std::runtime_error("Soma unit does not simulate latency or provide default latency costs in the architecture description.");
+        cc.soma_energy[0] = su.se[0];
+        cc.soma_energy[1] = su.se[0] + su.se[1];
+        cc.soma_energy[2] = (su.se[0] + su.se[1]) + su.se[2];
+        cc.soma_latency[0] = su.sl[0];
+        cc.soma_latency[1] = su.sl[0] + su.sl[1];
+        cc.soma_latency[2] = (su.sl[0] + su.sl[1]) + su.sl[2];
+        if (bp <= SANAFE_BUF_INSIDE_DENDRITE)
+        {
+            if (!du.e_update) throw std::runtime_error("Dendrite unit does not simulate energy or provide a default energy cost in the architecture description.");
+            if (!du.l_update) throw std::runtime_error("Dendrite unit does not simulate latency or provide a default latency cost in the architecture description.");
+            cc.dendrite_energy = *du.e_update;
+            cc.dendrite_latency = *du.l_update;
+        }
+        CostKey ck;
+        std::memcpy(ck.b, &cc, sizeof(cc));
+        auto cit = cost_ids.find(ck);
+        if (cit == cost_ids.end())
+        {
+            cit = cost_ids.emplace(ck, static_cast<uint32_t>(mc.cost_classes.size())).first;
+            mc.cost_classes.push_back(cc);
+            if (mc.cost_classes.size() > 1024) throw UnsupportedError("more than 1024 distinct cost classes");
+        }
+        // ---- soma parameters: set_attribute_neuron in key order, src/models.cpp:375-439, 664-722, 832-853 ----
+        uint32_t model = SANAFE_SOMA_NONE, pcls = 0;
+        sanafe_hip_soma_class p{};
+        p.leak_decay = 1.0;
+        p.reset_mode = SANAFE_RESET_HARD;
+        p.reverse_reset_mode = SANAFE_RESET_NONE;
+        p.leak_towards_zero = 1;
+        if (su.model == M_LIF) model = SANAFE_SOMA_LIF;
+        else if (su.model == M_TRUENORTH) model = SANAFE_SOMA_TRUENORTH, p.leak_decay = 0.0;
+        else if (su.model == M_INPUT) model = SANAFE_SOMA_INPUT;
+        else throw UnsupportedError("soma unit '" + su.name + "' (plugin) is not implemented on the MI355X backend yet");
+        std::vector<double> train;
+        double rate = 0.0, poisson = 0.0;
+        for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+        {
+            const Attr a{&d.neuron_attrs, i, &d};
+            const std::string k = a.key();
+            if (k == "soma_hw_name" || k == "default_synapse_hw_name" || k == "dendrite_hw_name" || k == "log_spikes" ||
+                    k == "log_potential" || k == "log_v")
+                throw std::invalid_argument("Reserved neuron attribute '" + k + "' cannot be used as a model attribute. Pass it as a direct argument instead (if supported).");
+            if (!(a.fwd() & SANAFE_FWD_SOMA)) continue;
+            if (model == SANAFE_SOMA_LIF)
+            {
+                if (k == "threshold") p.threshold = a.as_double();
+                else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
+                else if (k == "reset") p.reset = a.as_double();
+                else if (k == "reverse_reset") p.reverse_reset = a.as_double();
+                else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
+                else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
+                else if (k == "leak_decay") p.leak_decay = a.as_double();
+                else if (k == "log_u") (void) a.as_bool();
+                else if (k == "input_decay") p.input_decay = a.as_double();
+                else if (k == "bias") mc.slot_bias[ls] = a.as_double();
+                else if (k == "force_update" || k == "force_update_every_timestep") p.force_update = a.as_bool();
+                else if (k == "refractory_delay") p.refractory_delay = a.as_int();
+                else if (k == "potential") mc.slot_v0[ls] = a.as_double();
+            }
+            else if (model == SANAFE_SOMA_TRUENORTH)
+            {
+                if (k == "threshold") p.threshold = a.as_double();
+                else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
+                else if (k == "reset") p.reset = a.as_double();
+                else if (k == "reverse_reset") p.reverse_reset = a.as_double();
+                else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
+                else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
+                else if (k == "leak") p.leak_decay = a.as_double();
+                else if (k == "bias") mc.slot_bias[ls] = a.as_double();
+                else if (k == "force_update_every_timestep" || k == "force_update") p.force_update = a.as_bool();
+                else if (k == "leak_towards_zero") p.leak_towards_zero = a.as_bool();
+                else if (k == "random_mask")
+                {
+                    const int m = a.as_int();
+                    if (m < 0) throw std::invalid_argument("random_mask < 0; must be unsigned.");
+                    if (m != 0) throw UnsupportedError("TrueNorth random_mask (libc rand stream) is not implemented on the MI355X backend");
+                }
+            }
+            else
+            {
+                if (k == "spikes")
+                {
+                    if (a.type() != SANAFE_ATTR_LIST) throw std::runtime_error("Error: Attribute spikes is not a list");
+                    train.assign(d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i], d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i + 1]);
+                }
+                else if (k == "poisson") poisson = a.as_double();
+                else if (k == "rate") rate = a.as_double();
+            }
+        }
+        if (model == SANAFE_SOMA_INPUT)
+        {
+            if (poisson > 0.0) throw UnsupportedError("poisson input (std::mt19937 stream) is not implemented on the MI355X backend");
+            mc.slot_aux[ls] = static_cast<uint32_t>(mc.in_train_beg.size());
+            const uint32_t beg = static_cast<uint32_t>(mc.in_train_bits.size()) * 32u;
+            mc.in_train_beg.push_back(beg);
+            mc.in_train_len.push_back(static_cast<uint32_t>(train.size()));
+            mc.in_train_bits.resize(mc.in_train_bits.size() + (train.size() + 31) / 32, 0u);
+            for (size_t b = 0; b < train.size(); b++)
+                if (train[b] != 0.0) mc.in_train_bits[(beg + b) >> 5] |= 1u << ((beg + b) & 31u);
+            int64_t period = 0;
+            if (rate > 0.0)
+            {
+                period = static_cast<long>(1.0 / rate); // src/models.cpp:891-892
+                if (period == 0) throw std::invalid_argument("input rate > 1 makes the reference divide by zero (SURVEY quirk 14)");
+            }
+            mc.in_rate_period.push_back(period);
+        }
+        else
+        {
+            ClassKey key;
+            std::memset(&key, 0, sizeof(key));
+            sanafe_hip_soma_class canon{};
+            canon.threshold = p.threshold;
+            canon.reverse_threshold = p.reverse_threshold;
+            canon.reset = p.reset;
+            canon.reverse_reset = p.reverse_reset;
+            canon.leak_decay = p.leak_decay;
+            canon.input_decay = p.input_decay;
+            canon.refractory_delay = p.refractory_delay;
+            canon.reset_mode = p.reset_mode;
+            canon.reverse_reset_mode = p.reverse_reset_mode;
+            canon.force_update = p.force_update;
+            canon.leak_towards_zero = p.leak_towards_zero;
+            std::memcpy(key.b, &canon, sizeof(canon));
+            auto it = class_ids.find(key);
+            if (it == class_ids.end())
+            {
+                it = class_ids.emplace(key, static_cast<uint32_t>(mc.soma_classes.size())).first;
+                mc.soma_classes.push_back(canon);
+                if (mc.soma_classes.size() > 65536) throw UnsupportedError("more than 65536 distinct soma parameter sets");
+            }
+            pcls = it->second;
+        }
+        mc.slot_cls[ls] = model | (static_cast<uint32_t>(kind) << 3) | (cit->second << 6) | (pcls << 16);
+        mc.slot_model[ls] = static_cast<uint8_t>(model);
+        mc.slot_log_spikes[ls] = d.neuron_log_spikes[gid];
+        mc.slot_log_potential[ls] = d.neuron_log_potential[gid];
+    }
+    if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
+    if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});
+    mc.ring_slots = any_delay_dendrite ? 6 : 1;
+
+    // ------------------------------------------------------------------ map_connections, src/chip.cpp:334-380
+    const int64_t E = d.n_edges;
+    std::vector<int32_t> edge_syn_unit(E);  // unit index inside the destination core's template
+    std::vector<uint8_t> edge_delay_eff;     // effective delay seen by the delay dendrite
+    int32_t memo_name = -2, memo_tmpl = -1, memo_unit = -1; // consecutive edges nearly always repeat the lookup
+    for (int64_t e = 0; e < E; e++)
+    {
+        const int64_t dst = d.edge_dst[e];
+        if (d.edge_src[e] < 0 || d.edge_src[e] >= N || dst < 0 || dst >= N) throw std::invalid_argument("edge endpoint out of range");
+        int32_t hw_id = d.edge_synapse_hw[e]; // get_synapse_hw_name, src/chip.cpp:308-332
+        if (hw_id < 0) hw_id = d.neuron_synapse_hw[dst];
+        const int32_t tm = d.core_template[d.neuron_core[dst]];
+        const Template &t = templates[tm];
+        if (hw_id != memo_name || tm != memo_tmpl)
+        {
+            memo_unit = find_unit(t, S(d, hw_id), true, false, false);
+            memo_name = hw_id;
+            memo_tmpl = tm;
+        }
+        const int su = memo_unit;
+        const UnitInfo &u = t.units[su];
+        if (u.model != M_CURRENT_BASED) throw UnsupportedError("synapse unit '" + u.name + "' (plugin) is not implemented on the MI355X backend");
+        if (u.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
+        if (!u.e_spike) throw std::runtime_error("Synapse unit does not simulate energy or provide a default energy cost in the architecture description.");
+        if (!u.l_spike) throw std::runtime_error("Synapse unit does not simulate latency or provide a default latency cost in the architecture description.");
+        edge_syn_unit[e] = su;
+    }
+    if (d.edge_delay && any_delay_dendrite)
+    {
+        // The delay dendrite stores delays[] indexed by the SYNAPSE unit's address of the
+        // connection (src/mapped.cpp:60-89, src/models.cpp:133-152): connections that reach the
+        // same dendrite unit through different synapse units share table entries.  Replay the
+        // assignments in map_connections order to get the delay each connection really sees.
+        std::vector<uint64_t> eo(E), tmp;
+        std::iota(eo.begin(), eo.end(), 0);
+        std::vector<uint64_t> rank_base(d.n_groups + 1, 0);
+        for (int i = 0; i < d.n_groups; i++)
+            rank_base[i + 1] = rank_base[i] + (d.group_ptr[mc.group_lex_order[i] + 1] - d.group_ptr[mc.group_lex_order[i]]);
+        auto src_key = [&](uint64_t e) {
+            const int64_t s = d.edge_src[e];
+            const int g = group_of[s];
+            return rank_base[lex_rank[g]] + (s - d.group_ptr[g]);
+        };
+        counting_sort(eo, src_key, N, tmp);
+        std::map<std::pair<uint32_t, int>, uint64_t> syn_count;            // (core, synapse unit) -> next address
+        std::map<std::pair<uint32_t, int>, std::vector<uint8_t>> delays;   // (core, dendrite unit) -> delays[]
+        std::vector<uint64_t> syn_addr(E);
+        for (uint64_t e : eo)
+        {
+            const int64_t dst = d.edge_dst[e];
+            const uint32_t c = d.neuron_core[dst];
+            const uint64_t addr = syn_count[{c, edge_syn_unit[e]}]++;
+            syn_addr[e] = addr;
+            if (neuron_dend_kind[dst] == 2)
+            {
+                auto &tab = delays[{c, dend_unit[dst]}];
+                if (tab.size() <= addr) tab.resize(addr + 1, 0); // every forwarded attribute resizes (weight included)
+                if (d.edge_delay[e] >= 0)
+                {
+                    if (d.edge_delay[e] > 5) throw std::runtime_error("Error: delay > max delay\n");
+                    tab[addr] = static_cast<uint8_t>(d.edge_delay[e]);
+                }
+            }
+        }
+        edge_delay_eff.assign(E, 0);
+        for (int64_t e = 0; e < E; e++)
+        {
+            const int64_t dst = d.edge_dst[e];
+            if (neuron_dend_kind[dst] != 2) continue;
+            const auto &tab = delays[{static_cast<uint32_t>(d.neuron_core[dst]), dend_unit[dst]}];
+            edge_delay_eff[e] = syn_addr[e] < tab.size() ? tab[syn_addr[e]] : 0;
+        }
+    }
+
+    // ------------------------------------------------------------------ map_axons, src/chip.cpp:382-408, 1263-1391
+    // Delivery order at a destination core = (source core id, source neuron order, connection
+    // order) = (pre slot, creation order): two stable counting sorts.
+    std::vector<uint64_t> eo(E), tmp;
+    std::iota(eo.begin(), eo.end(), 0);
+    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(mc.slot_of_gid[d.edge_src[e]]); }, mc.n_global_slots, tmp);
+    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(d.neuron_core[d.edge_dst[e]]); }, d.n_cores, tmp);
+    tmp.clear();
+    tmp.shrink_to_fit();
+
+    std::vector<uint32_t> g_packets(mc.n_global_slots, 0), g_hops(mc.n_global_slots, 0), g_events(mc.n_global_slots, 0);
+    std::vector<double> g_e_net(mc.n_global_slots, 0.0), g_e_syn(mc.n_global_slots, 0.0), g_e_dend(mc.n_global_slots, 0.0);
+    mc.core_syn_base.assign(LC, 0);
+    std::vector<uint64_t> core_axon_beg(LC + 1, 0);
+    std::vector<uint32_t> dest_axon_count(d.n_cores, 0);
+    std::vector<uint64_t> out_count(static_cast<size_t>(mc.n_global_slots) + 1, 0);
+    const bool keep_out_tables = (n_ranks == 1);
+
+    int64_t i = 0;
+    while (i < E)
+    {
+        const uint64_t e0 = eo[i];
+        const uint32_t dc = d.neuron_core[d.edge_dst[e0]];
+        const uint32_t pre = mc.slot_of_gid[d.edge_src[e0]];
+        int64_t j = i;
+        while (j < E && static_cast<uint32_t>(d.neuron_core[d.edge_dst[eo[j]]]) == dc && mc.slot_of_gid[d.edge_src[eo[j]]] == pre) j++;
+        const uint32_t nsyn = static_cast<uint32_t>(j - i);
+        const Template &dt = tmpl_of(dc);
+        const int bp = d.core_buffer_pos[dc];
+        const bool local = dc >= mc.first_core && dc < mc.last_core;
+        // processing delay of the message: pipeline_process_axon_in + process_message, src/chip.cpp:738-800
+        if (dt.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
+        double proc = dt.ain_l[0];
+        double e_syn = 0.0, e_dend = 0.0;
+        for (int64_t k = i; k < j; k++)
+        {
+            const uint64_t e = eo[k];
+            const UnitInfo &su = dt.units[edge_syn_unit[e]];
+            const int64_t dst = d.edge_dst[e];
+            double lat = 0.0; // execute_pipeline: total_latency
+            lat += *su.l_spike;
+            e_syn += *su.e_spike;
+            if (bp > SANAFE_BUF_BEFORE_DENDRITE)
+            {
+                const UnitInfo &du = dt.units[dend_unit[dst]];
+                if (!du.e_update) throw std::runtime_error("Dendrite unit does not simulate energy or provide a default energy cost in the architecture description.");
+                if (!du.l_update) throw std::runtime_error("Dendrite unit does not simulate latency or provide a default latency cost in the architecture description.");
+                lat += *du.l_update;
+                e_dend += *du.e_update;
+            }
+            proc += lat;
+        }
+        // network costs: sim_estimate_network_costs, src/chip.cpp:1127-1169
+        const uint32_t sc = mc.core_of_slot[pre];
+        const uint32_t st = mc.core_tile[sc], dtile = mc.core_tile[dc];
+        const uint32_t sx = mc.tile_x[st], sy = mc.tile_y[st], dx = mc.tile_x[dtile], dy = mc.tile_y[dtile];
+        const uint32_t xh = sx > dx ? sx - dx : dx - sx, yh = sy > dy ? sy - dy : dy - sy;
+        double min_hop = 0.0, e_hop = 0.0;
+        if (sx < dx)
+        {
+            min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_EAST];
+            e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_EAST];
+        }
+        else
+        {
+            min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_WEST];
+            e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_WEST];
+        }
+        if (sy < dy)
+        {
+            min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_NORTH];
+            e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_NORTH];
+        }
+        else
+        {
+            min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_SOUTH];
+            e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_SOUTH];
+        }
+        // axon energies count only when the core has exactly one such unit: the counters live on
+        // unit 0 but the energy is read from the LAST unit (src/chip.cpp:1215-1221, 1248-1253)
+        const Template &stt = tmpl_of(sc);
+        const double e_aout = stt.aout_e.size() == 1 ? stt.aout_e[0] : 0.0;
+        const double e_ain = dt.ain_e.size() == 1 ? dt.ain_e[0] : 0.0;
+        g_packets[pre] += 1;
+        g_hops[pre] += xh + yh;
+        g_events[pre] += nsyn;
+        g_e_net[pre] += (e_aout + e_hop) + e_ain;
+        g_e_syn[pre] += e_syn;
+        g_e_dend[pre] += e_dend;
+        const uint32_t axon_id = dest_axon_count[dc]++;
+        if (local)
+        {
+            const uint32_t lc = dc - mc.first_core;
+            const uint64_t syn0 = mc.syn_meta.size();
+            if (core_axon_beg[lc + 1] == 0) mc.core_syn_base[lc] = syn0;
+            if (syn0 - mc.core_syn_base[lc] > 0xffffffffull) throw UnsupportedError("more than 2^32 synapses on one core");
+            mc.ax_pre.push_back(pre);
+            mc.ax_syn_beg.push_back(static_cast<uint32_t>(syn0 - mc.core_syn_base[lc]));
+            mc.ax_nsyn.push_back(nsyn);
+            mc.ax_proc_delay.push_back(proc);
+            if (keep_out_tables)
+            {
+                mc.ax_dest_core.push_back(dc);
+                mc.ax_dest_axon_id.push_back(axon_id);
+                mc.ax_hops.push_back(xh + yh);
+                mc.ax_min_hop_delay.push_back(min_hop);
+                out_count[pre + 1]++;
+            }
+            core_axon_beg[lc + 1]++;
+            for (int64_t k = i; k < j; k++)
+            {
+                const uint64_t e = eo[k];
+                const int64_t dst = d.edge_dst[e];
+                const uint32_t post = offset_in_core[dst];
+                if (post > 0xffffu) throw UnsupportedError("more than 65536 neurons on one core");
+                uint32_t meta = post;
+                if (neuron_dend_kind[dst] == 2) meta |= static_cast<uint32_t>(edge_delay_eff.empty() ? 0 : edge_delay_eff[e]) << 16;
+                if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
+                mc.syn_meta.push_back(meta);
+                mc.syn_weight.push_back(d.edge_weight[e]);
+            }
+        }
+        i = j;
+    }
+    for (uint32_t k = 0; k < LC; k++) core_axon_beg[k + 1] += core_axon_beg[k];
+    // cores without inbound axons still need a valid synapse base
+    {
+        uint64_t run = 0;
+        for (uint32_t k = 0; k < LC; k++)
+        {
+            if (core_axon_beg[k + 1] == core_axon_beg[k]) mc.core_syn_base[k] = run;
+            else
+            {
+                const uint64_t last = core_axon_beg[k + 1] - 1;
+                run = mc.core_syn_base[k] + mc.ax_syn_beg[last] + mc.ax_nsyn[last];
+            }
+        }
+    }
+    // per-slot aggregates of the local slots
+    mc.slot_packets.assign(g_packets.begin() + SO, g_packets.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    mc.slot_hops.assign(g_hops.begin() + SO, g_hops.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    mc.slot_events.assign(g_events.begin() + SO, g_events.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    mc.slot_e_net.assign(g_e_net.begin() + SO, g_e_net.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    mc.slot_e_syn.assign(g_e_syn.begin() + SO, g_e_syn.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    mc.slot_e_dend.assign(g_e_dend.begin() + SO, g_e_dend.begin() + SO + std::min<uint32_t>(LS, mc.n_global_slots - SO));
+    for (auto *v : {&mc.slot_packets, &mc.slot_hops, &mc.slot_events}) v->resize(LS, 0);
+    for (auto *v : {&mc.slot_e_net, &mc.slot_e_syn, &mc.slot_e_dend}) v->resize(LS, 0.0);
+
+    // ------------------------------------------------------------------ delivery slices
+    {
+        const uint64_t A = mc.ax_pre.size();
+        const uint64_t chunk = std::max<uint64_t>(4096, ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
+        for (uint32_t k = 0; k < LC; k++)
+        {
+            uint64_t b = core_axon_beg[k];
+            const uint64_t e = core_axon_beg[k + 1];
+            while (b < e)
+            {
+                // later slices start on a multiple of 4 axons so the 16-byte ax_pre loads stay aligned
+                uint64_t n = std::min<uint64_t>(chunk, e - b);
+                if (b + n < e) n -= (b + n) & 3ull;
+                mc.slice_core.push_back(k);
+                mc.slice_axon_beg.push_back(b);
+                mc.slice_axon_end.push_back(b + n);
+                b += n;
+            }
+        }
+    }
+    // ------------------------------------------------------------------ out tables (host message reconstruction)
+    if (keep_out_tables)
+    {
+        mc.out_ptr.assign(out_count.begin(), out_count.end());
+        for (size_t s = 0; s < mc.n_global_slots; s++) mc.out_ptr[s + 1] += mc.out_ptr[s];
+        mc.out_axon.resize(mc.ax_pre.size());
+        std::vector<uint64_t> cur(mc.out_ptr.begin(), mc.out_ptr.end() - 1);
+        for (uint64_t a = 0; a < mc.ax_pre.size(); a++) mc.out_axon[cur[mc.ax_pre[a]]++] = a; // ascending destination core
+    }
+}
+} // namespace sanafe_amd

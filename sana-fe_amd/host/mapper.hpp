@@ -1,0 +1,99 @@
+// mapper.hpp -- lowers a sanafe_desc (architecture + mapped SNN) to the flat device
+// image of include/sanafe_hip.h, reproducing the reference's mapping ORDER rules:
+//   SpikingChip::map_neurons / map_connections / map_axons, src/chip.cpp:186-408,
+//   1263-1391; Core::map_neuron / map_connection, src/core.cpp:116-184.
+// Everything is columnar; no per-neuron or per-synapse heap objects exist at any point.
+#ifndef SANAFE_HOST_MAPPER_HPP
+#define SANAFE_HOST_MAPPER_HPP
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/sanafe_desc.h"
+#include "../../include/sanafe_hip.h"
+
+namespace sanafe_amd
+{
+// Same exception vocabulary as the reference (src/mapped.hpp:30-38).
+class HardwareMappingError : public std::runtime_error
+{
+public:
+    explicit HardwareMappingError(const std::string &m) : std::runtime_error(m) {}
+};
+// Raised for configurations the MI355X backend does not implement yet.  The product never
+// falls back to a CPU path: load() fails loudly instead.
+class UnsupportedError : public std::runtime_error
+{
+public:
+    explicit UnsupportedError(const std::string &m) : std::runtime_error(m) {}
+};
+
+struct MappedChip
+{
+    // ---- geometry ----
+    uint32_t n_tiles{0}, n_cores{0};
+    std::vector<uint32_t> tile_x, tile_y;
+    std::vector<uint32_t> core_tile, core_offset;
+    uint32_t noc_width{1}, noc_height{1}, noc_buffer{0}, max_cores_per_tile{0};
+    uint64_t mapped_tiles{0}, mapped_cores{0};
+    double sync_delay{0.0};
+
+    // ---- slot layout (global, all ranks) ----
+    uint32_t n_global_slots{0};
+    std::vector<uint32_t> core_nbase, core_ncount;     // global slot base per core
+    std::vector<uint32_t> slot_of_gid;                 // neuron (desc order) -> global slot
+    std::vector<int64_t> gid_of_slot;                  // global slot -> neuron, -1 for padding
+    std::vector<uint32_t> core_of_slot;
+
+    // ---- rank window ----
+    uint32_t first_core{0}, last_core{0};              // [first, last) cores held by this rank
+    uint32_t slot_offset{0}, n_slots{0};
+
+    // ---- image arrays (local to the rank) ----
+    std::vector<uint32_t> l_core_nbase, l_core_ncount;
+    std::vector<double> core_axon_out_latency, core_axon_in_latency;
+    std::vector<sanafe_hip_soma_class> soma_classes;
+    std::vector<sanafe_hip_cost_class> cost_classes;
+    std::vector<uint32_t> slot_cls, slot_aux, slot_packets, slot_hops, slot_events;
+    std::vector<double> slot_bias, slot_v0, slot_e_net, slot_e_syn, slot_e_dend;
+    std::vector<uint32_t> in_train_beg, in_train_len, in_train_bits;
+    std::vector<int64_t> in_rate_period;
+    uint32_t ring_slots{1};
+    std::vector<uint32_t> slice_core;
+    std::vector<uint64_t> slice_axon_beg, slice_axon_end, core_syn_base;
+    std::vector<uint32_t> ax_pre, ax_syn_beg, ax_nsyn;
+    std::vector<double> ax_proc_delay;
+    std::vector<uint32_t> syn_meta;
+    std::vector<double> syn_weight;
+
+    // ---- host-side tables for message reconstruction (detailed timing, message trace) ----
+    // inbound axons (global over all destination cores of THIS rank) carry their destination;
+    // out_ptr/out_axon list, per GLOBAL slot, the axons a spike of that neuron activates,
+    // in the reference's message order (ascending destination core).
+    std::vector<uint32_t> ax_dest_core;     // global core id
+    std::vector<uint32_t> ax_dest_axon_id;  // index inside the destination core's axons_in
+    std::vector<uint32_t> ax_hops;
+    std::vector<double> ax_min_hop_delay;
+    std::vector<uint64_t> out_ptr;          // [n_global_slots + 1]
+    std::vector<uint64_t> out_axon;
+
+    // ---- per-slot host info ----
+    std::vector<uint8_t> slot_log_spikes, slot_log_potential;
+    std::vector<uint8_t> slot_model;        // SANAFE_SOMA_* (local slots)
+
+    // neuron groups (for trace ordering: lexicographic group name, offset)
+    std::vector<std::string> group_names;
+    std::vector<int64_t> group_ptr;
+    std::vector<int> group_lex_order;
+
+    sanafe_hip_image image() const;
+};
+
+// Maps `desc` and lowers the part owned by `rank` of `n_ranks` (tiles are split in
+// contiguous blocks).  Throws std::exception subclasses on any error.
+void map_and_lower(const sanafe_desc &desc, int n_ranks, int rank, uint32_t target_slices, MappedChip &out);
+} // namespace sanafe_amd
+
+#endif

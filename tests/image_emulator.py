@@ -1,0 +1,164 @@
+"""numpy emulation of the three device kernels over a lowered image (tests only).
+
+It follows sana-fe_amd/csrc/sanafe_hip.hip statement for statement, so that the mapper and the
+lowered-image semantics can be checked against the oracle on a machine without a GPU.  It is NOT
+a fallback: nothing in the product imports it."""
+import numpy as np
+
+
+class ImageEmulator:
+    def __init__(self, im):
+        self.im = im
+        n = im["n_slots"]
+        self.v = im["slot_v0"].astype(np.float64).copy()
+        self.icur = np.zeros(n)
+        self.refrac = np.zeros(n, dtype=np.int64)
+        self.status = np.zeros(n, dtype=np.uint8)
+        self.R = im["ring_slots"]
+        self.ring = np.zeros((self.R, n))
+        self.valid = np.zeros((self.R, n), dtype=bool)
+        self.in_pos = np.zeros(max(1, im["n_input"]), dtype=np.int64)
+        self.t = 0
+        cls = im["slot_cls"]
+        self.model = cls & 7
+        self.inkind = (cls >> 3) & 7
+        self.ccls = (cls >> 6) & 1023
+        self.pcls = cls >> 16
+        self.core_of_slot = np.zeros(n, dtype=np.int64)
+        for c in range(im["n_cores"]):
+            b, k = im["core_nbase"][c], im["core_ncount"][c]
+            self.core_of_slot[b:b + ((k + 63) // 64) * 64] = c
+        self.slot_core_off = np.arange(n) - im["core_nbase"][self.core_of_slot]
+
+    @staticmethod
+    def _cvt(x):
+        y = np.where((x > -2147483649.0) & (x < 2147483648.0), np.trunc(x), -2147483648.0)
+        return y
+
+    def step(self):
+        im = self.im
+        done, t = self.t, self.t + 1
+        rs = t % self.R
+        n = im["n_slots"]
+        status = np.zeros(n, dtype=np.uint8)
+        has_in = np.where(self.inkind == 1, True, self.valid[rs])
+        cur = np.where(self.inkind == 1, 0.0, np.where(self.valid[rs], self.ring[rs], 0.0))
+        buf = (self.inkind == 0) & self.valid[rs] & (self.model != 0)
+        self.ring[rs][buf] = 0.0
+        self.valid[rs][buf] = False
+        bias = im["slot_bias"]
+        sc = im["soma_classes"]
+
+        def col(name):
+            return np.array([c[name] for c in sc])[np.minimum(self.pcls, len(sc) - 1)]
+
+        with np.errstate(all="ignore"):
+            # ---- LIF ----
+            m = self.model == 1
+            if m.any():
+                v, ic, rc = self.v.copy(), self.icur.copy(), self.refrac.copy()
+                st = np.where((np.abs(v) > 0) | has_in | (np.abs(bias) > 0) | (col("force_update") != 0), 2, 1)
+                if done > 0:
+                    ic = ic * col("input_decay")
+                    v = v * col("leak_decay")
+                v = self._cvt(v * 64.0) / 64.0
+                active = ~(rc > 0)
+                v2 = v + bias
+                ic2 = ic + np.where(has_in, cur, 0.0)
+                v2 = v2 + ic2
+                th, rth = col("threshold"), col("reverse_threshold")
+                fired = v2 > th
+                rm, rrm = col("reset_mode"), col("reverse_reset_mode")
+                v3 = np.where(fired & (rm == 2), col("reset"), np.where(fired & (rm == 1), v2 - th, v2))
+                rc2 = np.where(fired, col("refractory_delay"), rc)
+                below = v3 < rth
+                v4 = np.where(below & (rrm == 1), v3 - rth,
+                              np.where(below & (rrm == 2), col("reverse_reset"), np.where(below & (rrm == 3), rth, v3)))
+                v = np.where(active, v4, v)
+                ic = np.where(active, ic2, ic)
+                rc = np.where(active, rc2, rc)
+                st = np.where(active & fired, 3, st)
+                rc = np.maximum(rc - 1, 0)
+                self.v[m], self.icur[m], self.refrac[m] = v[m], ic[m], rc[m]
+                status[m] = st[m]
+            # ---- TrueNorth ----
+            m = self.model == 2
+            if m.any():
+                v = self.v.copy()
+                st = np.where((np.abs(v) > 0) | has_in | (np.abs(bias) > 0) | (col("force_update") != 0), 2, 1)
+                leak, ltz = col("leak_decay"), col("leak_towards_zero") != 0
+                v = np.where(ltz, np.where(v > 0, v - leak, np.where(v < 0, v + leak, v)), v + leak)
+                v = v + bias
+                v = np.where(has_in, v + cur, v)
+                th, rth = col("threshold"), col("reverse_threshold")
+                rm, rrm = col("reset_mode"), col("reverse_reset_mode")
+                fired = v >= th
+                low = (~fired) & (v <= rth)
+                vf = np.where(rm == 2, col("reset"), np.where(rm == 1, v - th, np.where(rm == 3, th, v)))
+                vl = np.where(rrm == 2, col("reverse_reset"), np.where(rrm == 1, v + rth, np.where(rrm == 3, rth, v)))
+                v = np.where(fired, vf, np.where(low, vl, v))
+                st = np.where(fired, 3, st)
+                self.v[m] = v[m]
+                status[m] = st[m]
+        # ---- input ----
+        for g in np.nonzero(self.model == 3)[0]:
+            a = im["slot_aux"][g]
+            pos = self.in_pos[a]
+            send = False
+            if pos < im["in_train_len"][a]:
+                b = int(im["in_train_beg"][a]) + int(pos)
+                send = bool((int(im["in_train_bits"][b >> 5]) >> (b & 31)) & 1)
+                self.in_pos[a] = pos + 1
+            period = im["in_rate_period"][a]
+            if period > 0 and t % period == 0:
+                send = True
+            status[g] = 3 if send else 1
+        self.status = status
+        live = self.model != 0
+        cc = im["cost_classes"]
+        se = np.array([c["soma_energy"] for c in cc])[self.ccls]
+        sl = np.array([c["soma_latency"] for c in cc])[self.ccls]
+        de = np.array([c["dendrite_energy"] for c in cc])[self.ccls]
+        dl = np.array([c["dendrite_latency"] for c in cc])[self.ccls]
+        idx = np.maximum(status.astype(np.int64) - 1, 0)
+        ar = np.arange(n)
+        fired = status == 3
+        tot = dict(timesteps=1, spikes=int(im["slot_events"][fired].sum()), packets_sent=int(im["slot_packets"][fired].sum()),
+                   neurons_updated=int((status >= 2).sum()), neurons_fired=int(fired.sum()),
+                   total_hops=int(im["slot_hops"][fired].sum()))
+        tot["soma_energy"] = float(se[ar, idx][live].sum())
+        tot["dendrite_energy"] = float(de[live].sum() + im["slot_e_dend"][fired].sum())
+        tot["synapse_energy"] = float(im["slot_e_syn"][fired].sum())
+        tot["network_energy"] = float(im["slot_e_net"][fired].sum())
+        tot["total_energy"] = tot["network_energy"] + tot["synapse_energy"] + tot["dendrite_energy"] + tot["soma_energy"]
+        lat = np.where(live, (0.0 + dl) + sl[ar, idx], 0.0)
+        gen = np.zeros(im["n_cores"])
+        np.add.at(gen, self.core_of_slot, lat)
+        pk = np.zeros(im["n_cores"])
+        np.add.at(pk, self.core_of_slot[fired], im["slot_packets"][fired])
+        gen += pk * im["core_axon_out_latency"]
+        # ---- delivery ----
+        proc = np.zeros(im["n_cores"])
+        fired_global = fired  # single rank: local == global
+        for s in range(im["n_slices"]):
+            c = im["slice_core"][s]
+            a0, a1 = int(im["slice_axon_beg"][s]), int(im["slice_axon_end"][s])
+            act = np.nonzero(fired_global[im["ax_pre"][a0:a1]])[0] + a0
+            if len(act) == 0:
+                continue
+            proc[c] += im["ax_proc_delay"][act].sum()
+            base = int(im["core_syn_base"][c])
+            nb = im["core_nbase"][c]
+            for a in act:
+                s0 = base + int(im["ax_syn_beg"][a])
+                for k in range(int(im["ax_nsyn"][a])):
+                    meta = int(im["syn_meta"][s0 + k])
+                    if (meta >> 19) & 1:
+                        continue
+                    post, d = meta & 0xffff, (meta >> 16) & 7
+                    ws = (t + 1 + d) % self.R
+                    self.ring[ws][nb + post] += im["syn_weight"][s0 + k]
+                    self.valid[ws][nb + post] = True
+        tot["sim_time"] = float(max(proc.max(), gen.max()) + im["sync_delay"])
+        self.t = t
+        return tot

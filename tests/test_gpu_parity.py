@@ -1,0 +1,209 @@
+"""Parity of the MI355X path (through the C ABI) against the CPU oracle on the same inputs.
+
+Integer outputs (statuses, spike lists, counters, message ids/hops) are compared exactly;
+potentials bit-for-bit where weights are integers (all reference configs) and within 1e-9
+relative otherwise; energies and simulated time within 1e-9 relative (north_star asks 1e-6)."""
+import numpy as np
+import pytest
+
+import nets
+from oracle.oracle import OracleChip
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = (("spikes", "spike_count"), ("packets_sent", "packets_sent"), ("neurons_updated", "neurons_updated"),
+            ("neurons_fired", "neurons_fired"), ("total_hops", "total_hops"))
+DBL_KEYS = ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy", "network_energy", "sim_time")
+REL = 1e-9
+
+
+def make(S, arch, net):
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    return chip, OracleChip(S.to_desc(arch, net))
+
+
+def check_stepwise(S, arch, net, steps, timing="simple", exact_v=True):
+    chip, orc = make(S, arch, net)
+    for t in range(steps):
+        a = chip.run(1, timing, record=True)
+        b = orc.step(timing)
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        st = orc.status()
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.step_fired(0), (st == 3).astype(np.uint8)), t
+        if exact_v:
+            assert np.array_equal(chip.potentials(), orc.potentials()), t
+        else:
+            assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-9, atol=1e-12), t
+    return chip, orc
+
+
+def check_batched(S, arch, net, steps, timing="simple"):
+    """Whole run on the device in one call, per-step records compared afterwards."""
+    chip, orc = make(S, arch, net)
+    tot = chip.run(steps, timing, record=True)
+    recs = chip.step_totals(0, steps)
+    acc = {}
+    for t in range(steps):
+        b = orc.step(timing)
+        for ka, kb in INT_KEYS:
+            assert recs[ka][t] == b[kb], (t, ka)
+        for k in DBL_KEYS:
+            assert recs[k][t] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        assert np.array_equal(chip.step_fired(t), (orc.status() == 3).astype(np.uint8)), t
+        for k, v in b.items():
+            acc[k] = acc.get(k, 0) + v
+    for ka, kb in INT_KEYS:
+        assert tot[ka] == acc[kb]
+    for k in DBL_KEYS:
+        assert tot[k] == pytest.approx(acc[k], rel=REL)
+    assert np.array_equal(chip.potentials(), orc.potentials())
+    return chip, orc, tot
+
+
+def test_example_chip_simple(S):
+    check_stepwise(S, *nets.example(S), steps=30)
+
+
+def test_example_chip_probe_values(S):
+    """The reference's recorded outputs for C1, now from the GPU path, detailed timing."""
+    arch, net = nets.example(S)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    r = chip.sim(10, timing_model="detailed", spike_trace=True, potential_trace=True)
+    assert (r["spikes"], r["packets_sent"], r["neurons_updated"], r["neurons_fired"]) == (5, 3, 20, 3)
+    assert r["energy"]["total"] == pytest.approx(1.04e-09, rel=5e-3)
+    assert r["sim_time"] == pytest.approx(1.24e-07, rel=5e-3)
+    assert r["spike_trace"][:3] == [[("in", 1)], [("out", 1)], [("in", 1)]]
+    assert r["potential_trace"][:4] == [[0.0, 0.0], [1.0, 0.0], [1.0, -4.0], [2.0, -1.0]]
+
+
+def test_example_chip_detailed_messages(S):
+    arch, net = nets.example(S)
+    chip, orc = make(S, arch, net)
+    for t in range(12):
+        a = chip.run(1, "detailed", record=True)
+        b = orc.step("detailed")
+        assert a["sim_time"] == b["sim_time"], t  # same serial algorithm on identical inputs: bit-exact
+        ma, mb = chip.step_messages(0), orc.messages()
+        assert len(ma) == len(mb)
+        for name in ma.dtype.names:
+            assert np.array_equal(ma[name], mb[name]), (t, name)
+
+
+def test_random_loihi_before_soma(S):
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=100, out_degree=24, arch_kind="loihi", refractory=True)
+    check_stepwise(S, arch, net, steps=25)
+
+
+def test_random_loihi_delay_line(S):
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=100, out_degree=24, arch_kind="large", delays=True)
+    check_stepwise(S, arch, net, steps=30)
+
+
+def test_random_loihi_detailed_messages(S):
+    arch, net = nets.random_loihi(S, n_tiles=6, neurons_per_core=50, out_degree=16, arch_kind="loihi", seed=3)
+    chip, orc = make(S, arch, net)
+    for t in range(8):
+        a = chip.run(1, "detailed", record=True)
+        b = orc.step("detailed")
+        ma, mb = chip.step_messages(0), orc.messages()
+        assert len(ma) == len(mb) > 0
+        for name in ma.dtype.names:
+            assert np.array_equal(ma[name], mb[name]), (t, name)
+        assert a["sim_time"] == b["sim_time"]
+
+
+def test_plain_accumulator_inside_dendrite_quirk(S):
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
+    for g in net._order:
+        g.dendrite_hw[:] = net.strings("loihi_dendrites")
+    check_stepwise(S, arch, net, steps=12)
+
+
+def test_truenorth(S):
+    check_stepwise(S, *nets.truenorth_net(S, n_tiles=16, neurons_per_core=256), steps=20)
+
+
+def test_float_weights(S):
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=16, arch_kind="loihi", weights="float")
+    check_stepwise(S, arch, net, steps=20, exact_v=False)
+
+
+def test_multi_slice_core(S):
+    """A core whose inbound axon list is split over several delivery workgroups (atomic write-back)."""
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=1000, cores_used=4, out_degree=600, arch_kind="loihi",
+                                  p_fire=0.3)
+    chip, orc = check_stepwise(S, arch, net, steps=6)
+    assert chip.info()["n_slices"] > 4
+
+
+def test_batched_run_records(S):
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=128, out_degree=32, arch_kind="large", delays=True, seed=5)
+    check_batched(S, arch, net, steps=40)
+
+
+@pytest.mark.slow
+def test_tutorial5_dvs_golden_on_gpu(S):
+    """tutorial/tutorial_5_dvs.ipynb: neurons_fired == 365277 after 1000 steps -- from the HIP path."""
+    arch, net = nets.tutorial5_dvs(S)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    r = chip.sim(1000, timing_model="simple")
+    assert r["neurons_fired"] == 365277
+
+
+@pytest.mark.slow
+def test_dvs_yaml_c2_spike_trace(S):
+    """Config C2: loihi + dvs.yaml, spike trace bit-exact vs the oracle, potentials of group 1 equal."""
+    arch, net = nets.dvs_yaml(S)
+    chip, orc, tot = check_batched(S, arch, net, steps=300)
+    assert tot["neurons_fired"] > 0
+
+
+def test_set_bias_between_sims(S):
+    """The DVS workflow rewrites input biases between sim() calls (scripts/tcad2025/dvs_gesture.py:140-151)."""
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, arch_kind="loihi", p_fire=0.0)
+    chip, orc = make(S, arch, net)
+    rng = np.random.default_rng(0)
+    for frame in range(3):
+        bias = rng.integers(0, 40, size=net.neuron_count).astype(np.float64)
+        chip.set_bias("n", bias)
+        for g in range(net.neuron_count):
+            orc.set_neuron_attr(g, "bias", (2, float(bias[g]), None, None))
+        for t in range(5):
+            a, b = chip.run(1, "simple"), orc.step("simple")
+            assert a["neurons_fired"] == b["neurons_fired"]
+            assert np.array_equal(chip.potentials(), orc.potentials())
+
+
+def test_reset(S):
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, arch_kind="loihi")
+    chip, orc = make(S, arch, net)
+    for t in range(5):
+        chip.run(1, "simple")
+        orc.step("simple")
+    chip.reset()
+    orc.reset()
+    for t in range(5):
+        a, b = chip.run(1, "simple"), orc.step("simple")
+        assert a["neurons_fired"] == b["neurons_fired"]
+        assert np.array_equal(chip.potentials(), orc.potentials())
+
+
+def test_no_device_fallback_is_an_error(S):
+    """A chip mapped without a device cannot simulate: there is no CPU execution path."""
+    import ctypes as C
+    arch, net = nets.example(S)
+    L = S.chip.lib()
+    built = S.to_desc(arch, net)
+    h = C.c_void_p()
+    assert L.sanafe_chip_create(C.addressof(built.desc), -1, 1, 0, C.byref(h)) == 0
+    t = S.chip.Totals()
+    assert L.sanafe_chip_sim(h, 1, 0, 0, C.byref(t)) != 0
+    assert b"no CPU execution path" in L.sanafe_last_error()
+    L.sanafe_chip_destroy(h)
