@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the SANA-FE timestep loop on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N=1 by default)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
+
+Workload (BASELINE.json configs[2], made concrete in SURVEY 8d): arch/loihi_large.yaml + a synthetic
+random SNN of 262,144 LIF neurons per GPU (512 neurons on each of 512 cores), out-degree 2,621
+(1 % of 262,144), integer weights, `loihi_dendrites_delay` dendrites, 10 % of the neurons biased to
+fire every step; `simple` timing model on the device.  With N GPUs the tiles are sharded in
+contiguous blocks, every GPU holds 262,144 neurons (weak scaling) and the only exchange per step is
+an RCCL all-gather of the spike bitmaps.
+
+One "step" = one simulated timestep of the whole chip.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed):
+    D = S.description
+    n_tiles = max(1024, (cores_per_gpu * n_gpus + 3) // 4) if cores_per_gpu * n_gpus > 4096 else 1024
+    arch = S.presets.loihi_large(n_tiles=n_tiles, n_inputs=4)
+    cores = arch.cores()
+    tiles_per_rank = (n_tiles + n_gpus - 1) // n_gpus
+    n_per_gpu = cores_per_gpu * neurons_per_core
+    n = n_per_gpu * n_gpus
+    net = S.Network("random_%dk" % (n // 1024))
+    g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
+                                "loihi_dendrites_delay", False, True, "loihi_lif")
+    rng = np.random.default_rng(seed)
+    g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128, 0).astype(np.int64), D.ATTR_INT)
+    src, dst, w = S.chip.generate_random_edges(n, out_degree, seed)
+    net._add_edges(src, dst, w, None, np.full(len(src), net.strings("loihi_sparse_synapse"), dtype=np.int32))
+    for r in range(n_gpus):
+        first_core = r * tiles_per_rank * 4
+        for c in range(cores_per_gpu):
+            lo = (r * cores_per_gpu + c) * neurons_per_core
+            g.map_to_core(cores[first_core + c], lo, lo + neurons_per_core)
+    return arch, net
+
+
+def cpu_baseline(S, args):
+    """The oracle (a scalar CPU port of the reference loop) on a bounded sample of the same recipe."""
+    import nets  # noqa: F401
+    from oracle.oracle import OracleChip
+    cores, npc = 64, 256
+    n = cores * npc
+    deg = max(8, n // 100)
+    arch = S.presets.loihi_large(n_tiles=16, n_inputs=4, width=4, height=4)
+    net = S.Network("sample")
+    g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
+                                "loihi_dendrites_delay", False, True, "loihi_lif")
+    rng = np.random.default_rng(args.seed)
+    g.set_attribute_column("bias", np.where(rng.random(n) < args.p_fire, 128, 0).astype(np.int64), S.description.ATTR_INT)
+    src, dst, w = S.chip.generate_random_edges(n, deg, args.seed)
+    net._add_edges(src, dst, w, None, np.full(len(src), net.strings("loihi_sparse_synapse"), dtype=np.int32))
+    ac = arch.cores()
+    for c in range(cores):
+        g.map_to_core(ac[c], c * npc, (c + 1) * npc)
+    chip = OracleChip(S.to_desc(arch, net))
+    for _ in range(3):
+        chip.step("simple")
+    steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        r = chip.step("simple")
+        steps += 1
+        events += r["spike_count"]
+        updates += r["neurons_updated"]
+    dt = time.perf_counter() - t0
+    return dict(steps=steps, seconds=dt, events_per_s=events / dt, updates_per_s=updates / dt, steps_per_s=steps / dt,
+                sample="oracle (scalar C++ port, 1 thread) on %d LIF neurons / %d cores, out-degree %d, %d steps in %.1f s"
+                       % (n, cores, deg, steps, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cores-per-gpu", type=int, default=512)
+    ap.add_argument("--neurons-per-core", type=int, default=512)
+    ap.add_argument("--out-degree", type=int, default=2621)
+    ap.add_argument("--p-fire", type=float, default=0.1)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--timed-steps", type=int, default=20, help="steps of the event-timed roofline pass")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+    import _sanafe_pkg
+    S = _sanafe_pkg.load()
+
+    t_setup = time.perf_counter()
+    arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire, args.seed)
+    t_net = time.perf_counter() - t_setup
+    chip = S.SpikingChip(arch, device=local_rank, n_ranks=world, rank=rank)
+    chip.load(net)
+    info = chip.info()
+    t_load = time.perf_counter() - t_setup - t_net
+    H = S.chip.hip_lib()
+    dev = chip.device_handle()
+
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        stream = torch.cuda.current_stream()
+        assert H.sanafe_hip_set_stream(dev, C.c_void_p(stream.cuda_stream)) == 0
+        bufs = chip.spike_buffers()
+
+        class _Dev:
+            def __init__(self, ptr, nbytes):
+                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+
+        t_local = torch.as_tensor(_Dev(bufs["local_ptr"], bufs["local_bytes"]), device="cuda")
+        t_global = torch.as_tensor(_Dev(bufs["global_ptr"], bufs["global_bytes"]), device="cuda")
+        assert bufs["global_bytes"] == bufs["local_bytes"] * world, "ranks must hold equal slot counts"
+
+        def run_steps(k):
+            for _ in range(k):
+                chip.step_neurons()
+                dist.all_gather_into_tensor(t_global, t_local)  # RCCL over xGMI: the per-step spike exchange
+                chip.step_deliver("simple")
+
+        def sync():
+            torch.cuda.synchronize()
+    else:
+        def run_steps(k):
+            if H.sanafe_hip_step(dev, k, 1, 0) != 0:
+                raise RuntimeError(H.sanafe_hip_last_error().decode())
+
+        def sync():
+            chip.synchronize()
+
+    run_steps(args.warmup)
+    sync()
+    before = chip.read_totals()
+    if dist:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    sync()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    after = chip.read_totals()
+    local = {k: after[k] - before[k] for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")}
+    if dist:
+        import torch
+        t = torch.tensor([elapsed] + [float(local[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")],
+                         dtype=torch.float64, device="cuda")
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        elapsed = float(tmax[0])
+        agg = dict(zip(("spikes", "packets_sent", "neurons_updated", "neurons_fired"), [float(x) for x in t[1:]]))
+    else:
+        agg = {k: float(v) for k, v in local.items()}
+
+    # ---- roofline pass: HIP events around every kernel on its own stream (single-GPU path) ----
+    roof = None
+    if world == 1 and args.timed_steps > 0:
+        H.sanafe_hip_set_timing(dev, 1)
+        b2 = chip.read_totals()
+        if H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
+            raise RuntimeError(H.sanafe_hip_last_error().decode())
+        a2 = chip.read_totals()
+        nm, dm, rm, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        H.sanafe_hip_read_timing(dev, C.byref(nm), C.byref(dm), C.byref(rm), C.byref(ln))
+        H.sanafe_hip_set_timing(dev, 0)
+        ev = (a2["spikes"] - b2["spikes"]) / args.timed_steps
+        msgs = (a2["packets_sent"] - b2["packets_sent"]) / args.timed_steps
+        upd = (a2["neurons_updated"] - b2["neurons_updated"]) / args.timed_steps
+        # 48 B per neuron update, 28 B per synaptic event, 96 B per message.
+        # The delivery kernel does the per-event and per-message work, the neuron kernel the per-neuron work.
+        deliver_bytes = 28.0 * ev + 96.0 * msgs
+        achieved = deliver_bytes / (dm.value * 1e-3) / 1e9 if dm.value > 0 else 0.0
+        roof = {"bound": "hbm", "kernel": "deliver_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_launch": deliver_bytes, "avg_launch_ms": dm.value,
+                "neuron_kernel": {"avg_launch_ms": nm.value, "algorithmic_bytes_per_launch": 48.0 * upd,
+                                  "achieved_GBps": (48.0 * upd) / (nm.value * 1e-3) / 1e9 if nm.value > 0 else 0.0},
+                "reduce_kernel_avg_ms": rm.value, "launches": ln.value,
+                "whole_step": {"algorithmic_bytes": 48.0 * upd + deliver_bytes,
+                               "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        c = cpu_baseline(S, args)
+        events_per_step = agg["spikes"] / args.steps
+        est = c["events_per_s"] / events_per_step if events_per_step > 0 else c["steps_per_s"]
+        cpu = {"value": est, "unit": "timesteps/s", "cores": 1, "kind": "port",
+               "sample": c["sample"] + "; value = measured synaptic-events/s (%.3g) / events per step of the GPU workload (%.3g)"
+                         % (c["events_per_s"], events_per_step),
+               "measured": {"timesteps_per_s_on_sample": c["steps_per_s"], "synaptic_events_per_s": c["events_per_s"],
+                            "neuron_updates_per_s": c["updates_per_s"]}}
+
+    if rank == 0:
+        n_total = args.cores_per_gpu * args.neurons_per_core * world
+        out = {
+            "metric": "simulated timesteps/sec", "value": args.steps / elapsed, "unit": "timesteps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "arch/loihi_large.yaml + synthetic random SNN (BASELINE configs[2]): %d LIF neurons "
+                                   "(%d cores x %d per GPU), out-degree %d, %.0f%% biased to fire every step, "
+                                   "loihi_dendrites_delay, simple timing" % (n_total, args.cores_per_gpu,
+                                                                             args.neurons_per_core, args.out_degree,
+                                                                             100 * args.p_fire),
+                       "neurons": n_total, "synapses_per_gpu": int(info["n_synapses"]), "axons_per_gpu": int(info["n_axons"]),
+                       "timing_model": "simple", "exchange": "rccl all_gather of spike bitmaps" if world > 1 else "none"},
+            "neuron_updates_per_s": agg["neurons_updated"] / elapsed,
+            "synaptic_events_per_s": agg["spikes"] / elapsed, "messages_per_s": agg["packets_sent"] / elapsed,
+            "per_step": {"neurons_updated": agg["neurons_updated"] / args.steps, "neurons_fired": agg["neurons_fired"] / args.steps,
+                         "synaptic_events": agg["spikes"] / args.steps, "messages": agg["packets_sent"] / args.steps},
+            "setup_s": {"build_network": t_net, "map_and_upload": t_load},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -185,6 +185,8 @@ int sanafe_hip_step_deliver(sanafe_hip_chip *chip, int simple_timing, int record
 int sanafe_hip_spike_buffers(sanafe_hip_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
         uint64_t *global_bytes);
 void *sanafe_hip_stream(sanafe_hip_chip *chip); /* hipStream_t the kernels run on */
+/* Run on a caller-owned stream instead (e.g. the stream a collective library orders against). */
+int sanafe_hip_set_stream(sanafe_hip_chip *chip, void *hip_stream);
 
 /* Run totals since create/reset_totals, and per-step records of the last sim. */
 int sanafe_hip_read_totals(sanafe_hip_chip *chip, sanafe_hip_totals *out);

@@ -82,6 +82,12 @@ int sanafe_chip_spike_buffers(sanafe_chip *chip, void **local_bits, uint64_t *lo
 int sanafe_chip_synchronize(sanafe_chip *chip);
 int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out);
 
+/* Synthetic random SNN edges for the benchmark configs: `out_degree` distinct
+ * uniformly drawn targets per neuron, integer weights in {-8..8}\{0}; arrays hold
+ * n_neurons * out_degree entries; global ids are offset by src_base / dst_base. */
+int sanafe_generate_random_edges(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t src_base, int64_t dst_base, int64_t *src, int64_t *dst, double *weight);
+
 #ifdef __cplusplus
 }
 #endif

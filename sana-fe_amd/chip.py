@@ -91,6 +91,8 @@ def lib():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sanafe_chip_synchronize.argtypes = [C.c_void_p]
     L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
+    L.sanafe_generate_random_edges.argtypes = [C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.c_int64,
+                                               C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -108,6 +110,7 @@ def hip_lib():
     L.sanafe_hip_stream.argtypes = [C.c_void_p]
     L.sanafe_hip_stream.restype = C.c_void_p
     L.sanafe_hip_read_core_delays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.sanafe_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     return L
 
 
@@ -515,3 +518,16 @@ def map_only(arch, net, n_ranks=1, rank=0):
         return out, slot_of
     finally:
         L.sanafe_chip_destroy(h)
+
+
+def generate_random_edges(n_neurons, out_degree, seed=1, n_threads=None, src_base=0, dst_base=0):
+    """(src, dst, weight) of the synthetic random SNN of the benchmark configs."""
+    n_threads = n_threads or min(32, os.cpu_count() or 1)
+    e = int(n_neurons) * int(out_degree)
+    src = np.empty(e, dtype=np.int64)
+    dst = np.empty(e, dtype=np.int64)
+    w = np.empty(e, dtype=np.float64)
+    if lib().sanafe_generate_random_edges(n_neurons, out_degree, seed, n_threads, src_base, dst_base, src.ctypes.data,
+                                          dst.ctypes.data, w.ctypes.data) != 0:
+        raise RuntimeError(lib().sanafe_last_error().decode())
+    return src, dst, w

@@ -635,6 +635,7 @@ struct sanafe_hip_chip
 {
     int device{0};
     hipStream_t stream{nullptr};
+    bool own_stream{true};
     DevImage im{};
     DevState st{};
     std::vector<void *> allocs;
@@ -879,7 +880,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     if (c->d_host_slots) (void) hipFree(c->d_host_slots);
     if (c->d_host_status) (void) hipFree(c->d_host_status);
-    if (c->stream) (void) hipStreamDestroy(c->stream);
+    if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
 
@@ -1003,6 +1004,17 @@ extern "C" int sanafe_hip_spike_buffers(sanafe_hip_chip *c, void **local_bits, u
 }
 
 extern "C" void *sanafe_hip_stream(sanafe_hip_chip *c) { return c ? c->stream : nullptr; }
+
+extern "C" int sanafe_hip_set_stream(sanafe_hip_chip *c, void *stream)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->own_stream) HIPCHK(hipStreamDestroy(c->stream));
+    c->stream = static_cast<hipStream_t>(stream);
+    c->own_stream = false;
+    return 0;
+}
 
 template <typename T> static int d2h(sanafe_hip_chip *c, T *dst, const T *src, size_t n)
 {

@@ -674,7 +674,8 @@ def to_desc(arch: Architecture, net: Network) -> BuiltDesc:
     d = Desc()
 
     def arr(values, dtype):
-        a = np.ascontiguousarray(values, dtype=dtype)
+        a = values if (isinstance(values, np.ndarray) and values.dtype == dtype and values.flags.c_contiguous) \
+            else np.ascontiguousarray(values, dtype=dtype)
         if a.size == 0:
             a = np.zeros(1, dtype=dtype)
         keep.append(a)
@@ -771,7 +772,10 @@ def to_desc(arch: Architecture, net: Network) -> BuiltDesc:
     # ---- edges
     blocks = net._edge_blocks
     d.n_edges = net._n_edges
-    if blocks:
+    if len(blocks) == 1:
+        src, dst, w, _, hw = blocks[0]  # no copy: synthetic networks are one multi-GB block
+        dl = blocks[0][3]
+    elif blocks:
         src = np.concatenate([b[0] for b in blocks])
         dst = np.concatenate([b[1] for b in blocks])
         w = np.concatenate([b[2] for b in blocks])

@@ -8,8 +8,11 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <random>
+#include <thread>
 #include <list>
 #include <memory>
 #include <queue>
@@ -283,7 +286,12 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     auto chip = std::make_unique<sanafe_chip>();
     try
     {
-        sanafe_amd::map_and_lower(*desc, n_ranks, rank, 2048, chip->mc);
+        // SANAFE_TARGET_SLICES: delivery work items to aim for (tests use it to force multi-slice cores)
+        uint32_t target_slices = 2048;
+        if (const char *env = std::getenv("SANAFE_TARGET_SLICES")) target_slices = static_cast<uint32_t>(std::max(1L, std::atol(env)));
+        uint32_t min_slice_axons = 4096;
+        if (const char *env = std::getenv("SANAFE_MIN_SLICE_AXONS")) min_slice_axons = static_cast<uint32_t>(std::max(4L, std::atol(env)));
+        sanafe_amd::map_and_lower(*desc, n_ranks, rank, target_slices, min_slice_axons, chip->mc);
     }
     catch (const sanafe_amd::UnsupportedError &e)
     {
@@ -591,5 +599,53 @@ extern "C" int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out
 {
     if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
     DEV(sanafe_hip_read_totals(chip->dev, out));
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Synthetic-network generator for the benchmark configs (after
+// scripts/tcad2025/random_network.py:63-105): every neuron gets `out_degree` distinct targets
+// drawn uniformly (rejection against a per-thread bitmap) and an integer weight in
+// {-8..8}\{0}; neuron i uses its own std::mt19937_64 stream seeded from (seed, i), so the
+// result does not depend on the thread count.
+// ---------------------------------------------------------------------------------------------
+extern "C" int sanafe_generate_random_edges(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t src_base, int64_t dst_base, int64_t *src, int64_t *dst, double *weight)
+{
+    if (n_neurons <= 0 || out_degree < 0 || out_degree > n_neurons || !src || !dst || !weight)
+        return fail(SANAFE_HIP_ERR_INVALID, "bad generator arguments");
+    n_threads = std::max(1, n_threads);
+    auto work = [&](int tid) {
+        std::vector<uint64_t> seen((n_neurons + 63) / 64, 0);
+        for (int64_t i = tid; i < n_neurons; i += n_threads)
+        {
+            std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(i) + 1);
+            int64_t *d = dst + i * out_degree;
+            for (int64_t k = 0; k < out_degree; k++)
+            {
+                uint64_t r;
+                do
+                {
+                    r = gen() % static_cast<uint64_t>(n_neurons);
+                } while (seen[r >> 6] & (1ull << (r & 63)));
+                seen[r >> 6] |= 1ull << (r & 63);
+                d[k] = dst_base + static_cast<int64_t>(r);
+                src[i * out_degree + k] = src_base + i;
+                const uint64_t w = gen();
+                const double mag = static_cast<double>(1 + (w % 8));
+                weight[i * out_degree + k] = (w & (1ull << 40)) ? mag : -mag;
+            }
+            for (int64_t k = 0; k < out_degree; k++)
+            {
+                const uint64_t r = static_cast<uint64_t>(d[k] - dst_base);
+                seen[r >> 6] &= ~(1ull << (r & 63));
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
     return 0;
 }

@@ -8,6 +8,9 @@
 #include <numeric>
 #include <optional>
 #include <tuple>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace sanafe_amd
 {
@@ -236,8 +239,16 @@ sanafe_hip_image MappedChip::image() const
     return im;
 }
 
-void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_slices, MappedChip &mc)
+void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_slices, uint32_t min_slice_axons, MappedChip &mc)
 {
+    const bool timing = std::getenv("SANAFE_MAP_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[map] %-28s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
     // ------------------------------------------------------------------ architecture
     mc.n_tiles = d.n_tiles;
@@ -591,6 +602,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});
     mc.ring_slots = any_delay_dendrite ? 6 : 1;
 
+    lap("neurons + slots");
     // ------------------------------------------------------------------ map_connections, src/chip.cpp:334-380
     const int64_t E = d.n_edges;
     std::vector<int32_t> edge_syn_unit(E);  // unit index inside the destination core's template
@@ -665,6 +677,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         }
     }
 
+    lap("edge units + delays");
     // ------------------------------------------------------------------ map_axons, src/chip.cpp:382-408, 1263-1391
     // Delivery order at a destination core = (source core id, source neuron order, connection
     // order) = (pre slot, creation order): two stable counting sorts.
@@ -674,6 +687,12 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(d.neuron_core[d.edge_dst[e]]); }, d.n_cores, tmp);
     tmp.clear();
     tmp.shrink_to_fit();
+    lap("edge sorts");
+    if (rank >= 0)
+    {
+        mc.syn_meta.reserve(n_ranks == 1 ? E : E / n_ranks + E / 8);
+        mc.syn_weight.reserve(n_ranks == 1 ? E : E / n_ranks + E / 8);
+    }
 
     std::vector<uint32_t> g_packets(mc.n_global_slots, 0), g_hops(mc.n_global_slots, 0), g_events(mc.n_global_slots, 0);
     std::vector<double> g_e_net(mc.n_global_slots, 0.0), g_e_syn(mc.n_global_slots, 0.0), g_e_dend(mc.n_global_slots, 0.0);
@@ -789,6 +808,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         }
         i = j;
     }
+    lap("axons + synapses");
     for (uint32_t k = 0; k < LC; k++) core_axon_beg[k + 1] += core_axon_beg[k];
     // cores without inbound axons still need a valid synapse base
     {
@@ -816,7 +836,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     // ------------------------------------------------------------------ delivery slices
     {
         const uint64_t A = mc.ax_pre.size();
-        const uint64_t chunk = std::max<uint64_t>(4096, ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
+        const uint64_t chunk = std::max<uint64_t>(std::max<uint32_t>(4, min_slice_axons & ~3u), ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
         for (uint32_t k = 0; k < LC; k++)
         {
             uint64_t b = core_axon_beg[k];

@@ -93,7 +93,7 @@ struct MappedChip
 
 // Maps `desc` and lowers the part owned by `rank` of `n_ranks` (tiles are split in
 // contiguous blocks).  Throws std::exception subclasses on any error.
-void map_and_lower(const sanafe_desc &desc, int n_ranks, int rank, uint32_t target_slices, MappedChip &out);
+void map_and_lower(const sanafe_desc &desc, int n_ranks, int rank, uint32_t target_slices, uint32_t min_slice_axons, MappedChip &out);
 } // namespace sanafe_amd
 
 #endif

@@ -78,7 +78,8 @@ def test_example_chip_probe_values(S):
     assert (r["spikes"], r["packets_sent"], r["neurons_updated"], r["neurons_fired"]) == (5, 3, 20, 3)
     assert r["energy"]["total"] == pytest.approx(1.04e-09, rel=5e-3)
     assert r["sim_time"] == pytest.approx(1.24e-07, rel=5e-3)
-    assert r["spike_trace"][:3] == [[("in", 1)], [("out", 1)], [("in", 1)]]
+    # out.1 fires at step 2 but group `out` does not set log_spikes (snn/example_snn.yaml:9-12)
+    assert r["spike_trace"][:3] == [[("in", 1)], [], [("in", 1)]]
     assert r["potential_trace"][:4] == [[0.0, 0.0], [1.0, 0.0], [1.0, -4.0], [2.0, -1.0]]
 
 
@@ -134,8 +135,10 @@ def test_float_weights(S):
     check_stepwise(S, arch, net, steps=20, exact_v=False)
 
 
-def test_multi_slice_core(S):
+def test_multi_slice_core(S, monkeypatch):
     """A core whose inbound axon list is split over several delivery workgroups (atomic write-back)."""
+    monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "512")
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=1000, cores_used=4, out_degree=600, arch_kind="loihi",
                                   p_fire=0.3)
     chip, orc = check_stepwise(S, arch, net, steps=6)
