@@ -64,7 +64,6 @@ constexpr int WAVE = 64;
 constexpr int NEURON_BLOCK = 256;   // 4 wavefronts = 4 simulated cores per workgroup
 constexpr int DELIVER_BLOCK = 256;
 constexpr int AX_PER_THREAD = 4;    // one 16-byte load of ax_pre per lane
-constexpr int DELIVER_BATCH = DELIVER_BLOCK * AX_PER_THREAD;
 constexpr int REDUCE_BLOCK = 256;
 
 // Per-core partial sums written by K1 (one record per core, one writer).
@@ -76,7 +75,7 @@ struct CorePart
 
 struct DevImage
 {
-    uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots;
+    uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots, delay_slots;
     double sync_delay;
     const uint32_t *core_nbase, *core_ncount;
     const double *core_axon_out_latency, *core_axon_in_latency;
@@ -342,55 +341,61 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
 }
 
 // ---------------------------------------------------------------------------------------
-// K2: spike delivery.  grid = n_slices, block = 256, dynamic LDS = accumulators
+// K2: spike delivery.  grid = n_slices, block = 256 (4 independent wavefronts), dynamic LDS
+//
+// The four waves of a workgroup share only the LDS accumulators of their destination core.
+// Each wave walks its own interleaved 256-axon chunks of the slice with NO workgroup
+// barrier inside the loop (scan -> ballot/prefix compaction -> expansion all stay inside the
+// wave, ordered by LDS issue order), so 16-32 waves per CU keep independent chains of
+// global loads in flight: the loop is a latency-bound gather, not a bandwidth-bound stream.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t block_exclusive_scan(uint32_t x, uint32_t *wave_tot, uint32_t &total)
+constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
+
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    uint32_t incl = x;
+    const int lane = threadIdx.x & (WAVE - 1);
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1)
     {
-        const uint32_t y = __shfl_up(incl, o, WAVE);
-        if (lane >= o) incl += y;
+        const uint32_t y = __shfl_up(x, o, WAVE);
+        if (lane >= o) x += y;
     }
-    if (lane == WAVE - 1) wave_tot[wave] = incl;
-    __syncthreads();
-    uint32_t base = 0;
-    total = 0;
-#pragma unroll
-    for (int w = 0; w < DELIVER_BLOCK / WAVE; w++)
-    {
-        const uint32_t c = wave_tot[w];
-        if (w < wave) base += c;
-        total += c;
-    }
-    __syncthreads();
-    return base + incl - x;
+    return x;
+}
+
+// LDS traffic of ONE wave is executed in issue order, so a ds_read issued after a ds_write of
+// the same wave sees it even across lanes; this only has to stop the compiler from reordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 extern __shared__ __align__(16) unsigned char deliver_lds[];
 
 __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
 {
-    __shared__ uint32_t s_beg[DELIVER_BATCH];      // first synapse of each active axon
-    __shared__ uint32_t s_pref[DELIVER_BATCH + 1]; // exclusive prefix of their synapse counts
-    __shared__ uint32_t s_wave[DELIVER_BLOCK / WAVE];
+    __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
+    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE_CHUNK + 4];  // exclusive prefix of their synapse counts
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
 
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const uint32_t slice = blockIdx.x;
     const uint32_t core = im.slice_core[slice];
     const uint32_t ncount = im.core_ncount[core];
     const uint32_t npad = (ncount + 63u) & ~63u;
     const uint32_t nbase = im.core_nbase[core];
     const uint32_t R = im.ring_slots;
+    const uint32_t D = im.delay_slots; // LDS holds one accumulator row per delay value in use
     const long long t = *st.t + 1;
     const unsigned long long a_beg = im.slice_axon_beg[slice], a_end = im.slice_axon_end[slice];
     const unsigned long long syn_base = im.core_syn_base[core];
-    double *acc = reinterpret_cast<double *>(deliver_lds);                      // [R][npad]
-    uint8_t *touched = deliver_lds + (size_t) im.ring_slots * im.max_core_slots * sizeof(double); // [R][npad]
+    double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
+    uint8_t *touched = deliver_lds + (size_t) im.delay_slots * im.max_core_slots * sizeof(double); // [D][npad]
+    uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
 
-    for (uint32_t i = threadIdx.x; i < R * npad; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * npad; i += DELIVER_BLOCK)
     {
         acc[i] = 0.0;
         touched[i] = 0;
@@ -399,21 +404,19 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
 
     double proc = 0.0;
     const uint32_t *bits = st.bits_global;
-    for (unsigned long long b0 = a_beg; b0 < a_end; b0 += DELIVER_BATCH)
+    for (unsigned long long c0 = a_beg + (unsigned long long) wave * WAVE_CHUNK; c0 < a_end;
+            c0 += (unsigned long long) (DELIVER_BLOCK / WAVE) * WAVE_CHUNK)
     {
         // ---- scan: which of my 4 consecutive inbound axons carry a spike this step? ----
-        const unsigned long long a0 = b0 + (unsigned long long) threadIdx.x * AX_PER_THREAD;
-        uint32_t pre[AX_PER_THREAD];
+        const unsigned long long a0 = c0 + (unsigned long long) lane * AX_PER_THREAD;
         uint32_t amask = 0;
         if (a0 + AX_PER_THREAD <= a_end && ((a0 & 3ull) == 0))
         {
             const uint4 p4 = *reinterpret_cast<const uint4 *>(im.ax_pre + a0);
-            pre[0] = p4.x;
-            pre[1] = p4.y;
-            pre[2] = p4.z;
-            pre[3] = p4.w;
-#pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++) amask |= ((bits[pre[k] >> 5] >> (pre[k] & 31u)) & 1u) << k;
+            amask |= ((bits[p4.x >> 5] >> (p4.x & 31u)) & 1u);
+            amask |= ((bits[p4.y >> 5] >> (p4.y & 31u)) & 1u) << 1;
+            amask |= ((bits[p4.z >> 5] >> (p4.z & 31u)) & 1u) << 2;
+            amask |= ((bits[p4.w >> 5] >> (p4.w & 31u)) & 1u) << 3;
         }
         else
         {
@@ -421,77 +424,66 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
             for (int k = 0; k < AX_PER_THREAD; k++)
                 if (a0 + k < a_end)
                 {
-                    pre[k] = im.ax_pre[a0 + k];
-                    amask |= ((bits[pre[k] >> 5] >> (pre[k] & 31u)) & 1u) << k;
+                    const uint32_t pre = im.ax_pre[a0 + k];
+                    amask |= ((bits[pre >> 5] >> (pre & 31u)) & 1u) << k;
                 }
         }
-        uint32_t n_act;
-        uint32_t pos = block_exclusive_scan((uint32_t) __popc(amask), s_wave, n_act);
-        if (n_act == 0) continue; // uniform across the workgroup
-        // ---- compact the active axons, in axon (= reference delivery) order ----
+        if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
+        // ---- compact the active axons in axon (= reference delivery) order ----
+        const uint32_t my_act = (uint32_t) __popc(amask);
+        const uint32_t incl_act = wave_inclusive_scan(my_act);
+        const uint32_t n_act = __shfl(incl_act, WAVE - 1, WAVE);
+        uint32_t pos = incl_act - my_act;
+        uint32_t my_syn = 0;
 #pragma unroll
         for (int k = 0; k < AX_PER_THREAD; k++)
             if (amask & (1u << k))
             {
                 const unsigned long long a = a0 + k;
-                s_beg[pos] = im.ax_syn_beg[a];
-                s_pref[pos] = im.ax_nsyn[a];
+                const uint32_t ns = im.ax_nsyn[a];
+                w_beg[pos] = im.ax_syn_beg[a];
+                w_pref[pos] = my_syn; // lane-local exclusive prefix; the lane base is added below
+                my_syn += ns;
                 proc += im.ax_proc_delay[a];
                 pos++;
             }
-        __syncthreads();
-        // ---- exclusive prefix of synapse counts over the compacted list ----
-        uint32_t cnt[AX_PER_THREAD];
-        uint32_t mine = 0;
-#pragma unroll
-        for (int k = 0; k < AX_PER_THREAD; k++)
+        const uint32_t incl_syn = wave_inclusive_scan(my_syn);
+        const uint32_t n_ev = __shfl(incl_syn, WAVE - 1, WAVE);
+        const uint32_t lane_base = incl_syn - my_syn;
+        pos = incl_act - my_act;
+        for (uint32_t k = 0; k < my_act; k++) w_pref[pos + k] += lane_base;
+        if (lane == 0) w_pref[n_act] = n_ev;
+        wave_lds_fence();
+        // ---- expand to synaptic events: lane l of tile e0 handles event e0 + l ----
+        for (uint32_t e = lane; e < n_ev; e += WAVE)
         {
-            const uint32_t i = threadIdx.x * AX_PER_THREAD + k;
-            cnt[k] = i < n_act ? s_pref[i] : 0u;
-            mine += cnt[k];
-        }
-        uint32_t n_ev;
-        uint32_t run = block_exclusive_scan(mine, s_wave, n_ev);
-#pragma unroll
-        for (int k = 0; k < AX_PER_THREAD; k++)
-        {
-            const uint32_t i = threadIdx.x * AX_PER_THREAD + k;
-            if (i < n_act) s_pref[i] = run;
-            run += cnt[k];
-        }
-        if (threadIdx.x == 0) s_pref[n_act] = n_ev;
-        __syncthreads();
-        // ---- expand to synaptic events, load-balanced: thread e handles event e ----
-        for (uint32_t e = threadIdx.x; e < n_ev; e += DELIVER_BLOCK)
-        {
-            uint32_t lo = 0, hi = n_act; // largest lo with s_pref[lo] <= e
+            uint32_t lo = 0, hi = n_act; // largest lo with w_pref[lo] <= e
             while (hi - lo > 1)
             {
                 const uint32_t mid = (lo + hi) >> 1;
-                if (s_pref[mid] <= e) lo = mid;
+                if (w_pref[mid] <= e) lo = mid;
                 else hi = mid;
             }
-            const unsigned long long s = syn_base + s_beg[lo] + (e - s_pref[lo]);
+            const unsigned long long s = syn_base + w_beg[lo] + (e - w_pref[lo]);
             const uint32_t meta = im.syn_meta[s];
             const double w = im.syn_weight[s];
             if (!((meta >> 19) & 1u))
             {
-                const uint32_t post = meta & 0xffffu;
-                const uint32_t d = (meta >> 16) & 7u;
-                const uint32_t wslot = (uint32_t) ((t + 1 + d) % R);
-                const uint32_t idx = wslot * npad + post;
+                const uint32_t idx = ((meta >> 16) & 7u) * npad + (meta & 0xffffu);
                 atomicAdd(&acc[idx], w); // ds_add_f64
                 touched[idx] = 1;
             }
         }
-        __syncthreads();
+        wave_lds_fence(); // the lists are rewritten by the next chunk
     }
-    // ---- write the accumulated charge back (one RMW per touched neuron and slot) ----
+    __syncthreads();
+    // ---- write the accumulated charge back (one RMW per touched neuron and delay value) ----
     const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
-    for (uint32_t i = threadIdx.x; i < R * npad; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * npad; i += DELIVER_BLOCK)
     {
         if (!touched[i]) continue;
-        const uint32_t wslot = i / npad, n = i - wslot * npad;
+        const uint32_t d = i / npad, n = i - d * npad;
+        const uint32_t wslot = (uint32_t) ((t + 1 + d) % R);
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
         if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
         else st.ring[gi] += acc[i];
@@ -499,7 +491,7 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
     }
     // ---- processing-delay sum of this slice (simple timing model) ----
     proc = wave_sum(proc);
-    if ((threadIdx.x & (WAVE - 1)) == 0) s_red[threadIdx.x >> 6] = proc;
+    if (lane == 0) s_red[wave] = proc;
     __syncthreads();
     if (threadIdx.x == 0)
     {
@@ -859,10 +851,17 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         HIPC(hipMemcpy(st.v, h.slot_v0, (size_t) h.n_slots * sizeof(double), hipMemcpyHostToDevice));
     }
     c->neuron_grid = (h.n_cores + (NEURON_BLOCK / WAVE) - 1) / (NEURON_BLOCK / WAVE);
-    c->deliver_lds = (size_t) h.ring_slots * max_pad * (sizeof(double) + 1);
+    {
+        // LDS accumulator rows: one per synaptic delay value actually present in the image
+        uint32_t max_delay = 0;
+        for (uint64_t k = 0; k < h.n_synapses; k++) max_delay = std::max(max_delay, (h.syn_meta[k] >> 16) & 7u);
+        if (max_delay >= h.ring_slots) return bail(fail(SANAFE_HIP_ERR_INVALID, "synaptic delay %u needs more than %u ring slots", max_delay, h.ring_slots));
+        im.delay_slots = max_delay + 1;
+    }
+    c->deliver_lds = (size_t) im.delay_slots * max_pad * (sizeof(double) + 1);
     if (c->deliver_lds + 9 * 1024 > 160 * 1024)
-        return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay slots needs %zu B of LDS (> 160 KiB)",
-                max_pad, h.ring_slots, c->deliver_lds));
+        return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu B of LDS (> 160 KiB)",
+                max_pad, im.delay_slots, c->deliver_lds));
     HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
             (int) c->deliver_lds));
     HIPC(hipDeviceSynchronize());
