@@ -142,6 +142,12 @@ typedef struct sanafe_hip_image
     const uint32_t *ax_syn_beg;   /* first synapse, relative to core_syn_base[dest core] */
     const uint32_t *ax_nsyn;      /* synapses behind the axon (Message::spikes) */
     const double *ax_proc_delay;  /* processing delay of the message, src/chip.cpp:738-764 */
+    /* optional compression hint: when every synaptic event behind an axon costs the same
+     * latency, ax_lat_class[a] < 255 indexes lat_class_per_event and the device evaluates
+     * axon-in latency + nsyn * per-event latency instead of reading ax_proc_delay[a]
+     * (255, or a NULL array: read ax_proc_delay) */
+    const uint8_t *ax_lat_class;
+    const double *lat_class_per_event; /* [255] */
 
     /* ---- per synapse [n_synapses] ---- */
     const uint32_t *syn_meta;     /* post-neuron offset in core (16b) | delay (3b) << 16 | drop (1b) << 19 */

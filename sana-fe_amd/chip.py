@@ -466,7 +466,7 @@ class HipImage(C.Structure):
         ("slice_core", _p(C.c_uint32)), ("slice_axon_beg", _p(C.c_uint64)), ("slice_axon_end", _p(C.c_uint64)),
         ("core_syn_base", _p(C.c_uint64)), ("core_axon_in_latency", _p(C.c_double)),
         ("ax_pre", _p(C.c_uint32)), ("ax_syn_beg", _p(C.c_uint32)), ("ax_nsyn", _p(C.c_uint32)),
-        ("ax_proc_delay", _p(C.c_double)),
+        ("ax_proc_delay", _p(C.c_double)), ("ax_lat_class", _p(C.c_uint8)), ("lat_class_per_event", _p(C.c_double)),
         ("syn_meta", _p(C.c_uint32)), ("syn_weight", _p(C.c_double)),
     ]
 
@@ -493,7 +493,7 @@ def map_only(arch, net, n_ranks=1, rank=0):
         counts = {"core_nbase": im.n_cores, "core_ncount": im.n_cores, "core_axon_out_latency": im.n_cores,
                   "core_syn_base": im.n_cores, "core_axon_in_latency": im.n_cores,
                   "slice_core": im.n_slices, "slice_axon_beg": im.n_slices, "slice_axon_end": im.n_slices,
-                  "ax_pre": im.n_axons, "ax_syn_beg": im.n_axons, "ax_nsyn": im.n_axons, "ax_proc_delay": im.n_axons,
+                  "ax_pre": im.n_axons, "ax_syn_beg": im.n_axons, "ax_nsyn": im.n_axons, "ax_proc_delay": im.n_axons, "ax_lat_class": im.n_axons, "lat_class_per_event": 255,
                   "syn_meta": im.n_synapses, "syn_weight": im.n_synapses,
                   "in_train_beg": im.n_input, "in_train_len": im.n_input, "in_rate_period": im.n_input,
                   "in_train_bits": im.n_train_words}

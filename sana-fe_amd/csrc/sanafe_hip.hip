@@ -30,6 +30,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -88,10 +89,15 @@ struct DevImage
     const uint32_t *slice_core;
     const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
     const uint32_t *core_slice_beg; // [n_cores+1]
-    const uint32_t *ax_pre, *ax_syn_beg, *ax_nsyn;
-    const double *ax_proc_delay;
+    // Device layout of the inbound axons: one 8-byte record per axon, streamed once per step
+    //   bits 0-31 pre-synaptic GLOBAL slot | 32-47 synapse count | 48-55 latency class (255: read ax_proc_delay)
+    const unsigned long long *ax_rec;
+    const uint32_t *ax_syn_beg;   // first synapse (relative to the core); read once per 256-axon chunk
+    const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
+    const double *lat_class;      // [256] per-event latency of each class
+    // synapses: post (16b) | delay (3b) << 16 | drop << 19 | [packed weights: 12-bit signed weight << 20]
     const uint32_t *syn_meta;
-    const double *syn_weight;
+    const double *syn_weight;     // NULL when the weights are packed into syn_meta
 };
 
 struct DevState
@@ -350,6 +356,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
 // global loads in flight: the loop is a latency-bound gather, not a bandwidth-bound stream.
 // ---------------------------------------------------------------------------------------
 constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
+constexpr int EXPAND_UNROLL = 4;
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
@@ -374,6 +381,7 @@ __device__ __forceinline__ void wave_lds_fence()
 
 extern __shared__ __align__(16) unsigned char deliver_lds[];
 
+template <bool PACKED_W>
 __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
@@ -391,6 +399,7 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
     const long long t = *st.t + 1;
     const unsigned long long a_beg = im.slice_axon_beg[slice], a_end = im.slice_axon_end[slice];
     const unsigned long long syn_base = im.core_syn_base[core];
+    const double ain_lat = im.core_axon_in_latency[core];
     double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * im.max_core_slots * sizeof(double); // [D][npad]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
@@ -404,75 +413,108 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
 
     double proc = 0.0;
     const uint32_t *bits = st.bits_global;
-    for (unsigned long long c0 = a_beg + (unsigned long long) wave * WAVE_CHUNK; c0 < a_end;
-            c0 += (unsigned long long) (DELIVER_BLOCK / WAVE) * WAVE_CHUNK)
+    constexpr unsigned long long NONE = ~0ull; // "past the end of the slice"
+    // the 4 consecutive axon records of this lane (two 16-byte loads when aligned)
+    auto load4 = [&](unsigned long long a0, unsigned long long (&r)[AX_PER_THREAD]) {
+        if (a0 + AX_PER_THREAD <= a_end && ((a0 & 1ull) == 0))
+        {
+            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(im.ax_rec + a0);
+            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(im.ax_rec + a0 + 2);
+            r[0] = lo.x;
+            r[1] = lo.y;
+            r[2] = hi.x;
+            r[3] = hi.y;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++) r[k] = (a0 + k < a_end) ? im.ax_rec[a0 + k] : NONE;
+    };
+    const unsigned long long stride = (unsigned long long) (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
+    unsigned long long c0 = a_beg + (unsigned long long) wave * WAVE_CHUNK;
+    unsigned long long cur[AX_PER_THREAD] = {NONE, NONE, NONE, NONE};
+    if (c0 < a_end) load4(c0 + (unsigned long long) lane * AX_PER_THREAD, cur);
+    for (; c0 < a_end; c0 += stride)
     {
         // ---- scan: which of my 4 consecutive inbound axons carry a spike this step? ----
         const unsigned long long a0 = c0 + (unsigned long long) lane * AX_PER_THREAD;
-        uint32_t amask = 0;
-        if (a0 + AX_PER_THREAD <= a_end && ((a0 & 3ull) == 0))
-        {
-            const uint4 p4 = *reinterpret_cast<const uint4 *>(im.ax_pre + a0);
-            amask |= ((bits[p4.x >> 5] >> (p4.x & 31u)) & 1u);
-            amask |= ((bits[p4.y >> 5] >> (p4.y & 31u)) & 1u) << 1;
-            amask |= ((bits[p4.z >> 5] >> (p4.z & 31u)) & 1u) << 2;
-            amask |= ((bits[p4.w >> 5] >> (p4.w & 31u)) & 1u) << 3;
-        }
-        else
-        {
+        uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
 #pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++)
-                if (a0 + k < a_end)
-                {
-                    const uint32_t pre = im.ax_pre[a0 + k];
-                    amask |= ((bits[pre >> 5] >> (pre & 31u)) & 1u) << k;
-                }
+        for (int k = 0; k < AX_PER_THREAD; k++)
+        {
+            const unsigned long long r = cur[k];
+            const uint32_t pre = (uint32_t) r;
+            nsyn[k] = (r == NONE) ? 0u : (uint32_t) ((r >> 32) & 0xffffu);
+            lcls[k] = (uint32_t) ((r >> 48) & 0xffu);
+            if (r != NONE) amask |= ((bits[pre >> 5] >> (pre & 31u)) & 1u) << k;
         }
+        // prefetch the next chunk's records: their latency hides behind this chunk's work
+        if (c0 + stride < a_end) load4(a0 + stride, cur);
         if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
+        // the chunk's synapses are contiguous: one base + a prefix over ALL its axons' counts
+        const uint32_t chunk_syn0 = im.ax_syn_beg[c0];
+        const uint32_t lane_syn = nsyn[0] + nsyn[1] + nsyn[2] + nsyn[3];
+        uint32_t syn_off = chunk_syn0 + wave_inclusive_scan(lane_syn) - lane_syn;
         // ---- compact the active axons in axon (= reference delivery) order ----
         const uint32_t my_act = (uint32_t) __popc(amask);
         const uint32_t incl_act = wave_inclusive_scan(my_act);
         const uint32_t n_act = __shfl(incl_act, WAVE - 1, WAVE);
         uint32_t pos = incl_act - my_act;
-        uint32_t my_syn = 0;
+        uint32_t my_ev = 0;
 #pragma unroll
         for (int k = 0; k < AX_PER_THREAD; k++)
+        {
             if (amask & (1u << k))
             {
-                const unsigned long long a = a0 + k;
-                const uint32_t ns = im.ax_nsyn[a];
-                w_beg[pos] = im.ax_syn_beg[a];
-                w_pref[pos] = my_syn; // lane-local exclusive prefix; the lane base is added below
-                my_syn += ns;
-                proc += im.ax_proc_delay[a];
+                w_beg[pos] = syn_off;
+                w_pref[pos] = my_ev; // lane-local exclusive prefix; the lane base is added below
+                my_ev += nsyn[k];
+                proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a0 + k];
                 pos++;
             }
-        const uint32_t incl_syn = wave_inclusive_scan(my_syn);
-        const uint32_t n_ev = __shfl(incl_syn, WAVE - 1, WAVE);
-        const uint32_t lane_base = incl_syn - my_syn;
+            syn_off += nsyn[k];
+        }
+        const uint32_t incl_ev = wave_inclusive_scan(my_ev);
+        const uint32_t n_ev = __shfl(incl_ev, WAVE - 1, WAVE);
+        const uint32_t lane_base = incl_ev - my_ev;
         pos = incl_act - my_act;
         for (uint32_t k = 0; k < my_act; k++) w_pref[pos + k] += lane_base;
         if (lane == 0) w_pref[n_act] = n_ev;
         wave_lds_fence();
-        // ---- expand to synaptic events: lane l of tile e0 handles event e0 + l ----
-        for (uint32_t e = lane; e < n_ev; e += WAVE)
+        // ---- expand to synaptic events, EXPAND_UNROLL tiles of 64 per pass so that several
+        //      independent gathers are in flight before the first accumulate waits on them ----
+        for (uint32_t e0 = 0; e0 < n_ev; e0 += WAVE * EXPAND_UNROLL)
         {
-            uint32_t lo = 0, hi = n_act; // largest lo with w_pref[lo] <= e
-            while (hi - lo > 1)
+            uint32_t meta[EXPAND_UNROLL];
+            double wgt[EXPAND_UNROLL];
+#pragma unroll
+            for (int u = 0; u < EXPAND_UNROLL; u++)
             {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (w_pref[mid] <= e) lo = mid;
-                else hi = mid;
+                const uint32_t e = e0 + u * WAVE + lane;
+                meta[u] = 1u << 19; // "drop": nothing to add
+                wgt[u] = 0.0;
+                if (e < n_ev)
+                {
+                    uint32_t lo = 0, hi = n_act; // largest lo with w_pref[lo] <= e
+                    while (hi - lo > 1)
+                    {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (w_pref[mid] <= e) lo = mid;
+                        else hi = mid;
+                    }
+                    const unsigned long long s = syn_base + w_beg[lo] + (e - w_pref[lo]);
+                    meta[u] = im.syn_meta[s];
+                    if (!PACKED_W) wgt[u] = im.syn_weight[s];
+                }
             }
-            const unsigned long long s = syn_base + w_beg[lo] + (e - w_pref[lo]);
-            const uint32_t meta = im.syn_meta[s];
-            const double w = im.syn_weight[s];
-            if (!((meta >> 19) & 1u))
-            {
-                const uint32_t idx = ((meta >> 16) & 7u) * npad + (meta & 0xffffu);
-                atomicAdd(&acc[idx], w); // ds_add_f64
-                touched[idx] = 1;
-            }
+#pragma unroll
+            for (int u = 0; u < EXPAND_UNROLL; u++)
+                if (!((meta[u] >> 19) & 1u))
+                {
+                    const uint32_t idx = ((meta[u] >> 16) & 7u) * npad + (meta[u] & 0xffffu);
+                    const double w = PACKED_W ? (double) ((int) meta[u] >> 20) : wgt[u];
+                    atomicAdd(&acc[idx], w); // ds_add_f64
+                    touched[idx] = 1;
+                }
         }
         wave_lds_fence(); // the lists are rewritten by the next chunk
     }
@@ -628,6 +670,7 @@ struct sanafe_hip_chip
     int device{0};
     hipStream_t stream{nullptr};
     bool own_stream{true};
+    bool packed_weights{false};
     DevImage im{};
     DevState st{};
     std::vector<void *> allocs;
@@ -714,6 +757,9 @@ int validate(const sanafe_hip_image *im)
         for (uint64_t a = im->slice_axon_beg[s]; a < im->slice_axon_end[s]; a++)
         {
             if (im->ax_pre[a] >= im->n_global_slots) return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: bad pre slot", (unsigned long long) a);
+            if (im->ax_nsyn[a] > 0xffffu) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "axon %llu has more than 65535 synapses", (unsigned long long) a);
+            if (a > im->slice_axon_beg[s] && im->ax_syn_beg[a] != im->ax_syn_beg[a - 1] + im->ax_nsyn[a - 1])
+                return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: synapses of a slice must be contiguous in axon order", (unsigned long long) a);
             if (im->core_syn_base[core] + im->ax_syn_beg[a] + im->ax_nsyn[a] > core_syn_end)
                 return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: synapse range leaves its core", (unsigned long long) a);
             const uint64_t sb = im->core_syn_base[core] + im->ax_syn_beg[a];
@@ -813,12 +859,47 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_beg), h.n_slices, &im.slice_axon_beg));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_end), h.n_slices, &im.slice_axon_end));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.core_syn_base), h.n_cores, &im.core_syn_base));
-    TRYC(upload(c, h.ax_pre, h.n_axons, &im.ax_pre));
-    TRYC(upload(c, h.ax_syn_beg, h.n_axons, &im.ax_syn_beg));
-    TRYC(upload(c, h.ax_nsyn, h.n_axons, &im.ax_nsyn));
-    TRYC(upload(c, h.ax_proc_delay, h.n_axons, &im.ax_proc_delay));
-    TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
-    TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
+    {
+        // pack the axon arrays into the 8-byte records the delivery kernel streams
+        std::vector<unsigned long long> rec(h.n_axons);
+        bool any_exact = false;
+        for (uint64_t a = 0; a < h.n_axons; a++)
+        {
+            const uint32_t cls = h.ax_lat_class ? h.ax_lat_class[a] : 255u;
+            any_exact |= (cls == 255u);
+            rec[a] = (unsigned long long) h.ax_pre[a] | ((unsigned long long) h.ax_nsyn[a] << 32) | ((unsigned long long) cls << 48);
+        }
+        TRYC(upload(c, rec.data(), rec.size(), &im.ax_rec));
+        TRYC(upload(c, h.ax_syn_beg, h.n_axons, &im.ax_syn_beg));
+        TRYC(upload(c, h.ax_proc_delay, any_exact ? h.n_axons : 0, &im.ax_proc_delay));
+        std::vector<double> lat(256, 0.0);
+        if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat.begin());
+        TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
+    }
+    {
+        // weights that are integers in [-2048, 2047] ride in the top 12 bits of syn_meta (4 B/synapse
+        // instead of 12); anything else keeps the separate f64 array
+        bool packable = h.n_synapses > 0;
+        for (uint64_t k = 0; k < h.n_synapses && packable; k++)
+        {
+            const double w = h.syn_weight[k];
+            packable = (w >= -2048.0 && w <= 2047.0 && w == (double) (int) w && !(w == 0.0 && std::signbit(w)));
+        }
+        c->packed_weights = packable;
+        if (packable)
+        {
+            std::vector<uint32_t> meta(h.n_synapses);
+            for (uint64_t k = 0; k < h.n_synapses; k++)
+                meta[k] = (h.syn_meta[k] & 0xfffffu) | ((uint32_t) ((int) h.syn_weight[k] & 0xfff) << 20);
+            TRYC(upload(c, meta.data(), meta.size(), &im.syn_meta));
+            im.syn_weight = nullptr;
+        }
+        else
+        {
+            TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
+            TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
+        }
+    }
     {
         std::vector<uint32_t> beg(h.n_cores + 1, 0);
         for (uint32_t s = 0; s < h.n_slices; s++) beg[h.slice_core[s] + 1]++;
@@ -862,7 +943,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     if (c->deliver_lds + 9 * 1024 > 160 * 1024)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu B of LDS (> 160 KiB)",
                 max_pad, im.delay_slots, c->deliver_lds));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (int) c->deliver_lds));
+    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
             (int) c->deliver_lds));
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -907,7 +990,10 @@ static int launch_deliver(sanafe_hip_chip *c)
 {
     if (c->im.n_slices > 0)
     {
-        hipLaunchKernelGGL(deliver_kernel, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
+        if (c->packed_weights)
+            hipLaunchKernelGGL(deliver_kernel<true>, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
+        else
+            hipLaunchKernelGGL(deliver_kernel<false>, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
         HIPCHK(hipGetLastError());
     }
     return 0;

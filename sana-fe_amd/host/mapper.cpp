@@ -234,6 +234,8 @@ sanafe_hip_image MappedChip::image() const
     im.ax_syn_beg = ax_syn_beg.data();
     im.ax_nsyn = ax_nsyn.data();
     im.ax_proc_delay = ax_proc_delay.data();
+    im.ax_lat_class = ax_lat_class.data();
+    im.lat_class_per_event = lat_class_per_event.data();
     im.syn_meta = syn_meta.data();
     im.syn_weight = syn_weight.data();
     return im;
@@ -718,6 +720,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         if (dt.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
         double proc = dt.ain_l[0];
         double e_syn = 0.0, e_dend = 0.0;
+        double first_lat = 0.0;
+        bool uniform_lat = true;
         for (int64_t k = i; k < j; k++)
         {
             const uint64_t e = eo[k];
@@ -735,6 +739,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 e_dend += *du.e_update;
             }
             proc += lat;
+            if (k == i) first_lat = lat;
+            else if (lat != first_lat) uniform_lat = false;
         }
         // network costs: sim_estimate_network_costs, src/chip.cpp:1127-1169
         const uint32_t sc = mc.core_of_slot[pre];
@@ -784,6 +790,17 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             mc.ax_syn_beg.push_back(static_cast<uint32_t>(syn0 - mc.core_syn_base[lc]));
             mc.ax_nsyn.push_back(nsyn);
             mc.ax_proc_delay.push_back(proc);
+            {
+                uint8_t cls = 255;
+                if (uniform_lat)
+                {
+                    size_t q = 0;
+                    while (q < mc.lat_class_per_event.size() && mc.lat_class_per_event[q] != first_lat) q++;
+                    if (q == mc.lat_class_per_event.size() && q < 255) mc.lat_class_per_event.push_back(first_lat);
+                    if (q < 255) cls = static_cast<uint8_t>(q);
+                }
+                mc.ax_lat_class.push_back(cls);
+            }
             if (keep_out_tables)
             {
                 mc.ax_dest_core.push_back(dc);
@@ -809,6 +826,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         i = j;
     }
     lap("axons + synapses");
+    mc.lat_class_per_event.resize(255, 0.0);
     for (uint32_t k = 0; k < LC; k++) core_axon_beg[k + 1] += core_axon_beg[k];
     // cores without inbound axons still need a valid synapse base
     {

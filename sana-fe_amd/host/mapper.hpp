@@ -65,6 +65,8 @@ struct MappedChip
     std::vector<uint64_t> slice_axon_beg, slice_axon_end, core_syn_base;
     std::vector<uint32_t> ax_pre, ax_syn_beg, ax_nsyn;
     std::vector<double> ax_proc_delay;
+    std::vector<uint8_t> ax_lat_class;
+    std::vector<double> lat_class_per_event;
     std::vector<uint32_t> syn_meta;
     std::vector<double> syn_weight;
 
