@@ -98,6 +98,11 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-steps", type=int, default=20, help="steps of the event-timed roofline pass")
+    ap.add_argument("--exchange", choices=("nccl", "host"), default="nccl",
+                    help="N>1 spike exchange: RCCL all-gather on device buffers (default) or gloo through host memory "
+                         "(functional check of the multi-rank path on a single GPU)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use device 0 (with --exchange host)")
+    ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group + exchange) even with one rank")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,7 +117,7 @@ def main():
     t_setup = time.perf_counter()
     arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire, args.seed)
     t_net = time.perf_counter() - t_setup
-    chip = S.SpikingChip(arch, device=local_rank, n_ranks=world, rank=rank)
+    chip = S.SpikingChip(arch, device=0 if args.same_device else local_rank, n_ranks=world, rank=rank)
     chip.load(net)
     info = chip.info()
     t_load = time.perf_counter() - t_setup - t_net
@@ -120,7 +125,27 @@ def main():
     dev = chip.device_handle()
 
     dist = None
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi and args.exchange == "host":
+        import torch
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("gloo")
+        bufs = chip.spike_buffers()
+        h_local = torch.zeros(bufs["local_bytes"], dtype=torch.uint8)
+        h_global = torch.zeros(bufs["global_bytes"], dtype=torch.uint8)
+
+        def run_steps(k):
+            for _ in range(k):
+                chip.step_neurons()
+                assert H.sanafe_hip_export_spikes(dev, h_local.data_ptr()) == 0
+                dist.all_gather_into_tensor(h_global, h_local)
+                assert H.sanafe_hip_import_spikes(dev, h_global.data_ptr()) == 0
+                chip.step_deliver("simple")
+
+        def sync():
+            chip.synchronize()
+    elif multi:
         import torch
         import torch.distributed as dist_mod
         dist = dist_mod
@@ -171,7 +196,7 @@ def main():
     if dist:
         import torch
         t = torch.tensor([elapsed] + [float(local[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")],
-                         dtype=torch.float64, device="cuda")
+                         dtype=torch.float64, device="cuda" if args.exchange == "nccl" else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -182,7 +207,7 @@ def main():
 
     # ---- roofline pass: HIP events around every kernel on its own stream (single-GPU path) ----
     roof = None
-    if world == 1 and args.timed_steps > 0:
+    if not multi and args.timed_steps > 0:
         H.sanafe_hip_set_timing(dev, 1)
         b2 = chip.read_totals()
         if H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
@@ -208,7 +233,7 @@ def main():
                                "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline:
         c = cpu_baseline(S, args)
         events_per_step = agg["spikes"] / args.steps
         est = c["events_per_s"] / events_per_step if events_per_step > 0 else c["steps_per_s"]
@@ -230,7 +255,9 @@ def main():
                                                                              args.neurons_per_core, args.out_degree,
                                                                              100 * args.p_fire),
                        "neurons": n_total, "synapses_per_gpu": int(info["n_synapses"]), "axons_per_gpu": int(info["n_axons"]),
-                       "timing_model": "simple", "exchange": "rccl all_gather of spike bitmaps" if world > 1 else "none"},
+                       "timing_model": "simple",
+                       "exchange": ("rccl all_gather of spike bitmaps" if args.exchange == "nccl" else "gloo via host") if world > 1 else "none"},
+            "totals_in_timed_region": agg,
             "neuron_updates_per_s": agg["neurons_updated"] / elapsed,
             "synaptic_events_per_s": agg["spikes"] / elapsed, "messages_per_s": agg["packets_sent"] / elapsed,
             "per_step": {"neurons_updated": agg["neurons_updated"] / args.steps, "neurons_fired": agg["neurons_fired"] / args.steps,

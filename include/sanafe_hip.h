@@ -17,7 +17,7 @@
  *   sanafe_hip_write_*       <- MappedNeuron::set_attributes between sim() calls
  *                               (src/mapped.cpp:113-166)
  *   sanafe_hip_reset         <- SpikingChip::reset (src/chip.cpp:576-600)
- *   sanafe_hip_{export,import}_spikes
+ *   sanafe_hip_step_neurons / _spike_buffers / _{export,import}_spikes / _step_deliver
  *                            <- the inter-tile message exchange when tiles are sharded
  *                               over GPUs (no reference equivalent)
  *
@@ -190,6 +190,10 @@ int sanafe_hip_step_deliver(sanafe_hip_chip *chip, int simple_timing, int record
  * them (on one GPU they alias).  RCCL all-gather runs directly on these. */
 int sanafe_hip_spike_buffers(sanafe_hip_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
         uint64_t *global_bytes);
+/* Host-staged variant of the exchange (tests, or no device-to-device path): copy the local
+ * bitmap out / the gathered global bitmap in; both synchronise the chip's stream. */
+int sanafe_hip_export_spikes(sanafe_hip_chip *chip, uint32_t *local_bits_out);
+int sanafe_hip_import_spikes(sanafe_hip_chip *chip, const uint32_t *global_bits);
 void *sanafe_hip_stream(sanafe_hip_chip *chip); /* hipStream_t the kernels run on */
 /* Run on a caller-owned stream instead (e.g. the stream a collective library orders against). */
 int sanafe_hip_set_stream(sanafe_hip_chip *chip, void *hip_stream);

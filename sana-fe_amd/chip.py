@@ -111,6 +111,8 @@ def hip_lib():
     L.sanafe_hip_stream.restype = C.c_void_p
     L.sanafe_hip_read_core_delays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.sanafe_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sanafe_hip_export_spikes.argtypes = [C.c_void_p, C.c_void_p]
+    L.sanafe_hip_import_spikes.argtypes = [C.c_void_p, C.c_void_p]
     return L
 
 

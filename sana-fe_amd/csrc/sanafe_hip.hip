@@ -1077,6 +1077,8 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     return launch_reduce(c, simple_timing, 0);
 }
 
+template <typename T> static int d2h(sanafe_hip_chip *c, T *dst, const T *src, size_t n);
+
 extern "C" int sanafe_hip_spike_buffers(sanafe_hip_chip *c, void **local_bits, uint64_t *local_bytes, void **global_bits,
         uint64_t *global_bytes)
 {
@@ -1085,6 +1087,20 @@ extern "C" int sanafe_hip_spike_buffers(sanafe_hip_chip *c, void **local_bits, u
     if (local_bytes) *local_bytes = (uint64_t) c->im.n_slots / 8;
     if (global_bits) *global_bits = c->st.bits_global;
     if (global_bytes) *global_bytes = (uint64_t) c->im.n_global_slots / 8;
+    return 0;
+}
+
+extern "C" int sanafe_hip_export_spikes(sanafe_hip_chip *c, uint32_t *local_bits_out)
+{
+    if (!c || !local_bits_out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    return d2h(c, local_bits_out, c->st.bits_local, (size_t) c->im.n_slots / 32);
+}
+extern "C" int sanafe_hip_import_spikes(sanafe_hip_chip *c, const uint32_t *global_bits)
+{
+    if (!c || !global_bits) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->st.bits_global, global_bits, (size_t) c->im.n_global_slots / 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 

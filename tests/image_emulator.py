@@ -36,6 +36,11 @@ class ImageEmulator:
         return y
 
     def step(self):
+        tot, fired = self.step_neurons()
+        return self.step_deliver(tot, fired)
+
+    def step_neurons(self):
+        """K1: returns (partial totals, local fired flags per local slot)."""
         im = self.im
         done, t = self.t, self.t + 1
         rs = t % self.R
@@ -137,9 +142,16 @@ class ImageEmulator:
         pk = np.zeros(im["n_cores"])
         np.add.at(pk, self.core_of_slot[fired], im["slot_packets"][fired])
         gen += pk * im["core_axon_out_latency"]
+        self._gen = gen
+        return tot, fired
+
+    def step_deliver(self, tot, fired_global):
+        """K2 + K3 with the GLOBAL fired flags (all ranks' slots concatenated)."""
+        im = self.im
+        t = self.t + 1
+        gen = self._gen
         # ---- delivery ----
         proc = np.zeros(im["n_cores"])
-        fired_global = fired  # single rank: local == global
         for s in range(im["n_slices"]):
             c = im["slice_core"][s]
             a0, a1 = int(im["slice_axon_beg"][s]), int(im["slice_axon_end"][s])
