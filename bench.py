@@ -105,6 +105,13 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group + exchange) even with one rank")
     args = ap.parse_args()
 
+    # Libraries (RCCL's version banner, gloo's connection notes) write to stdout; the contract is ONE
+    # JSON line there, so everything else is sent to stderr and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -265,7 +272,8 @@ def main():
             "setup_s": {"build_network": t_net, "map_and_upload": t_load},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        real_stdout.write(json.dumps(out) + "\n")
+        real_stdout.flush()
     if dist:
         dist.destroy_process_group()
 
