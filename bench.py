@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed):
+def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0):
     D = S.description
     n_tiles = max(1024, (cores_per_gpu * n_gpus + 3) // 4) if cores_per_gpu * n_gpus > 4096 else 1024
     arch = S.presets.loihi_large(n_tiles=n_tiles, n_inputs=4)
@@ -42,7 +42,9 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
                                 "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(seed)
     g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128, 0).astype(np.int64), D.ATTR_INT)
-    src, dst, w = S.chip.generate_random_edges(n, out_degree, seed)
+    # a rank only needs the edges that start or end in its own shard of the neurons
+    shard = None if n_gpus == 1 else (rank * n_per_gpu, (rank + 1) * n_per_gpu)
+    src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard)
     net._add_edges(src, dst, w, None, np.full(len(src), net.strings("loihi_sparse_synapse"), dtype=np.int32))
     for r in range(n_gpus):
         first_core = r * tiles_per_rank * 4
@@ -122,7 +124,8 @@ def main():
     S = _sanafe_pkg.load()
 
     t_setup = time.perf_counter()
-    arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire, args.seed)
+    arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire, args.seed,
+                               rank)
     t_net = time.perf_counter() - t_setup
     chip = S.SpikingChip(arch, device=0 if args.same_device else local_rank, n_ranks=world, rank=rank)
     chip.load(net)

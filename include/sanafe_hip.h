@@ -216,9 +216,17 @@ int sanafe_hip_write_bias(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t c
 int sanafe_hip_write_potential(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const double *v);
 int sanafe_hip_write_slot_class(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const uint32_t *cls);
 int sanafe_hip_write_soma_classes(sanafe_hip_chip *chip, uint32_t n, const sanafe_hip_soma_class *classes);
-/* Host-evaluated soma units: status (0..3) of SANAFE_SOMA_HOST slots for the
- * step in flight, written between step_neurons and step_deliver. */
-int sanafe_hip_write_host_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status);
+/* Host-evaluated soma units (plugins, `extern "C" PipelineUnit *create_<model>()`,
+ * src/plugins.cpp:45-98), between step_neurons and step_deliver:
+ *   read_host_inputs   the synaptic input of the listed SANAFE_SOMA_HOST slots for the step in
+ *                      flight (read-and-clear of the time-step buffer, src/chip.cpp:717-723)
+ *   write_host_status  status (0..3) the plugin returned, the LOCAL core of each slot and the
+ *                      energy / latency of its neuron-processing pipeline (src/pipeline.hpp:631-714);
+ *                      folded into the step's totals with the spike's downstream costs. */
+int sanafe_hip_read_host_inputs(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, double *current_out,
+        uint8_t *has_out);
+int sanafe_hip_write_host_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core, const double *energy, const double *latency);
 
 /* SpikingChip::reset: potentials, input currents and buffers to zero. */
 int sanafe_hip_reset(sanafe_hip_chip *chip);

@@ -88,6 +88,14 @@ int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out);
 int sanafe_generate_random_edges(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
         int64_t src_base, int64_t dst_base, int64_t *src, int64_t *dst, double *weight);
 
+/* Sharded variant: only the edges whose source or destination neuron is in [lo, hi) (what one
+ * rank of a tile-sharded run needs); same per-neuron streams as the unsharded generator. */
+typedef struct sanafe_edge_set sanafe_edge_set;
+int sanafe_generate_random_edges_sharded(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t lo, int64_t hi, sanafe_edge_set **out, int64_t *count);
+int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t *dst, double *weight);
+void sanafe_edge_set_free(sanafe_edge_set *set);
+
 #ifdef __cplusplus
 }
 #endif

@@ -651,14 +651,58 @@ __global__ void fill_double(double *p, size_t n, double v)
     if (i < n) p[i] = v;
 }
 
-// Host-evaluated soma units (plugins): apply the statuses the host computed for this step.
-__global__ void host_status_kernel(DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status)
+// Host-evaluated soma units (plugins).  Between K1 and K2 the host (1) gathers the synaptic input
+// of those slots -- reading AND clearing the time-step buffer exactly like K1 does for device
+// somas -- (2) calls the plugin's update() and (3) hands back status, energy and latency, which are
+// folded into the per-core partials together with the spike's static downstream totals.
+__global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t g = slots[i];
-    st.status[g] = status[i];
-    if (status[i] == 3) atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
+    const long long t = *st.t + 1;
+    const size_t gi = (size_t) (t % im.ring_slots) * im.n_slots + g;
+    const uint32_t inkind = (im.slot_cls[g] >> 3) & 7u;
+    if (inkind == SANAFE_IN_ZERO)
+    {
+        has[i] = 1;
+        cur[i] = 0.0;
+        return;
+    }
+    const uint8_t h = st.ring_valid[gi];
+    has[i] = h;
+    cur[i] = h ? st.ring[gi] : 0.0;
+    if (h)
+    {
+        st.ring[gi] = 0.0;
+        st.ring_valid[gi] = 0;
+    }
+}
+
+__global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core, const double *energy, const double *latency)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t g = slots[i];
+    const uint8_t s = status[i];
+    st.status[g] = s;
+    CorePart *cp = st.core_part + core[i];
+    atomicAdd(&cp->e_soma, energy[i]);
+    atomicAdd(&cp->gen_sum, latency[i]);
+    if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
+    if (s == 3)
+    {
+        atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
+        atomicAdd((unsigned long long *) &cp->fired, 1ull);
+        atomicAdd((unsigned long long *) &cp->packets, (unsigned long long) im.slot_packets[g]);
+        atomicAdd((unsigned long long *) &cp->hops, (unsigned long long) im.slot_hops[g]);
+        atomicAdd((unsigned long long *) &cp->events, (unsigned long long) im.slot_events[g]);
+        atomicAdd(&cp->e_net, im.slot_e_net[g]);
+        atomicAdd(&cp->e_syn, im.slot_e_syn[g]);
+        atomicAdd(&cp->e_dend, im.slot_e_dend[g]);
+        atomicAdd(&cp->gen_sum, (double) im.slot_packets[g] * im.core_axon_out_latency[core[i]]);
+    }
 }
 } // namespace
 
@@ -681,8 +725,10 @@ struct sanafe_hip_chip
     double t_neuron{0}, t_deliver{0}, t_reduce{0};
     long long t_launches{0};
     std::vector<double> v0;
-    uint32_t *d_host_slots{nullptr};
+    // staging for host-evaluated units
+    uint32_t *d_host_slots{nullptr}, *d_host_core{nullptr};
     uint8_t *d_host_status{nullptr};
+    double *d_host_a{nullptr}, *d_host_b{nullptr};
     uint32_t host_cap{0};
 };
 
@@ -960,8 +1006,9 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     for (void *p : c->allocs) (void) hipFree(p);
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
-    if (c->d_host_slots) (void) hipFree(c->d_host_slots);
-    if (c->d_host_status) (void) hipFree(c->d_host_status);
+    for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
+                 (void *) c->d_host_b})
+        if (p) (void) hipFree(p);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1212,25 +1259,60 @@ extern "C" int sanafe_hip_write_soma_classes(sanafe_hip_chip *c, uint32_t n, con
     c->im.soma_classes = static_cast<const sanafe_hip_soma_class *>(p);
     return 0;
 }
-extern "C" int sanafe_hip_write_host_status(sanafe_hip_chip *c, uint32_t count, const uint32_t *slots, const uint8_t *status)
+static int ensure_host_staging(sanafe_hip_chip *c, uint32_t count)
 {
-    if (!c || (count > 0 && (!slots || !status))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (c->host_cap >= count) return 0;
+    for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
+                 (void *) c->d_host_b})
+        if (p) HIPCHK(hipFree(p));
+    c->d_host_slots = c->d_host_core = nullptr;
+    c->d_host_status = nullptr;
+    c->d_host_a = c->d_host_b = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_slots), (size_t) count * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_core), (size_t) count * sizeof(uint32_t)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_status), (size_t) count));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_a), (size_t) count * sizeof(double)));
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_b), (size_t) count * sizeof(double)));
+    c->host_cap = count;
+    return 0;
+}
+
+extern "C" int sanafe_hip_read_host_inputs(sanafe_hip_chip *c, uint32_t count, const uint32_t *slots, double *current_out,
+        uint8_t *has_out)
+{
+    if (!c || (count > 0 && (!slots || !current_out || !has_out))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
     if (count == 0) return 0;
     HIPCHK(hipSetDevice(c->device));
     for (uint32_t i = 0; i < count; i++)
-        if (slots[i] >= c->im.n_slots || status[i] > 3) return fail(SANAFE_HIP_ERR_INVALID, "bad host status entry %u", i);
-    if (c->host_cap < count)
-    {
-        if (c->d_host_slots) HIPCHK(hipFree(c->d_host_slots));
-        if (c->d_host_status) HIPCHK(hipFree(c->d_host_status));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_slots), (size_t) count * sizeof(uint32_t)));
-        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_status), (size_t) count));
-        c->host_cap = count;
-    }
+        if (slots[i] >= c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad host slot %u", i);
+    TRY(ensure_host_staging(c, count));
     HIPCHK(hipMemcpyAsync(c->d_host_slots, slots, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(host_input_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
+            c->d_host_slots, c->d_host_a, c->d_host_status);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(current_out, c->d_host_a, (size_t) count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(has_out, c->d_host_status, (size_t) count, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_write_host_status(sanafe_hip_chip *c, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core, const double *energy, const double *latency)
+{
+    if (!c || (count > 0 && (!slots || !status || !core || !energy || !latency))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++)
+        if (slots[i] >= c->im.n_slots || status[i] > 3 || core[i] >= c->im.n_cores)
+            return fail(SANAFE_HIP_ERR_INVALID, "bad host status entry %u", i);
+    TRY(ensure_host_staging(c, count));
+    HIPCHK(hipMemcpyAsync(c->d_host_slots, slots, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_host_core, core, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_host_status, status, (size_t) count, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->st, count, c->d_host_slots,
-            c->d_host_status);
+    HIPCHK(hipMemcpyAsync(c->d_host_a, energy, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_host_b, latency, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
+            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b);
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

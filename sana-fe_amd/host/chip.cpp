@@ -19,8 +19,12 @@
 #include <string>
 #include <vector>
 
+#include <dlfcn.h>
+#include <map>
+
 #include "../../include/sanafe_host.h"
 #include "mapper.hpp"
+#include "plugin_abi/pipeline.hpp"
 
 using sanafe_amd::MappedChip;
 
@@ -64,6 +68,128 @@ struct sanafe_chip
     std::vector<std::vector<uint32_t>> rec_spike_bits;
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
+
+    // ---- host-evaluated (plugin) soma units: plugin_get_hw, src/plugins.cpp:45-98 ----
+    std::vector<std::unique_ptr<sanafe::PipelineUnit>> plugin_units; // parallel to mc.host_units
+    std::vector<void *> plugin_handles;
+    std::vector<uint32_t> h_slots, h_cores;
+    std::vector<uint8_t> h_status, h_has;
+    std::vector<double> h_cur, h_energy, h_latency;
+
+    ~sanafe_chip()
+    {
+        plugin_units.clear(); // destroy the objects before their code is unloaded
+        for (void *h : plugin_handles) dlclose(h);
+    }
+
+    static sanafe::ModelAttribute to_model_attribute(const sanafe_desc &d, const sanafe_attr_table &t, int64_t i)
+    {
+        sanafe::ModelAttribute a;
+        a.name = std::string(d.strings[t.key[i]]);
+        a.forward_to_synapse = t.fwd ? (t.fwd[i] & SANAFE_FWD_SYNAPSE) != 0 : true;
+        a.forward_to_dendrite = t.fwd ? (t.fwd[i] & SANAFE_FWD_DENDRITE) != 0 : true;
+        a.forward_to_soma = t.fwd ? (t.fwd[i] & SANAFE_FWD_SOMA) != 0 : true;
+        switch (t.type[i])
+        {
+        case SANAFE_ATTR_BOOL: a.value = (t.num[i] != 0.0); break;
+        case SANAFE_ATTR_INT: a.value = static_cast<int>(t.num[i]); break;
+        case SANAFE_ATTR_DOUBLE: a.value = t.num[i]; break;
+        case SANAFE_ATTR_STRING: a.value = std::string(t.str[i] >= 0 ? d.strings[t.str[i]] : ""); break;
+        default:
+        {
+            std::vector<sanafe::ModelAttribute> v;
+            for (int64_t k = t.list_ptr[i]; k < t.list_ptr[i + 1]; k++)
+            {
+                sanafe::ModelAttribute e;
+                const double x = t.list_num[k];
+                if (x == static_cast<double>(static_cast<int>(x))) e.value = static_cast<int>(x);
+                else e.value = x;
+                v.push_back(e);
+            }
+            a.value = v;
+        }
+        }
+        return a;
+    }
+
+    void load_plugins(const sanafe_desc &d)
+    {
+        std::map<std::string, void *> libs;
+        for (const MappedChip::HostUnit &hu : mc.host_units)
+        {
+            void *&lib = libs[hu.plugin_path];
+            if (!lib)
+            {
+                lib = dlopen(hu.plugin_path.c_str(), RTLD_LAZY | RTLD_LOCAL);
+                if (!lib) throw std::runtime_error(std::string("Error: Couldn't load library ") + hu.plugin_path + ": " + dlerror());
+                plugin_handles.push_back(lib);
+            }
+            using Factory = sanafe::PipelineUnit *(*) ();
+            const std::string sym = "create_" + hu.model;
+            dlerror();
+            auto create = reinterpret_cast<Factory>(dlsym(lib, sym.c_str()));
+            if (!create) throw std::runtime_error("Error: Couldn't load symbol " + sym + " from " + hu.plugin_path);
+            std::unique_ptr<sanafe::PipelineUnit> unit(create());
+            if (!unit->implements_soma || unit->implements_synapse || unit->implements_dendrite)
+                throw std::runtime_error("plugin unit '" + hu.name + "' must implement the soma interface only");
+            unit->name = hu.name;
+            unit->model = hu.model;
+            unit->plugin_lib = hu.plugin_path;
+            for (int64_t i = d.unit_attr_ptr[hu.desc_unit]; i < d.unit_attr_ptr[hu.desc_unit + 1]; i++)
+            {
+                const sanafe::ModelAttribute a = to_model_attribute(d, d.unit_attrs, i);
+                unit->model_attributes[*a.name] = a;
+            }
+            for (const auto &kv : unit->model_attributes) unit->set_attribute_hw(kv.first, kv.second); // key order
+            plugin_units.push_back(std::move(unit));
+        }
+        for (const MappedChip::HostNeuron &hn : mc.host_neurons)
+        {
+            sanafe::PipelineUnit &u = *plugin_units[hn.unit];
+            u.add_neuron();
+            for (int64_t i = d.neuron_attr_ptr[hn.gid]; i < d.neuron_attr_ptr[hn.gid + 1]; i++)
+            {
+                const sanafe::ModelAttribute a = to_model_attribute(d, d.neuron_attrs, i);
+                if (a.forward_to_soma) u.set_attribute_neuron(hn.addr, *a.name, a);
+            }
+            h_slots.push_back(hn.slot);
+            h_cores.push_back(hn.core_local);
+        }
+        const size_t n = mc.host_neurons.size();
+        h_status.assign(n, 0);
+        h_has.assign(n, 0);
+        h_cur.assign(n, 0.0);
+        h_energy.assign(n, 0.0);
+        h_latency.assign(n, 0.0);
+    }
+
+    // One timestep of the host-evaluated somas: soma `update`, then the default costing of
+    // process_soma_output (src/pipeline.hpp:453-458, 631-714).
+    void run_plugins(int64_t timestep)
+    {
+        for (size_t i = 0; i < mc.host_neurons.size(); i++)
+        {
+            const MappedChip::HostNeuron &hn = mc.host_neurons[i];
+            const MappedChip::HostUnit &hu = mc.host_units[hn.unit];
+            sanafe::PipelineUnit &u = *plugin_units[hn.unit];
+            const std::optional<double> cur = h_has[i] ? std::optional<double>(h_cur[i]) : std::nullopt;
+            sanafe::PipelineResult r = u.update(static_cast<size_t>(hn.addr), cur, static_cast<long int>(timestep));
+            if (r.status == sanafe::neuron_state_unset) throw std::runtime_error("Soma output; should return valid neuron state.");
+            if (r.energy.has_value() && hu.has_energy)
+                throw std::runtime_error("Error: Soma unit simulates energy and also has default energy metrics set. Remove the default energy metrics from the architecture description.");
+            if (r.latency.has_value() && hu.has_latency)
+                throw std::runtime_error("Error: Soma unit simulates latency and also has default latency costs set. Remove the default latency metrics from the architecture description");
+            const int k = static_cast<int>(r.status) - 1;
+            if (hu.has_energy) r.energy = hu.energy[k];
+            if (hu.has_latency) r.latency = hu.latency[k];
+            if (!r.energy.has_value()) throw std::runtime_error("Soma unit does not simulate energy or provide default energy costs in the architecture description.");
+            if (!r.latency.has_value()) throw std::runtime_error("Soma unit does not simulate latency or provide default latency costs in the architecture description.");
+            h_status[i] = static_cast<uint8_t>(r.status);
+            h_energy[i] = *r.energy;
+            h_latency[i] = *r.latency;
+            if (!slot_lat[0].empty()) slot_lat[k][mc.slot_offset + hn.slot] = *r.latency; // exact generation delays (detailed model)
+        }
+    }
 
     // ------------------------------------------------------------------------------
     // Rebuild one timestep's messages from the spike bitmap + per-slot status.
@@ -321,6 +447,19 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
             for (int k = 0; k < 3; k++) chip->slot_lat[k][s] = (0.0 + cc.dendrite_latency) + cc.soma_latency[k];
         }
     }
+    if (!chip->mc.host_units.empty())
+    {
+        try
+        {
+            chip->load_plugins(*desc);
+        }
+        catch (const std::exception &e)
+        {
+            sanafe_hip_chip_destroy(chip->dev);
+            chip->dev = nullptr;
+            return fail(SANAFE_HIP_ERR_INVALID, e.what());
+        }
+    }
     *out = chip.release();
     return 0;
 }
@@ -401,7 +540,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_spike_bits.clear();
     chip->rec_first_timestep = chip->total_timesteps + 1;
     chip->rec_count = 0;
-    if (timing_model == SANAFE_TIMING_SIMPLE)
+    const bool host_units = !chip->mc.host_neurons.empty();
+    if (timing_model == SANAFE_TIMING_SIMPLE && !host_units)
     {
         // Whole run stays on the device; nothing comes back per step unless recorded.
         DEV(sanafe_hip_reset_totals(chip->dev));
@@ -427,25 +567,54 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     {
         // `detailed`: functional step on the GPU, NoC discrete-event schedule on the host
         // (serial by construction, src/schedule.cpp:234-281), one step at a time.
-        if (mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing needs a single-rank chip");
+        // The same stepwise loop serves plugin (host-evaluated) soma units under either timing model.
+        const bool detailed = (timing_model == SANAFE_TIMING_DETAILED);
+        if (detailed && mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing needs a single-rank chip");
         std::vector<uint8_t> status(mc.n_slots);
         std::vector<std::vector<Msg>> per_core;
         for (int64_t s = 0; s < timesteps; s++)
         {
             DEV(sanafe_hip_reset_totals(chip->dev));
-            DEV(sanafe_hip_step(chip->dev, 1, 0, 0));
+            if (host_units)
+            {
+                const uint32_t n = static_cast<uint32_t>(chip->h_slots.size());
+                DEV(sanafe_hip_step_neurons(chip->dev));
+                DEV(sanafe_hip_read_host_inputs(chip->dev, n, chip->h_slots.data(), chip->h_cur.data(), chip->h_has.data()));
+                try
+                {
+                    chip->run_plugins(chip->total_timesteps + 1);
+                }
+                catch (const std::exception &e)
+                {
+                    return fail(SANAFE_HIP_ERR_INVALID, e.what());
+                }
+                DEV(sanafe_hip_write_host_status(chip->dev, n, chip->h_slots.data(), chip->h_status.data(), chip->h_cores.data(),
+                        chip->h_energy.data(), chip->h_latency.data()));
+                DEV(sanafe_hip_step_deliver(chip->dev, detailed ? 0 : 1, 0));
+            }
+            else
+            {
+                DEV(sanafe_hip_step(chip->dev, 1, 0, 0));
+            }
             sanafe_hip_totals ts{};
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
             DEV(sanafe_hip_read_status(chip->dev, status.data()));
             chip->total_timesteps += 1;
-            chip->build_messages(chip->total_timesteps, status, per_core);
-            try
+            if (detailed)
             {
-                ts.sim_time = chip->schedule_detailed(per_core);
+                chip->build_messages(chip->total_timesteps, status, per_core);
+                try
+                {
+                    ts.sim_time = chip->schedule_detailed(per_core);
+                }
+                catch (const std::exception &e)
+                {
+                    return fail(SANAFE_HIP_ERR_INVALID, e.what());
+                }
             }
-            catch (const std::exception &e)
+            else
             {
-                return fail(SANAFE_HIP_ERR_INVALID, e.what());
+                per_core.clear();
             }
             ts.timesteps = chip->total_timesteps;
             add_totals(run, ts);
@@ -478,6 +647,7 @@ extern "C" int sanafe_chip_reset(sanafe_chip *chip)
 {
     if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     DEV(sanafe_hip_reset(chip->dev));
+    for (auto &u : chip->plugin_units) u->reset();
     return 0;
 }
 
@@ -509,7 +679,11 @@ extern "C" int sanafe_chip_get_status(sanafe_chip *chip, uint8_t *out)
 extern "C" int sanafe_chip_get_potentials(sanafe_chip *chip, double *out)
 {
     if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
-    return gather_by_gid(chip, out, [&](double *p) { return sanafe_hip_read_potentials(chip->dev, p); });
+    const int rc = gather_by_gid(chip, out, [&](double *p) { return sanafe_hip_read_potentials(chip->dev, p); });
+    if (rc != 0) return rc;
+    for (const MappedChip::HostNeuron &hn : chip->mc.host_neurons) // plugin somas keep their own state
+        out[hn.gid] = chip->plugin_units[hn.unit]->get_potential(hn.addr);
+    return 0;
 }
 extern "C" int sanafe_chip_get_input_current(sanafe_chip *chip, double *out)
 {
@@ -649,3 +823,79 @@ extern "C" int sanafe_generate_random_edges(int64_t n_neurons, int64_t out_degre
     for (auto &th : pool) th.join();
     return 0;
 }
+
+// Sharded variant for tile-sharded (multi-GPU) runs: keeps only the edges a rank needs, i.e. those
+// whose source OR destination neuron lies in [lo, hi).  The per-neuron streams are the same as in
+// sanafe_generate_random_edges, so every rank sees a consistent slice of one global network
+// without ever holding all of it.
+struct sanafe_edge_set
+{
+    std::vector<std::vector<int64_t>> src, dst;
+    std::vector<std::vector<double>> w;
+};
+
+extern "C" int sanafe_generate_random_edges_sharded(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t lo, int64_t hi, sanafe_edge_set **out, int64_t *count)
+{
+    if (n_neurons <= 0 || out_degree < 0 || out_degree > n_neurons || !out || !count)
+        return fail(SANAFE_HIP_ERR_INVALID, "bad generator arguments");
+    n_threads = std::max(1, n_threads);
+    auto set = std::make_unique<sanafe_edge_set>();
+    set->src.resize(n_threads);
+    set->dst.resize(n_threads);
+    set->w.resize(n_threads);
+    auto work = [&](int tid) {
+        std::vector<uint64_t> seen((n_neurons + 63) / 64, 0);
+        std::vector<int64_t> targets(out_degree);
+        const int64_t b = n_neurons * tid / n_threads, e = n_neurons * (tid + 1) / n_threads; // contiguous: output stays sorted by source
+        for (int64_t i = b; i < e; i++)
+        {
+            std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(i) + 1);
+            const bool src_local = (i >= lo && i < hi);
+            for (int64_t k = 0; k < out_degree; k++)
+            {
+                uint64_t r;
+                do
+                {
+                    r = gen() % static_cast<uint64_t>(n_neurons);
+                } while (seen[r >> 6] & (1ull << (r & 63)));
+                seen[r >> 6] |= 1ull << (r & 63);
+                targets[k] = static_cast<int64_t>(r);
+                const uint64_t wv = gen();
+                if (src_local || (targets[k] >= lo && targets[k] < hi))
+                {
+                    const double mag = static_cast<double>(1 + (wv % 8));
+                    set->src[tid].push_back(i);
+                    set->dst[tid].push_back(targets[k]);
+                    set->w[tid].push_back((wv & (1ull << 40)) ? mag : -mag);
+                }
+            }
+            for (int64_t k = 0; k < out_degree; k++) seen[targets[k] >> 6] &= ~(1ull << (targets[k] & 63));
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    int64_t total = 0;
+    for (auto &v : set->src) total += static_cast<int64_t>(v.size());
+    *count = total;
+    *out = set.release();
+    return 0;
+}
+
+extern "C" int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t *dst, double *weight)
+{
+    if (!set || !src || !dst || !weight) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    int64_t o = 0;
+    for (size_t t = 0; t < set->src.size(); t++)
+    {
+        std::copy(set->src[t].begin(), set->src[t].end(), src + o);
+        std::copy(set->dst[t].begin(), set->dst[t].end(), dst + o);
+        std::copy(set->w[t].begin(), set->w[t].end(), weight + o);
+        o += static_cast<int64_t>(set->src[t].size());
+    }
+    return 0;
+}
+
+extern "C" void sanafe_edge_set_free(sanafe_edge_set *set) { delete set; }

@@ -460,8 +460,12 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         const uint32_t ls = s - SO;
         // ---- cost class (src/pipeline.hpp:574-714) ----
         sanafe_hip_cost_class cc{};
-        if (!su.has_soma_e) throw std::runtime_error("Soma unit does not simulate energy or provide default energy costs in the architecture description.");
-        if (!su.has_soma_l) throw std::runtime_error("Soma unit does not simulate latency or provide default latency costs in the architecture description.");
+        const bool host_soma = (su.model == M_PLUGIN);
+        if (host_soma && (su.syn || su.dend))
+            throw UnsupportedError("plugin unit '" + su.name + "': only soma plugins are implemented on the MI355X backend");
+        // a plugin may simulate its own energy/latency instead of using architecture defaults
+        if (!host_soma && !su.has_soma_e) throw std::runtime_error("Soma unit does not simulate energy or provide default energy costs in the architecture description.");
+        if (!host_soma && !su.has_soma_l) throw std::runtime_error("Soma unit does not simulate latency or provide default latency costs in the architecture description.");
         cc.soma_energy[0] = su.se[0];
         cc.soma_energy[1] = su.se[0] + su.se[1];
         cc.soma_energy[2] = (su.se[0] + su.se[1]) + su.se[2];
@@ -494,7 +498,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         if (su.model == M_LIF) model = SANAFE_SOMA_LIF;
         else if (su.model == M_TRUENORTH) model = SANAFE_SOMA_TRUENORTH, p.leak_decay = 0.0;
         else if (su.model == M_INPUT) model = SANAFE_SOMA_INPUT;
-        else throw UnsupportedError("soma unit '" + su.name + "' (plugin) is not implemented on the MI355X backend yet");
+        else model = SANAFE_SOMA_HOST;
         std::vector<double> train;
         double rate = 0.0, poisson = 0.0;
         for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
@@ -551,7 +555,38 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 else if (k == "rate") rate = a.as_double();
             }
         }
-        if (model == SANAFE_SOMA_INPUT)
+        if (model == SANAFE_SOMA_HOST)
+        {
+            // one plugin instance per (core, unit); addresses in arrival order on the unit
+            uint32_t hu = 0;
+            while (hu < mc.host_units.size() && !(mc.host_units[hu].core == static_cast<uint32_t>(c) &&
+                           mc.host_units[hu].desc_unit == d.tmpl_unit_ptr[d.core_template[c]] + soma_unit[gid]))
+                hu++;
+            if (hu == mc.host_units.size())
+            {
+                MappedChip::HostUnit h;
+                h.core = c;
+                h.desc_unit = d.tmpl_unit_ptr[d.core_template[c]] + soma_unit[gid];
+                h.name = su.name;
+                h.model = S(d, d.unit_model[h.desc_unit]);
+                h.plugin_path = S(d, d.unit_plugin[h.desc_unit]);
+                h.has_energy = su.has_soma_e;
+                h.has_latency = su.has_soma_l;
+                for (int k = 0; k < 3; k++)
+                {
+                    h.energy[k] = cc.soma_energy[k];
+                    h.latency[k] = cc.soma_latency[k];
+                }
+                mc.host_units.push_back(h);
+            }
+            MappedChip::HostNeuron hn;
+            hn.slot = ls;
+            hn.core_local = c - mc.first_core;
+            hn.unit = hu;
+            hn.gid = gid;
+            mc.host_neurons.push_back(hn);
+        }
+        else if (model == SANAFE_SOMA_INPUT)
         {
             if (poisson > 0.0) throw UnsupportedError("poisson input (std::mt19937 stream) is not implemented on the MI355X backend");
             mc.slot_aux[ls] = static_cast<uint32_t>(mc.in_train_beg.size());
@@ -599,6 +634,16 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         mc.slot_model[ls] = static_cast<uint8_t>(model);
         mc.slot_log_spikes[ls] = d.neuron_log_spikes[gid];
         mc.slot_log_potential[ls] = d.neuron_log_potential[gid];
+    }
+    {
+        // soma addresses follow the order neurons arrive on the unit (map order), src/pipeline.cpp:79-85
+        std::vector<size_t> idx(mc.host_neurons.size());
+        std::iota(idx.begin(), idx.end(), 0);
+        std::stable_sort(idx.begin(), idx.end(), [&](size_t a, size_t b) {
+            return d.neuron_map_order[mc.host_neurons[a].gid] < d.neuron_map_order[mc.host_neurons[b].gid];
+        });
+        std::vector<uint32_t> next(mc.host_units.size(), 0);
+        for (size_t i : idx) mc.host_neurons[i].addr = next[mc.host_neurons[i].unit]++;
     }
     if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});

@@ -85,6 +85,23 @@ struct MappedChip
     std::vector<uint8_t> slot_log_spikes, slot_log_potential;
     std::vector<uint8_t> slot_model;        // SANAFE_SOMA_* (local slots)
 
+    // ---- host-evaluated (plugin) soma units: one instance per (core, unit), src/core.cpp:196-231 ----
+    struct HostUnit
+    {
+        uint32_t core{0};
+        int desc_unit{0};          // index into sanafe_desc::unit_* (attributes, model, plugin path)
+        std::string name, model, plugin_path;
+        bool has_energy{false}, has_latency{false};
+        double energy[3]{}, latency[3]{}; // idle / updated / fired sums of the architecture defaults
+    };
+    struct HostNeuron
+    {
+        uint32_t slot{0}, core_local{0}, unit{0}, addr{0};
+        int64_t gid{0};
+    };
+    std::vector<HostUnit> host_units;
+    std::vector<HostNeuron> host_neurons;
+
     // neuron groups (for trace ordering: lexicographic group name, offset)
     std::vector<std::string> group_names;
     std::vector<int64_t> group_ptr;

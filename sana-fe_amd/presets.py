@@ -135,3 +135,18 @@ def example_snn(arch):
     gin.map_to_core(cores[1], 1, 2)
     gout.map_to_core(cores[0])
     return net
+
+
+def loihi_with_plugin_somas(k, plugin_path, model="hodgkin_huxley", n_inputs=4):
+    """Config C5: the Loihi architecture plus `k` plugin soma units `hh[0..k-1]` on every core
+    (one neuron per unit instance, like plugins/hodgkin_huxley.cpp), with the soma default costs the
+    plugin does not simulate itself (src/pipeline.hpp:698-713)."""
+    arch = loihi(n_inputs=n_inputs)
+    tmpl = arch.cores()[0].template
+    core = arch.cores()[0]
+    costs = _f(energy_access_neuron=51.2e-12, latency_access_neuron=6.0e-9, energy_update_neuron=21.6e-12,
+               latency_update_neuron=3.7e-9, energy_spike_out=69.3e-12, latency_spike_out=30.0e-9)
+    for i in range(k):
+        core.create_soma("hh[%d]" % i, model, dict(costs), plugin=plugin_path)
+    assert core.template is tmpl
+    return arch

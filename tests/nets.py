@@ -154,3 +154,35 @@ def truenorth_net(S, n_tiles=16, neurons_per_core=256, remote_fraction=0.8, seed
     for c in range(n_tiles):
         g.map_to_core(cores[c], c * neurons_per_core, (c + 1) * neurons_per_core)
     return arch, net
+
+
+def hh_plugin_path():
+    return os.path.join(os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0], "sana-fe_amd", "plugins",
+                        "libhodgkin_huxley.so")
+
+
+def hodgkin_huxley(S, k=12, lif=24, seed=4):
+    """Config C5: `k` Hodgkin-Huxley plugin somas (snn/hh_example.net scaled up: m=0.0529 n=0.3177
+    h=0.5961, a distinct `current` each) driving a small LIF population on the Loihi architecture."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    arch = S.presets.loihi_with_plugin_somas(k, hh_plugin_path())
+    cores = arch.cores()
+    net = S.Network("hh")
+    g = net.create_neuron_group("hh", k, {"m": 0.0529, "n": 0.3177, "h": 0.5961}, "loihi_sparse_synapse", "", True, True)
+    for i in range(k):
+        g.apply_config(i, i + 1, soma_hw_name="hh[%d]" % i,
+                       attrs={"current": ((D.ATTR_DOUBLE, float(25 * i), None, None), D.FWD_ALL),
+                              "m": ((D.ATTR_DOUBLE, 0.0529, None, None), D.FWD_ALL),
+                              "n": ((D.ATTR_DOUBLE, 0.3177, None, None), D.FWD_ALL),
+                              "h": ((D.ATTR_DOUBLE, 0.5961, None, None), D.FWD_ALL)})
+    out = net.create_neuron_group("lif", lif, {"threshold": 3, "reset": 0, "leak_decay": 0.9}, "loihi_sparse_synapse", "",
+                                  True, True, "loihi_lif")
+    pairs = np.array([(i, j) for i in range(k) for j in rng.choice(lif, size=6, replace=False)])
+    g.connect_neurons_sparse(out, {"weight": rng.integers(1, 4, size=len(pairs)).astype(np.float64)}, pairs, narrow_float=False)
+    ring = np.array([(i, (i + 1) % k) for i in range(k)])
+    g.connect_neurons_sparse(g, {"weight": np.ones(k)}, ring, narrow_float=False)
+    g.map_to_core(cores[0])
+    out.map_to_core(cores[5], 0, lif // 2)
+    out.map_to_core(cores[0], lif // 2, lif)
+    return arch, net

@@ -210,3 +210,23 @@ def test_no_device_fallback_is_an_error(S):
     assert L.sanafe_chip_sim(h, 1, 0, 0, C.byref(t)) != 0
     assert b"no CPU execution path" in L.sanafe_last_error()
     L.sanafe_chip_destroy(h)
+
+
+@pytest.mark.parametrize("timing", ["simple", "detailed"])
+def test_hodgkin_huxley_plugin_c5(S, timing):
+    """Config C5: plugin somas loaded through `create_hodgkin_huxley` and evaluated by the host between the
+    neuron and the delivery kernels; V within 1e-6 relative (same libm here: bit-exact), spike steps exact."""
+    arch, net = nets.hodgkin_huxley(S)
+    chip, orc = make(S, arch, net)
+    fired_any = 0
+    for t in range(120):
+        a = chip.run(1, timing, record=True)
+        b = orc.step(timing)
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        assert np.array_equal(chip.status(), orc.status()), t
+        assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-6, atol=0), t
+        fired_any += a["neurons_fired"]
+    assert fired_any > 0
