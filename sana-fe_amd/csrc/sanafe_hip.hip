@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
 // ---------------------------------------------------------------------------------------
 constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
 constexpr int EXPAND_UNROLL = 4;
+constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bitmap
 
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
@@ -385,7 +386,7 @@ template <bool PACKED_W>
 __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
-    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE_CHUNK + 4];  // exclusive prefix of their synapse counts
+    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE_CHUNK + 4];  // lane-local event prefixes, then the head bitmap (+2 guard words)
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -458,63 +459,96 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
         const uint32_t my_act = (uint32_t) __popc(amask);
         const uint32_t incl_act = wave_inclusive_scan(my_act);
         const uint32_t n_act = __shfl(incl_act, WAVE - 1, WAVE);
-        uint32_t pos = incl_act - my_act;
         uint32_t my_ev = 0;
+        uint32_t st4[AX_PER_THREAD], sb4[AX_PER_THREAD]; // MY active axons, packed to the front: event start, first synapse
 #pragma unroll
-        for (int k = 0; k < AX_PER_THREAD; k++)
+        for (int k = 0; k < AX_PER_THREAD; k++) st4[k] = ~0u, sb4[k] = 0u;
         {
-            if (amask & (1u << k))
+            uint32_t j = 0;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
             {
-                w_beg[pos] = syn_off;
-                w_pref[pos] = my_ev; // lane-local exclusive prefix; the lane base is added below
-                my_ev += nsyn[k];
-                proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a0 + k];
-                pos++;
+                if (amask & (1u << k))
+                {
+                    // (static indices only: a runtime-indexed register array would go to scratch)
+                    if (j == 0) st4[0] = my_ev, sb4[0] = syn_off;
+                    else if (j == 1) st4[1] = my_ev, sb4[1] = syn_off;
+                    else if (j == 2) st4[2] = my_ev, sb4[2] = syn_off;
+                    else st4[3] = my_ev, sb4[3] = syn_off;
+                    j++;
+                    my_ev += nsyn[k];
+                    proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a0 + k];
+                }
+                syn_off += nsyn[k];
             }
-            syn_off += nsyn[k];
         }
         const uint32_t incl_ev = wave_inclusive_scan(my_ev);
         const uint32_t n_ev = __shfl(incl_ev, WAVE - 1, WAVE);
         const uint32_t lane_base = incl_ev - my_ev;
-        pos = incl_act - my_act;
-        for (uint32_t k = 0; k < my_act; k++) w_pref[pos + k] += lane_base;
-        if (lane == 0) w_pref[n_act] = n_ev;
-        wave_lds_fence();
-        // ---- expand to synaptic events, EXPAND_UNROLL tiles of 64 per pass so that several
-        //      independent gathers are in flight before the first accumulate waits on them ----
-        for (uint32_t e0 = 0; e0 < n_ev; e0 += WAVE * EXPAND_UNROLL)
+        // event e of the chunk belongs to the active axon i with start[i] <= e < start[i+1]; its synapse
+        // is syn_base + (first_synapse[i] - start[i]) + e, so one word per active axon is enough
         {
-            uint32_t meta[EXPAND_UNROLL];
-            double wgt[EXPAND_UNROLL];
+            const uint32_t pos = incl_act - my_act;
 #pragma unroll
-            for (int u = 0; u < EXPAND_UNROLL; u++)
+            for (int k = 0; k < AX_PER_THREAD; k++)
+                if ((uint32_t) k < my_act)
+                {
+                    st4[k] += lane_base;
+                    w_beg[pos + k] = sb4[k] - st4[k];
+                }
+        }
+        // ---- expand to synaptic events.  Ownership comes from a bitmap of axon starts ("heads"):
+        //      owner(e) = (#heads at or before e) - 1, a popcount instead of a binary search. ----
+        uint32_t heads_before = 0; // heads in earlier windows (wave-uniform)
+        for (uint32_t w0 = 0; w0 < n_ev; w0 += HEAD_WINDOW)
+        {
+            w_pref[lane] = 0u; // 64 words = HEAD_WINDOW bits
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
             {
-                const uint32_t e = e0 + u * WAVE + lane;
-                meta[u] = 1u << 19; // "drop": nothing to add
-                wgt[u] = 0.0;
-                if (e < n_ev)
-                {
-                    uint32_t lo = 0, hi = n_act; // largest lo with w_pref[lo] <= e
-                    while (hi - lo > 1)
-                    {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (w_pref[mid] <= e) lo = mid;
-                        else hi = mid;
-                    }
-                    const unsigned long long s = syn_base + w_beg[lo] + (e - w_pref[lo]);
-                    meta[u] = im.syn_meta[s];
-                    if (!PACKED_W) wgt[u] = im.syn_weight[s];
-                }
+                const uint32_t rel = st4[k] - w0;
+                if (st4[k] != ~0u && st4[k] >= w0 && rel < HEAD_WINDOW) atomicOr(&w_pref[rel >> 5], 1u << (rel & 31u));
             }
+            wave_lds_fence();
+            const uint32_t w_end = (n_ev - w0 < HEAD_WINDOW) ? n_ev - w0 : HEAD_WINDOW;
+            uint32_t seen = heads_before; // heads before the current tile
+            for (uint32_t e0 = 0; e0 < w_end; e0 += WAVE * EXPAND_UNROLL)
+            {
+                uint32_t meta[EXPAND_UNROLL];
+                double wgt[EXPAND_UNROLL];
 #pragma unroll
-            for (int u = 0; u < EXPAND_UNROLL; u++)
-                if (!((meta[u] >> 19) & 1u))
+                for (int u = 0; u < EXPAND_UNROLL; u++)
                 {
-                    const uint32_t idx = ((meta[u] >> 16) & 7u) * npad + (meta[u] & 0xffffu);
-                    const double w = PACKED_W ? (double) ((int) meta[u] >> 20) : wgt[u];
-                    atomicAdd(&acc[idx], w); // ds_add_f64
-                    touched[idx] = 1;
+                    const uint32_t tile = e0 + u * WAVE;
+                    meta[u] = 1u << 19; // "drop": nothing to add
+                    wgt[u] = 0.0;
+                    if (tile < w_end) // wave-uniform
+                    {
+                        const unsigned long long h = (unsigned long long) w_pref[tile >> 5] | ((unsigned long long) w_pref[(tile >> 5) + 1] << 32);
+                        const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                        const uint32_t owner = seen + (uint32_t) __popcll(h & le) - 1u;
+                        seen += (uint32_t) __popcll(h);
+                        const uint32_t e = w0 + tile + lane;
+                        if (e < n_ev)
+                        {
+                            const unsigned long long s = syn_base + (uint32_t) (w_beg[owner] + e);
+                            meta[u] = im.syn_meta[s];
+                            if (!PACKED_W) wgt[u] = im.syn_weight[s];
+                        }
+                    }
                 }
+#pragma unroll
+                for (int u = 0; u < EXPAND_UNROLL; u++)
+                    if (!((meta[u] >> 19) & 1u))
+                    {
+                        const uint32_t idx = ((meta[u] >> 16) & 7u) * npad + (meta[u] & 0xffffu);
+                        const double w = PACKED_W ? (double) ((int) meta[u] >> 20) : wgt[u];
+                        atomicAdd(&acc[idx], w); // ds_add_f64
+                        touched[idx] = 1;
+                    }
+            }
+            heads_before = seen;
         }
         wave_lds_fence(); // the lists are rewritten by the next chunk
     }
