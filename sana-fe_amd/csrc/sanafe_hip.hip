@@ -143,13 +143,16 @@ __device__ __forceinline__ int cvt_int_x86(double x)
 }
 
 // ---------------------------------------------------------------------------------------
-// K1: neuron update.  grid = ceil(n_cores / 4), block = 256 (wave w <-> core 4*blockIdx+w)
+// K1: neuron update.  grid = n_cores, block = 256: the core's 64-slot chunks are dealt to the
+// workgroup's 4 wavefronts (a 256-neuron TrueNorth core is one chunk per wave, a 1024-neuron
+// Loihi core four), every wave owns whole 64-slot chunks so the spike ballot maps 1:1 to bitmap words.
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t core = blockIdx.x * (NEURON_BLOCK / WAVE) + (threadIdx.x >> 6);
-    if (core >= im.n_cores) return;
+    __shared__ double s_d[NEURON_BLOCK / WAVE][5];
+    __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const uint32_t core = blockIdx.x;
     const long long done = *st.t;      // steps simulated before this one
     const long long t = done + 1;      // Timestep::timestep of this step
     const uint32_t nbase = im.core_nbase[core];
@@ -163,7 +166,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
     double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
     long long n_upd = 0, n_fire = 0, n_pack = 0, n_hops = 0, n_ev = 0;
 
-    for (uint32_t off = 0; off < ncount; off += WAVE)
+    for (uint32_t off = wave * WAVE; off < ncount; off += NEURON_BLOCK)
     {
         const uint32_t g = nbase + off + lane;
         const bool live = (off + lane) < ncount;
@@ -329,20 +332,43 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
     n_ev = wave_sum(n_ev);
     if (lane == 0)
     {
+        s_d[wave][0] = e_soma;
+        s_d[wave][1] = e_dend;
+        s_d[wave][2] = e_syn;
+        s_d[wave][3] = e_net;
+        s_d[wave][4] = lat;
+        s_l[wave][0] = n_upd;
+        s_l[wave][1] = n_fire;
+        s_l[wave][2] = n_pack;
+        s_l[wave][3] = n_hops;
+        s_l[wave][4] = n_ev;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double d[5] = {0, 0, 0, 0, 0};
+        long long l[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < NEURON_BLOCK / WAVE; w++) // fixed order: deterministic
+            for (int k = 0; k < 5; k++)
+            {
+                d[k] += s_d[w][k];
+                l[k] += s_l[w][k];
+            }
         CorePart cp;
-        cp.e_soma = e_soma;
-        cp.e_dend = e_dend;
-        cp.e_syn = e_syn;
-        cp.e_net = e_net;
+        cp.e_soma = d[0];
+        cp.e_dend = d[1];
+        cp.e_syn = d[2];
+        cp.e_net = d[3];
         // sum of Message::generation_delay over the core's messages incl. the placeholder
         // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81)
-        cp.gen_sum = lat + (double) n_pack * im.core_axon_out_latency[core];
-        cp.updated = n_upd;
-        cp.fired = n_fire;
-        cp.packets = n_pack;
-        cp.hops = n_hops;
-        cp.events = n_ev;
+        cp.gen_sum = d[4] + (double) l[2] * im.core_axon_out_latency[core];
+        cp.updated = l[0];
+        cp.fired = l[1];
+        cp.packets = l[2];
+        cp.hops = l[3];
+        cp.events = l[4];
         st.core_part[core] = cp;
+        st.core_proc[core] = 0.0; // the delivery slices of this step add their processing delays
     }
 }
 
@@ -573,7 +599,9 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
     {
         double p = 0.0;
         for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
-        st.slice_proc[slice] = p;
+        // one add per slice; the order over a core's slices is not fixed, which moves the simple
+        // timing model's per-core sum by at most an ulp or two (tolerance on sim_time is 1e-6)
+        atomicAdd(&st.core_proc[core], p);
     }
 }
 
@@ -623,10 +651,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
         hops += cp.hops;
         events += cp.events;
         gmax = fmax(gmax, cp.gen_sum);
-        double p = 0.0;
-        for (uint32_t s = im.core_slice_beg[c]; s < im.core_slice_beg[c + 1]; s++) p += st.slice_proc[s];
-        st.core_proc[c] = p;
-        pmax = fmax(pmax, p);
+        pmax = fmax(pmax, st.core_proc[c]);
     }
     e_soma = block_sum(e_soma, sd);
     e_dend = block_sum(e_dend, sd);
@@ -1011,7 +1036,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->v0.assign(h.slot_v0, h.slot_v0 + h.n_slots);
         HIPC(hipMemcpy(st.v, h.slot_v0, (size_t) h.n_slots * sizeof(double), hipMemcpyHostToDevice));
     }
-    c->neuron_grid = (h.n_cores + (NEURON_BLOCK / WAVE) - 1) / (NEURON_BLOCK / WAVE);
+    c->neuron_grid = h.n_cores;
     {
         // LDS accumulator rows: one per synaptic delay value actually present in the image
         uint32_t max_delay = 0;
