@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
 def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0):
-    D = S.description
+    """Built through the product front-end (C++17 / PyBind11 description objects)."""
     n_tiles = max(1024, (cores_per_gpu * n_gpus + 3) // 4) if cores_per_gpu * n_gpus > 4096 else 1024
     arch = S.presets.loihi_large(n_tiles=n_tiles, n_inputs=4)
     cores = arch.cores()
@@ -41,11 +41,12 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
     g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
                                 "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(seed)
-    g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128, 0).astype(np.int64), D.ATTR_INT)
+    g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128.0, 0.0), integer=True)
     # a rank only needs the edges that start or end in its own shard of the neurons
     shard = None if n_gpus == 1 else (rank * n_per_gpu, (rank + 1) * n_per_gpu)
     src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard)
-    net._add_edges(src, dst, w, None, np.full(len(src), net.strings("loihi_sparse_synapse"), dtype=np.int32))
+    net.add_edges(src, dst, w, "loihi_sparse_synapse")
+    del src, dst, w
     for r in range(n_gpus):
         first_core = r * tiles_per_rank * 4
         for c in range(cores_per_gpu):
@@ -66,13 +67,13 @@ def cpu_baseline(S, args):
     g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
                                 "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(args.seed)
-    g.set_attribute_column("bias", np.where(rng.random(n) < args.p_fire, 128, 0).astype(np.int64), S.description.ATTR_INT)
+    g.set_attribute_column("bias", np.where(rng.random(n) < args.p_fire, 128.0, 0.0), integer=True)
     src, dst, w = S.chip.generate_random_edges(n, deg, args.seed)
-    net._add_edges(src, dst, w, None, np.full(len(src), net.strings("loihi_sparse_synapse"), dtype=np.int32))
+    net.add_edges(src, dst, w, "loihi_sparse_synapse")
     ac = arch.cores()
     for c in range(cores):
         g.map_to_core(ac[c], c * npc, (c + 1) * npc)
-    chip = OracleChip(S.to_desc(arch, net))
+    chip = OracleChip(S.cpp.to_desc(arch, net))
     for _ in range(3):
         chip.step("simple")
     steps, events, updates, t0 = 0, 0, 0, time.perf_counter()

@@ -58,10 +58,13 @@ class OracleChip:
     SIMPLE, DETAILED = 0, 1
 
     def __init__(self, built_desc):
-        self._built = built_desc
-        self.n = int(built_desc.desc.n_neurons)
+        self._built = built_desc  # keeps the buffers alive: the oracle borrows them
+        if hasattr(built_desc, "address"):  # sanafecpp_amd.Desc (C++ front-end)
+            address, self.n = built_desc.address, int(built_desc.n_neurons)
+        else:  # description.BuiltDesc (Python twin)
+            address, self.n = C.addressof(built_desc.desc), int(built_desc.desc.n_neurons)
         err = C.create_string_buffer(1024)
-        self._h = lib().oracle_create(C.addressof(built_desc.desc), err, 1024)
+        self._h = lib().oracle_create(address, err, 1024)
         if not self._h:
             raise RuntimeError(err.value.decode())
 

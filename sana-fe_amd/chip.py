@@ -16,6 +16,34 @@ from . import description as D
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+try:  # C++17 / PyBind11 description objects (the product front-end); built by `make -C sana-fe_amd`
+    from . import sanafecpp_amd as cpp
+except ImportError:  # pragma: no cover - the Python twin in description.py still works for tests
+    cpp = None
+
+
+class _Lowered:
+    """A lowered description + what SpikingChip needs to label traces, from either front-end."""
+
+    def __init__(self, arch, net):
+        if cpp is not None and isinstance(net, cpp.Network):
+            if not isinstance(arch, cpp.Architecture):
+                raise TypeError("a sanafecpp_amd.Network needs a sanafecpp_amd.Architecture")
+            self.handle = cpp.to_desc(arch, net)
+            self.address = self.handle.address
+            self.n_neurons = int(self.handle.n_neurons)
+            self.groups = {name: (int(base), int(count)) for name, base, count in net.group_table()}
+            ls, lp = net.log_flags()
+            self.log_spikes, self.log_potential = np.asarray(ls).astype(bool), np.asarray(lp).astype(bool)
+        else:
+            self.handle = D.to_desc(arch, net)
+            self.address = C.addressof(self.handle.desc)
+            self.n_neurons = int(self.handle.desc.n_neurons)
+            self.groups = {g.name: (g.base, g.count) for g in net._order}
+            cat = lambda name: (np.concatenate([getattr(g, name) for g in net._order]).astype(bool)  # noqa: E731
+                                if net._order else np.zeros(0, bool))
+            self.log_spikes, self.log_potential = cat("log_spikes"), cat("log_potential")
+
 
 class Totals(C.Structure):
     """sanafe_hip_totals (include/sanafe_hip.h)."""
@@ -157,10 +185,9 @@ class SpikingChip:
                                       "use load(net, overwrite=True)")
         self._free()
         self._net = net
-        self._built = D.to_desc(self.arch, net)
+        self._built = _Lowered(self.arch, net)
         h = C.c_void_p()
-        rc = self._L.sanafe_chip_create(C.addressof(self._built.desc), self._device, self._n_ranks, self._rank,
-                                        C.byref(h))
+        rc = self._L.sanafe_chip_create(self._built.address, self._device, self._n_ranks, self._rank, C.byref(h))
         if rc != 0:
             msg = self._L.sanafe_last_error().decode()
             if msg.startswith("HardwareMappingError"):
@@ -169,21 +196,22 @@ class SpikingChip:
                 raise NotImplementedError(msg)
             raise RuntimeError(msg)
         self._h = h
-        self.n_neurons = int(self._built.desc.n_neurons)
-        self._log_spikes = np.concatenate([g.log_spikes for g in net._order]).astype(bool) if net._order else np.zeros(0, bool)
-        self._log_potential = np.concatenate([g.log_potential for g in net._order]).astype(bool) if net._order else np.zeros(0, bool)
+        self.n_neurons = self._built.n_neurons
+        self._log_spikes = self._built.log_spikes.copy()
+        self._log_potential = self._built.log_potential.copy()
         # trace order: groups lexicographically by name, neurons by offset (std::map, src/chip.cpp:1616-1629)
         order = []
-        for name in sorted(net.groups):
-            g = net.groups[name]
-            order.append(np.arange(g.base, g.base + g.count))
+        for name in sorted(self._built.groups):
+            base, count = self._built.groups[name]
+            order.append(np.arange(base, base + count))
         self._trace_order = np.concatenate(order) if order else np.zeros(0, np.int64)
         self._gid_label = {}
         self.total_timesteps = 0
 
     @property
     def mapped_neuron_groups(self):
-        return {name: [MappedNeuronRef(self, g.base + i) for i in range(g.count)] for name, g in self._net.groups.items()}
+        return {name: [MappedNeuronRef(self, base + i) for i in range(count)]
+                for name, (base, count) in self._built.groups.items()}
 
     def info(self):
         i = ChipInfo()
@@ -215,8 +243,8 @@ class SpikingChip:
 
     def set_bias(self, group, values):
         """Vectorised MappedNeuron.set_attributes(model_attributes={'bias': b}) for a whole group (DVS frames)."""
-        g = self._net.groups[str(group)]
-        self._set_bias(np.arange(g.base, g.base + g.count), np.asarray(values, dtype=np.float64))
+        base, count = self._built.groups[str(group)]
+        self._set_bias(np.arange(base, base + count), np.asarray(values, dtype=np.float64))
 
     # -- raw accessors (desc order) ------------------------------------------------------------
     def status(self):
@@ -334,9 +362,9 @@ class SpikingChip:
 
     def _labels(self):
         if not self._gid_label:
-            for name, g in self._net.groups.items():
-                for i in range(g.count):
-                    self._gid_label[g.base + i] = (name, i)  # NeuronAddress(group_name, neuron_offset)
+            for name, (base, count) in self._built.groups.items():
+                for i in range(count):
+                    self._gid_label[base + i] = (name, i)  # NeuronAddress(group_name, neuron_offset)
         return self._gid_label
 
     def _message_dicts(self, arr):

@@ -293,7 +293,9 @@ class Architecture:
         return t
 
     def create_core(self, name, parent_tile_id, buffer_position=BUF_BEFORE_SOMA, buffer_inside_unit=False,
-                    max_neurons_supported=1024, log_energy=False, template=None):
+                    max_neurons_supported=1024, log_energy=False, template=None, share_units_with=None):
+        if share_units_with is not None:
+            template = share_units_with.template
         if isinstance(buffer_position, str):
             buffer_position = parse_buffer_position(buffer_position, buffer_inside_unit)
         tile = self.tiles[parent_tile_id]
@@ -305,6 +307,9 @@ class Architecture:
 
     def cores(self):
         return list(self._cores)
+
+    def tile_cores(self, tile):
+        return list(self.tiles[tile].cores)
 
     @property
     def core_count(self):

@@ -899,3 +899,24 @@ extern "C" int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t 
 }
 
 extern "C" void sanafe_edge_set_free(sanafe_edge_set *set) { delete set; }
+
+// ---------------------------------------------------------------------------------------------
+// YAML subset reader: canonical JSON of a description file (tests compare it with PyYAML)
+// ---------------------------------------------------------------------------------------------
+#include "yaml_subset.hpp"
+extern "C" char *sanafe_yaml_file_to_json(const char *path)
+{
+    try
+    {
+        const std::string js = sanafe_amd::yaml_to_json(sanafe_amd::yaml_parse_file(path));
+        char *out = static_cast<char *>(std::malloc(js.size() + 1));
+        std::memcpy(out, js.c_str(), js.size() + 1);
+        return out;
+    }
+    catch (const std::exception &e)
+    {
+        g_err = e.what();
+        return nullptr;
+    }
+}
+extern "C" void sanafe_free(void *p) { std::free(p); }

@@ -1,0 +1,1038 @@
+// description.cpp -- see description.hpp.
+#include "description.hpp"
+
+#include <algorithm>
+#include <cerrno>
+#include <climits>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <numeric>
+#include <set>
+#include <stdexcept>
+
+#include "yaml_subset.hpp"
+
+namespace sanafe_amd
+{
+namespace
+{
+const std::set<std::string> kReserved = {"soma_hw_name", "default_synapse_hw_name", "dendrite_hw_name", "log_spikes",
+        "log_potential", "log_v"}; // src/attribute.hpp:24-31
+const std::set<std::string> kSkipKeys = {"soma_hw_name", "default_synapse_hw_name", "dendrite_hw_name", "log_spikes",
+        "log_potential", "synapse", "dendrite", "soma"}; // src/yaml_common.cpp:30-36
+
+std::string trim(const std::string &s)
+{
+    size_t b = 0, e = s.size();
+    while (b < e && (s[b] == ' ' || s[b] == '\t')) b++;
+    while (e > b && (s[e - 1] == ' ' || s[e - 1] == '\t')) e--;
+    return s.substr(b, e - b);
+}
+bool as_bool_text(const std::string &s)
+{
+    const std::string t = trim(s);
+    return t == "true" || t == "True" || t == "TRUE" || t == "1";
+}
+std::pair<int64_t, int64_t> parse_range(const std::string &s) // src/yaml_common.cpp:264-319
+{
+    const size_t d = s.find("..");
+    if (d == std::string::npos) throw std::runtime_error("Range delimiter '..' not found");
+    const size_t bs = s.find('['), be = s.find(']');
+    const size_t start = (bs != std::string::npos) ? bs + 1 : 0;
+    const size_t end = (be != std::string::npos) ? be : s.size();
+    if (end <= start || d <= start || d >= end) throw std::runtime_error("Invalid range format");
+    int64_t a = 0, b = 0;
+    try
+    {
+        a = std::stoll(s.substr(start, d - start));
+        b = std::stoll(s.substr(d + 2, end - d - 2));
+    }
+    catch (const std::exception &)
+    {
+        throw std::runtime_error("Invalid range string, failed to convert");
+    }
+    if (a > b) throw std::runtime_error("Invalid range; first > last");
+    return {a, b};
+}
+std::string base_name(const std::string &s) { return s.substr(0, s.find('[')); }
+} // namespace
+
+AttrValue scalar_attr(const std::string &text)
+{
+    const std::string t = trim(text);
+    if (!t.empty())
+    {
+        // int (must fit a C int, like c4::from_chars into `int`)
+        size_t i = (t[0] == '+' || t[0] == '-') ? 1 : 0;
+        bool digits = i < t.size();
+        for (size_t k = i; k < t.size(); k++)
+            if (t[k] < '0' || t[k] > '9') digits = false;
+        if (digits && t.size() - i <= 10)
+        {
+            const long long v = std::strtoll(t.c_str(), nullptr, 10);
+            if (v >= INT_MIN && v <= INT_MAX) return AttrValue::Int(static_cast<long>(v));
+        }
+        char *endp = nullptr;
+        errno = 0;
+        const double d = std::strtod(t.c_str(), &endp);
+        if (endp && *endp == '\0' && endp != t.c_str() && t != "true" && t != "false") return AttrValue::Double(d);
+    }
+    if (t == "true" || t == "True" || t == "TRUE") return AttrValue::Bool(true);
+    if (t == "false" || t == "False" || t == "FALSE") return AttrValue::Bool(false);
+    return AttrValue::String(text);
+}
+
+int parse_buffer_position(const std::string &s, bool inside)
+{
+    if (s == "dendrite") return inside ? SANAFE_BUF_INSIDE_DENDRITE : SANAFE_BUF_BEFORE_DENDRITE;
+    if (s == "soma") return inside ? SANAFE_BUF_INSIDE_SOMA : SANAFE_BUF_BEFORE_SOMA;
+    if (s == "axon_out") return SANAFE_BUF_BEFORE_AXON_OUT;
+    throw std::invalid_argument("Error: Buffer position not supported");
+}
+
+// ------------------------------------------------------------------------------ Architecture
+void CoreConfig::create_axon_in(const std::string &, double e, double l) { tmpl->axon_in.push_back({e, l}); }
+void CoreConfig::create_axon_out(const std::string &, double e, double l) { tmpl->axon_out.push_back({e, l}); }
+
+UnitConfig &CoreConfig::create_unit(const std::string &section, const std::string &unit_name, const std::string &model,
+        const std::map<std::string, AttrValue> &attributes, const std::string &plugin, bool log_e, bool log_l, bool every_ts)
+{
+    int bit = 0;
+    if (section == "synapse") bit = SANAFE_IMPL_SYNAPSE;
+    else if (section == "dendrite") bit = SANAFE_IMPL_DENDRITE;
+    else if (section == "soma") bit = SANAFE_IMPL_SOMA;
+    else throw std::runtime_error("Section not recognized");
+    for (UnitConfig &u : tmpl->units)
+        if (u.name == unit_name)
+        {
+            u.implements |= bit;
+            for (const auto &kv : attributes) u.attributes.emplace(kv.first, kv.second); // std::map::merge keeps existing keys
+            if (!plugin.empty()) u.plugin = plugin;
+            return u;
+        }
+    UnitConfig u;
+    u.name = unit_name;
+    u.model = model;
+    u.plugin = plugin;
+    u.implements = bit;
+    u.log_energy = log_e;
+    u.log_latency = log_l;
+    u.update_every_timestep = every_ts;
+    u.attributes = attributes;
+    u.attributes.emplace("model", AttrValue::String(model));
+    if (!plugin.empty()) u.attributes.emplace("plugin", AttrValue::String(plugin));
+    tmpl->units.push_back(std::move(u));
+    return tmpl->units.back();
+}
+
+Architecture::Architecture(std::string n, int width, int height, int link_buffer_size, std::map<int64_t, double> sync)
+        : name(std::move(n)), noc_width(width), noc_height(height), noc_buffer_size(link_buffer_size), sync_table(std::move(sync))
+{
+    if (sync_table.empty()) sync_table[0] = 0.0;
+}
+
+TileConfig &Architecture::create_tile(const std::string &tile_name, const std::array<double, 4> &he, const std::array<double, 4> &hl,
+        bool log_e)
+{
+    TileConfig t;
+    t.name = tile_name;
+    t.id = static_cast<int>(tiles.size());
+    t.hop_energy = he;
+    t.hop_latency = hl;
+    t.log_energy = log_e;
+    tiles.push_back(std::move(t));
+    return tiles.back();
+}
+
+CoreConfig &Architecture::create_core(const std::string &core_name, int parent_tile_id, int buffer_position, int64_t max_neurons,
+        bool log_e, std::shared_ptr<CoreTemplate> share)
+{
+    if (parent_tile_id < 0 || parent_tile_id >= static_cast<int>(tiles.size())) throw std::invalid_argument("Tile ID >= tile count");
+    if (!cores.empty() && cores.back().parent_tile_id > parent_tile_id)
+        throw std::invalid_argument("cores must be created in tile order");
+    CoreConfig c;
+    c.name = core_name;
+    c.parent_tile_id = parent_tile_id;
+    c.offset_within_tile = static_cast<int>(tiles[parent_tile_id].cores.size());
+    c.id = static_cast<int>(cores.size());
+    c.buffer_position = buffer_position;
+    c.max_neurons_supported = max_neurons;
+    c.log_energy = log_e;
+    c.tmpl = share ? std::move(share) : std::make_shared<CoreTemplate>();
+    tiles[parent_tile_id].cores.push_back(c.id);
+    cores.push_back(std::move(c));
+    return cores.back();
+}
+
+// ------------------------------------------------------------------------------ Network
+int32_t SpikingNetwork::intern(const std::string &s)
+{
+    if (s.empty()) return -1;
+    auto it = string_ids.find(s);
+    if (it != string_ids.end()) return it->second;
+    const int32_t id = static_cast<int32_t>(strings.size());
+    strings.push_back(s);
+    string_ids.emplace(s, id);
+    return id;
+}
+
+NeuronGroup::NeuronGroup(SpikingNetwork *n, std::string nm, int64_t cnt, int64_t b)
+        : net(n), name(std::move(nm)), count(cnt), base(b), core(cnt, -1), soma_hw(cnt, -1), dendrite_hw(cnt, -1), synapse_hw(cnt, -1),
+          map_order(cnt, 0), log_spikes(cnt, 0), log_potential(cnt, 0)
+{
+}
+
+void NeuronGroup::set_attribute(const std::string &key, const AttrValue &v, int fwd, int64_t lo, int64_t hi)
+{
+    if (kReserved.count(key))
+        throw std::invalid_argument("Reserved neuron attribute '" + key + "' cannot be used as a model attribute. Pass it as a direct argument instead.");
+    if (lo < 0 || hi > count || lo > hi) throw std::out_of_range("neuron range out of bounds");
+    Column &c = columns[key];
+    if (c.mask.empty())
+    {
+        c.mask.assign(count, 0);
+        c.type.assign(count, 0);
+        c.fwd.assign(count, 0);
+        c.num.assign(count, 0.0);
+        c.str.assign(count, -1);
+    }
+    const int32_t sid = v.type == SANAFE_ATTR_STRING ? net->intern(v.str) : -1;
+    for (int64_t i = lo; i < hi; i++)
+    {
+        c.mask[i] = 1;
+        c.type[i] = static_cast<uint8_t>(v.type);
+        c.fwd[i] = static_cast<uint8_t>(fwd);
+        c.num[i] = v.num;
+        c.str[i] = sid;
+        if (v.type == SANAFE_ATTR_LIST) list_values[{key, i}] = v.list;
+    }
+}
+
+void NeuronGroup::set_attribute_column(const std::string &key, const double *values, int attr_type, int fwd)
+{
+    if (kReserved.count(key)) throw std::invalid_argument("Reserved neuron attribute '" + key + "'");
+    Column &c = columns[key];
+    c.mask.assign(count, 1);
+    c.type.assign(count, static_cast<uint8_t>(attr_type));
+    c.fwd.assign(count, static_cast<uint8_t>(fwd));
+    c.num.assign(values, values + count);
+    c.str.assign(count, -1);
+}
+
+void NeuronGroup::apply_config(int64_t lo, int64_t hi, const std::optional<std::string> &soma, const std::optional<std::string> &syn,
+        const std::optional<std::string> &dend, const std::optional<bool> &ls, const std::optional<bool> &lp,
+        const std::map<std::string, std::pair<AttrValue, int>> &attributes)
+{
+    if (lo < 0 || hi > count || lo > hi) throw std::out_of_range("neuron range out of bounds");
+    if (syn) std::fill(synapse_hw.begin() + lo, synapse_hw.begin() + hi, net->intern(*syn));
+    if (dend) std::fill(dendrite_hw.begin() + lo, dendrite_hw.begin() + hi, net->intern(*dend));
+    if (soma) std::fill(soma_hw.begin() + lo, soma_hw.begin() + hi, net->intern(*soma));
+    if (ls) std::fill(log_spikes.begin() + lo, log_spikes.begin() + hi, *ls ? 1 : 0);
+    if (lp) std::fill(log_potential.begin() + lo, log_potential.begin() + hi, *lp ? 1 : 0);
+    for (const auto &kv : attributes) set_attribute(kv.first, kv.second.first, kv.second.second, lo, hi);
+}
+
+void NeuronGroup::map_to_core(const CoreConfig &c, int64_t lo, int64_t hi)
+{
+    if (lo < 0 || hi > count || lo > hi) throw std::out_of_range("neuron range out of bounds");
+    for (int64_t i = lo; i < hi; i++)
+    {
+        core[i] = c.id;
+        map_order[i] = ++net->mapping_count;
+    }
+}
+
+void SpikingNetwork::add_edge(int64_t s, int64_t d, double w, int delay, int32_t hw)
+{
+    if (delay >= 0 && edge_delay.size() < edge_src.size()) edge_delay.resize(edge_src.size(), -1);
+    edge_src.push_back(s);
+    edge_dst.push_back(d);
+    edge_weight.push_back(w);
+    edge_synapse_hw.push_back(hw);
+    if (delay >= 0 || !edge_delay.empty()) edge_delay.push_back(static_cast<int8_t>(delay));
+}
+
+void SpikingNetwork::add_edges(const int64_t *s, const int64_t *d, const double *w, const int8_t *delay, int32_t hw, int64_t n)
+{
+    if (delay && edge_delay.size() < edge_src.size()) edge_delay.resize(edge_src.size(), -1);
+    edge_src.insert(edge_src.end(), s, s + n);
+    edge_dst.insert(edge_dst.end(), d, d + n);
+    edge_weight.insert(edge_weight.end(), w, w + n);
+    edge_synapse_hw.insert(edge_synapse_hw.end(), n, hw);
+    if (delay) edge_delay.insert(edge_delay.end(), delay, delay + n);
+    else if (!edge_delay.empty()) edge_delay.insert(edge_delay.end(), n, -1);
+}
+
+NeuronGroup &SpikingNetwork::create_neuron_group(const std::string &group_name, int64_t n,
+        const std::map<std::string, std::pair<AttrValue, int>> &attributes, const std::string &syn, const std::string &dend, bool lp,
+        bool ls, const std::string &soma)
+{
+    if (groups.count(group_name)) throw std::invalid_argument("Group: " + group_name + " already exists in SNN.");
+    order.push_back(std::make_unique<NeuronGroup>(this, group_name, n, neuron_count));
+    NeuronGroup &g = *order.back();
+    neuron_count += n;
+    groups[group_name] = &g;
+    g.apply_config(0, n, soma.empty() ? std::nullopt : std::optional<std::string>(soma),
+            syn.empty() ? std::nullopt : std::optional<std::string>(syn), dend.empty() ? std::nullopt : std::optional<std::string>(dend), ls,
+            lp, attributes);
+    return g;
+}
+
+void NeuronGroup::connect_neurons_sparse(NeuronGroup &dest, const std::vector<std::pair<int64_t, int64_t>> &pairs,
+        const std::vector<double> &weight, const std::vector<int> &delay)
+{
+    if (!weight.empty() && weight.size() != pairs.size()) throw std::invalid_argument("Error: Length of attribute list != number of defined edges.");
+    if (!delay.empty() && delay.size() != pairs.size()) throw std::invalid_argument("Error: Length of attribute list != number of defined edges.");
+    for (size_t i = 0; i < pairs.size(); i++)
+    {
+        if (pairs[i].first < 0 || pairs[i].first >= count) throw std::invalid_argument("Error: src id is out of range.");
+        if (pairs[i].second < 0 || pairs[i].second >= dest.count) throw std::invalid_argument("Error: dest nid is out of range.");
+        net->add_edge(base + pairs[i].first, dest.base + pairs[i].second, weight.empty() ? 0.0 : weight[i], delay.empty() ? -1 : delay[i],
+                dest.synapse_hw[pairs[i].second]);
+    }
+}
+
+void NeuronGroup::connect_neurons_dense(NeuronGroup &dest, const std::vector<double> &weight, const std::vector<int> &delay)
+{
+    const size_t total = static_cast<size_t>(count) * static_cast<size_t>(dest.count);
+    if ((!weight.empty() && weight.size() < total) || (!delay.empty() && delay.size() < total))
+        throw std::invalid_argument("Not enough entries defined for attribute");
+    for (int64_t s = 0; s < count; s++)
+        for (int64_t t = 0; t < dest.count; t++)
+        {
+            const size_t k = static_cast<size_t>(s) * dest.count + t; // src/network.cpp:579-580
+            net->add_edge(base + s, dest.base + t, weight.empty() ? 0.0 : weight[k], delay.empty() ? -1 : delay[k], dest.synapse_hw[t]);
+        }
+}
+
+void NeuronGroup::connect_neurons_conv2d(NeuronGroup &dest, const std::vector<double> &weight, const std::vector<int> &delay, int iw,
+        int ih, int ic, int kw, int kh, int kc, int sw, int sh)
+{
+    const std::pair<const char *, int> params[] = {{"input_width", iw}, {"input_height", ih}, {"input_channels", ic}, {"kernel_width", kw},
+            {"kernel_height", kh}, {"kernel_count", kc}, {"stride_width", sw}, {"stride_height", sh}};
+    for (const auto &p : params)
+        if (p.second <= 0)
+            throw std::invalid_argument(std::string("Error: Conv2D parameter '") + p.first + "' must be > 0 (got " + std::to_string(p.second) + ").");
+    if (kw > iw || kh > ih) throw std::invalid_argument("Error: Conv2D kernel larger than input with zero padding.");
+    const int ow = (iw - kw) / sw + 1, oh = (ih - kh) / sh + 1;
+    if (static_cast<int64_t>(ic) * iw * ih != count)
+        throw std::invalid_argument("Expected " + std::to_string(static_cast<int64_t>(ic) * iw * ih) +
+                " neurons in source group for convolution but there are " + std::to_string(count) + " neurons.\n");
+    if (static_cast<int64_t>(kc) * ow * oh != dest.count)
+        throw std::invalid_argument("Expected " + std::to_string(static_cast<int64_t>(kc) * ow * oh) +
+                " neurons in dest group for convolution but there are " + std::to_string(dest.count) + " neurons.\n");
+    // creation order c_out, y_out, x_out, c_in, y_filter, x_filter (src/network.cpp:310-374)
+    for (int co = 0; co < kc; co++)
+        for (int yo = 0; yo < oh; yo++)
+            for (int xo = 0; xo < ow; xo++)
+            {
+                const int64_t d = static_cast<int64_t>(co) * ow * oh + static_cast<int64_t>(yo) * ow + xo;
+                for (int ci = 0; ci < ic; ci++)
+                    for (int yf = 0; yf < kh; yf++)
+                    {
+                        const int yp = yo * sh + yf;
+                        if (yp < 0 || yp >= ih) continue;
+                        for (int xf = 0; xf < kw; xf++)
+                        {
+                            const int xp = xo * sw + xf;
+                            if (xp < 0 || xp >= iw) continue;
+                            const int64_t s = static_cast<int64_t>(ci) * iw * ih + static_cast<int64_t>(yp) * iw + xp;
+                            const size_t f = static_cast<size_t>(yf) * kw * ic * kc + static_cast<size_t>(xf) * ic * kc +
+                                    static_cast<size_t>(ci) * kc + co; // [y][x][c_in][c_out], src/network.cpp:508-519
+                            if ((!weight.empty() && weight.size() <= f) || (!delay.empty() && delay.size() <= f))
+                                throw std::invalid_argument("Not enough entries defined for attribute");
+                            net->add_edge(base + s, dest.base + d, weight.empty() ? 0.0 : weight[f], delay.empty() ? -1 : delay[f],
+                                    dest.synapse_hw[d]);
+                        }
+                    }
+            }
+}
+
+// ------------------------------------------------------------------------------ lowering
+namespace
+{
+struct AttrRows
+{
+    std::vector<int32_t> key, str;
+    std::vector<uint8_t> type, fwd;
+    std::vector<double> num;
+    std::vector<int64_t> list_ptr{0};
+    std::vector<double> list_num;
+    void add(int32_t k, const AttrValue &v, int f, int32_t sid)
+    {
+        key.push_back(k);
+        type.push_back(static_cast<uint8_t>(v.type));
+        fwd.push_back(static_cast<uint8_t>(f));
+        num.push_back(v.num);
+        str.push_back(sid);
+        if (v.type == SANAFE_ATTR_LIST) list_num.insert(list_num.end(), v.list.begin(), v.list.end());
+        list_ptr.push_back(static_cast<int64_t>(list_num.size()));
+    }
+};
+template <typename T> const T *keep(std::vector<std::vector<T>> &store, std::vector<T> v)
+{
+    if (v.empty()) v.push_back(T{});
+    store.push_back(std::move(v));
+    return store.back().data();
+}
+sanafe_attr_table emit(BuiltDesc &b, AttrRows &r)
+{
+    sanafe_attr_table t{};
+    t.n = static_cast<int64_t>(r.key.size());
+    t.key = keep(b.i32, std::move(r.key));
+    t.type = keep(b.u8, std::move(r.type));
+    t.fwd = keep(b.u8, std::move(r.fwd));
+    t.num = keep(b.f64, std::move(r.num));
+    t.str = keep(b.i32, std::move(r.str));
+    t.list_ptr = keep(b.i64, std::move(r.list_ptr));
+    t.list_num = keep(b.f64, std::move(r.list_num));
+    return t;
+}
+} // namespace
+
+std::unique_ptr<BuiltDesc> to_desc(const Architecture &arch, SpikingNetwork &net)
+{
+    auto out = std::make_unique<BuiltDesc>();
+    BuiltDesc &b = *out;
+    sanafe_desc &d = b.desc;
+    auto S = [&](const std::string &s) { return net.intern(s); };
+
+    d.noc_width = arch.noc_width;
+    d.noc_height = arch.noc_height;
+    d.noc_buffer_size = arch.noc_buffer_size;
+    {
+        std::vector<int64_t> k;
+        std::vector<double> v;
+        for (const auto &kv : arch.sync_table)
+        {
+            k.push_back(kv.first);
+            v.push_back(kv.second);
+        }
+        d.n_sync = static_cast<int32_t>(k.size());
+        d.sync_key = keep(b.i64, std::move(k));
+        d.sync_val = keep(b.f64, std::move(v));
+    }
+    // tiles
+    {
+        std::vector<int32_t> nm;
+        std::vector<double> he, hl;
+        std::vector<uint8_t> lg;
+        for (const TileConfig &t : arch.tiles)
+        {
+            nm.push_back(S(t.name));
+            he.insert(he.end(), t.hop_energy.begin(), t.hop_energy.end());
+            hl.insert(hl.end(), t.hop_latency.begin(), t.hop_latency.end());
+            lg.push_back(t.log_energy);
+        }
+        d.n_tiles = static_cast<int32_t>(arch.tiles.size());
+        d.tile_name = keep(b.i32, std::move(nm));
+        d.tile_hop_energy = keep(b.f64, std::move(he));
+        d.tile_hop_latency = keep(b.f64, std::move(hl));
+        d.tile_log_energy = keep(b.u8, std::move(lg));
+    }
+    // cores + templates
+    {
+        std::vector<int32_t> nm, tile, bp, tmpl_of;
+        std::vector<int64_t> mx;
+        std::vector<uint8_t> lg;
+        std::map<const CoreTemplate *, int32_t> tmpl_id;
+        std::vector<int32_t> ain_ptr{0}, aout_ptr{0}, unit_ptr{0};
+        std::vector<double> ain_e, ain_l, aout_e, aout_l;
+        std::vector<int32_t> u_name, u_model, u_plugin;
+        std::vector<uint8_t> u_impl, u_flags;
+        std::vector<int64_t> u_attr_ptr{0};
+        AttrRows rows;
+        for (const CoreConfig &c : arch.cores)
+        {
+            nm.push_back(S(c.name));
+            tile.push_back(c.parent_tile_id);
+            bp.push_back(c.buffer_position);
+            mx.push_back(c.max_neurons_supported);
+            lg.push_back(c.log_energy);
+            auto it = tmpl_id.find(c.tmpl.get());
+            if (it == tmpl_id.end())
+            {
+                it = tmpl_id.emplace(c.tmpl.get(), static_cast<int32_t>(tmpl_id.size())).first;
+                for (const auto &a : c.tmpl->axon_in)
+                {
+                    ain_e.push_back(a[0]);
+                    ain_l.push_back(a[1]);
+                }
+                ain_ptr.push_back(static_cast<int32_t>(ain_e.size()));
+                for (const auto &a : c.tmpl->axon_out)
+                {
+                    aout_e.push_back(a[0]);
+                    aout_l.push_back(a[1]);
+                }
+                aout_ptr.push_back(static_cast<int32_t>(aout_e.size()));
+                for (const UnitConfig &u : c.tmpl->units)
+                {
+                    u_name.push_back(S(u.name));
+                    u_model.push_back(S(u.model));
+                    u_plugin.push_back(u.plugin.empty() ? -1 : S(u.plugin));
+                    u_impl.push_back(static_cast<uint8_t>(u.implements));
+                    u_flags.push_back(static_cast<uint8_t>((u.log_energy ? SANAFE_UNIT_LOG_ENERGY : 0) |
+                            (u.log_latency ? SANAFE_UNIT_LOG_LATENCY : 0) | (u.update_every_timestep ? SANAFE_UNIT_UPDATE_EVERY_TIMESTEP : 0)));
+                    for (const auto &kv : u.attributes)
+                        rows.add(S(kv.first), kv.second, 7, kv.second.type == SANAFE_ATTR_STRING ? S(kv.second.str) : -1);
+                    u_attr_ptr.push_back(static_cast<int64_t>(rows.key.size()));
+                }
+                unit_ptr.push_back(static_cast<int32_t>(u_name.size()));
+            }
+            tmpl_of.push_back(it->second);
+        }
+        d.n_cores = static_cast<int32_t>(arch.cores.size());
+        d.core_name = keep(b.i32, std::move(nm));
+        d.core_tile = keep(b.i32, std::move(tile));
+        d.core_buffer_pos = keep(b.i32, std::move(bp));
+        d.core_max_neurons = keep(b.i64, std::move(mx));
+        d.core_log_energy = keep(b.u8, std::move(lg));
+        d.core_template = keep(b.i32, std::move(tmpl_of));
+        d.n_templates = static_cast<int32_t>(tmpl_id.size());
+        d.tmpl_axon_in_ptr = keep(b.i32, std::move(ain_ptr));
+        d.axon_in_energy = keep(b.f64, std::move(ain_e));
+        d.axon_in_latency = keep(b.f64, std::move(ain_l));
+        d.tmpl_axon_out_ptr = keep(b.i32, std::move(aout_ptr));
+        d.axon_out_energy = keep(b.f64, std::move(aout_e));
+        d.axon_out_latency = keep(b.f64, std::move(aout_l));
+        d.tmpl_unit_ptr = keep(b.i32, std::move(unit_ptr));
+        d.n_units = static_cast<int32_t>(u_name.size());
+        d.unit_name = keep(b.i32, std::move(u_name));
+        d.unit_model = keep(b.i32, std::move(u_model));
+        d.unit_plugin = keep(b.i32, std::move(u_plugin));
+        d.unit_implements = keep(b.u8, std::move(u_impl));
+        d.unit_flags = keep(b.u8, std::move(u_flags));
+        d.unit_attr_ptr = keep(b.i64, std::move(u_attr_ptr));
+        d.unit_attrs = emit(b, rows);
+    }
+    // groups / neurons
+    {
+        std::vector<int32_t> gname;
+        std::vector<int64_t> gptr;
+        const int64_t N = net.neuron_count;
+        std::vector<int32_t> core(N), soma(N), dend(N), syn(N);
+        std::vector<int64_t> order(N);
+        std::vector<uint8_t> ls(N), lp(N);
+        std::vector<int64_t> aptr(N + 1, 0);
+        for (const auto &gp : net.order)
+        {
+            const NeuronGroup &g = *gp;
+            gname.push_back(S(g.name));
+            gptr.push_back(g.base);
+            std::copy(g.core.begin(), g.core.end(), core.begin() + g.base);
+            std::copy(g.soma_hw.begin(), g.soma_hw.end(), soma.begin() + g.base);
+            std::copy(g.dendrite_hw.begin(), g.dendrite_hw.end(), dend.begin() + g.base);
+            std::copy(g.synapse_hw.begin(), g.synapse_hw.end(), syn.begin() + g.base);
+            std::copy(g.map_order.begin(), g.map_order.end(), order.begin() + g.base);
+            std::copy(g.log_spikes.begin(), g.log_spikes.end(), ls.begin() + g.base);
+            std::copy(g.log_potential.begin(), g.log_potential.end(), lp.begin() + g.base);
+            for (const auto &kv : g.columns) // std::map: key order
+                for (int64_t i = 0; i < g.count; i++) aptr[g.base + i + 1] += kv.second.mask[i];
+        }
+        gptr.push_back(N);
+        for (int64_t i = 0; i < N; i++) aptr[i + 1] += aptr[i];
+        const int64_t total = aptr[N];
+        std::vector<int32_t> key(total), str(total, -1);
+        std::vector<uint8_t> type(total), fwd(total);
+        std::vector<double> num(total);
+        std::vector<int64_t> cursor(aptr.begin(), aptr.end() - 1);
+        std::vector<std::pair<int64_t, const std::vector<double> *>> lists;
+        for (const auto &gp : net.order)
+        {
+            const NeuronGroup &g = *gp;
+            for (const auto &kv : g.columns)
+            {
+                const int32_t kid = S(kv.first);
+                const NeuronGroup::Column &c = kv.second;
+                for (int64_t i = 0; i < g.count; i++)
+                {
+                    if (!c.mask[i]) continue;
+                    const int64_t p = cursor[g.base + i]++;
+                    key[p] = kid;
+                    type[p] = c.type[i];
+                    fwd[p] = c.fwd[i];
+                    num[p] = c.num[i];
+                    str[p] = c.str[i];
+                    if (c.type[i] == SANAFE_ATTR_LIST) lists.emplace_back(p, &g.list_values.at({kv.first, i}));
+                }
+            }
+        }
+        std::vector<int64_t> lptr(total + 1, 0);
+        for (const auto &l : lists) lptr[l.first + 1] = static_cast<int64_t>(l.second->size());
+        for (int64_t i = 0; i < total; i++) lptr[i + 1] += lptr[i];
+        std::vector<double> lnum(lptr[total]);
+        for (const auto &l : lists) std::copy(l.second->begin(), l.second->end(), lnum.begin() + lptr[l.first]);
+        d.n_groups = static_cast<int32_t>(net.order.size());
+        d.group_name = keep(b.i32, std::move(gname));
+        d.group_ptr = keep(b.i64, std::move(gptr));
+        d.n_neurons = N;
+        d.neuron_core = keep(b.i32, std::move(core));
+        d.neuron_map_order = keep(b.i64, std::move(order));
+        d.neuron_soma_hw = keep(b.i32, std::move(soma));
+        d.neuron_dendrite_hw = keep(b.i32, std::move(dend));
+        d.neuron_synapse_hw = keep(b.i32, std::move(syn));
+        d.neuron_log_spikes = keep(b.u8, std::move(ls));
+        d.neuron_log_potential = keep(b.u8, std::move(lp));
+        d.neuron_attr_ptr = keep(b.i64, std::move(aptr));
+        sanafe_attr_table t{};
+        t.n = total;
+        t.key = keep(b.i32, std::move(key));
+        t.type = keep(b.u8, std::move(type));
+        t.fwd = keep(b.u8, std::move(fwd));
+        t.num = keep(b.f64, std::move(num));
+        t.str = keep(b.i32, std::move(str));
+        t.list_ptr = keep(b.i64, std::move(lptr));
+        t.list_num = keep(b.f64, std::move(lnum));
+        d.neuron_attrs = t;
+    }
+    // edges: borrowed from the network (it must outlive the desc)
+    d.n_edges = net.edge_count();
+    static const int64_t zero64 = 0;
+    static const double zerof = 0.0;
+    static const int32_t zero32 = 0;
+    d.edge_src = net.edge_src.empty() ? &zero64 : net.edge_src.data();
+    d.edge_dst = net.edge_dst.empty() ? &zero64 : net.edge_dst.data();
+    d.edge_weight = net.edge_weight.empty() ? &zerof : net.edge_weight.data();
+    d.edge_synapse_hw = net.edge_synapse_hw.empty() ? &zero32 : net.edge_synapse_hw.data();
+    if (!net.edge_delay.empty() && net.edge_delay.size() < net.edge_src.size()) net.edge_delay.resize(net.edge_src.size(), -1);
+    d.edge_delay = net.edge_delay.empty() ? nullptr : net.edge_delay.data();
+    d.edge_attr_ptr = nullptr;
+    // strings last: everything above interns
+    b.strings = net.strings;
+    for (const std::string &s : b.strings) b.string_ptrs.push_back(s.c_str());
+    if (b.string_ptrs.empty()) b.string_ptrs.push_back("");
+    d.n_strings = static_cast<int32_t>(b.strings.size());
+    d.strings = b.string_ptrs.data();
+    return out;
+}
+
+// ------------------------------------------------------------------------------ YAML front-ends
+namespace
+{
+const YamlNode &req(const YamlNode &n, const char *key, const char *what)
+{
+    const YamlNode *c = n.find(key);
+    if (!c) throw std::invalid_argument(std::string("No ") + key + " defined in " + what + " (line " + std::to_string(n.line) + ")");
+    return *c;
+}
+double req_double(const YamlNode &n, const char *key)
+{
+    const YamlNode &c = req(n, key, "attributes");
+    char *e = nullptr;
+    const double v = std::strtod(c.scalar.c_str(), &e);
+    if (!c.is_scalar() || e == c.scalar.c_str()) throw std::invalid_argument(std::string("field '") + key + "' is not a number");
+    return v;
+}
+// a node that is either a sequence of entries or a single entry
+std::vector<const YamlNode *> seq_or_single(const YamlNode &n)
+{
+    std::vector<const YamlNode *> v;
+    if (n.is_seq())
+        for (const YamlNode &c : n.seq) v.push_back(&c);
+    else v.push_back(&n);
+    return v;
+}
+// description_parse_model_attributes_yaml (src/yaml_common.cpp:99-137): across list entries the first definition wins
+void model_attributes(const YamlNode &n, std::vector<std::pair<std::string, const YamlNode *>> &out)
+{
+    if (n.is_seq())
+    {
+        for (const YamlNode &c : n.seq) model_attributes(c, out);
+    }
+    else if (n.is_map())
+    {
+        for (const auto &kv : n.map)
+        {
+            if (kSkipKeys.count(kv.first)) continue;
+            bool seen = false;
+            for (const auto &o : out) seen |= (o.first == kv.first);
+            if (!seen) out.emplace_back(kv.first, &kv.second);
+        }
+    }
+    else if (n.kind != YamlNode::Null)
+    {
+        throw std::invalid_argument("Error: Model attributes must be an ordered map or mapping of named attributes.\n");
+    }
+}
+bool typed_attr(const YamlNode &n, AttrValue &out)
+{
+    if (n.is_scalar())
+    {
+        out = scalar_attr(n.scalar);
+        return true;
+    }
+    if (n.is_seq())
+    {
+        std::vector<double> v;
+        for (const YamlNode &c : n.seq)
+        {
+            if (!c.is_scalar()) return false;
+            const AttrValue a = scalar_attr(c.scalar);
+            if (a.type == SANAFE_ATTR_STRING) return false;
+            v.push_back(a.num);
+        }
+        out = AttrValue::List(std::move(v));
+        return true;
+    }
+    return false; // nested maps are not model attributes here
+}
+
+void parse_core(Architecture &arch, int tile_id, const YamlNode &node, const std::string &name,
+        std::map<const YamlNode *, std::shared_ptr<CoreTemplate>> &shared)
+{
+    const YamlNode &ca = req(node, "attributes", "core");
+    const YamlNode *inside = ca.find("buffer_inside_unit");
+    const YamlNode *lg = ca.find("log_energy");
+    auto it = shared.find(&node);
+    CoreConfig &core = arch.create_core(name, tile_id,
+            parse_buffer_position(req(ca, "buffer_position", "core attributes").scalar, inside && as_bool_text(inside->scalar)),
+            std::stoll(req(ca, "max_neurons_supported", "core attributes").scalar), lg && as_bool_text(lg->scalar),
+            it == shared.end() ? nullptr : it->second);
+    if (it != shared.end()) return;
+    shared[&node] = core.tmpl;
+    for (const char *section : {"axon_in", "synapse", "dendrite", "soma", "axon_out"}) // src/yaml_arch.cpp:260-266
+    {
+        const YamlNode *sn = node.find(section);
+        if (!sn || sn->kind == YamlNode::Null) throw std::invalid_argument(std::string("No ") + section + " section defined");
+        for (const YamlNode *unit : seq_or_single(*sn))
+        {
+            const std::string uname = req(*unit, "name", section).scalar;
+            const bool ranged = uname.find("..") != std::string::npos;
+            const auto range = ranged ? parse_range(uname) : std::make_pair<int64_t, int64_t>(0, 0);
+            static const YamlNode empty_map = [] {
+                YamlNode n;
+                n.kind = YamlNode::Map;
+                return n;
+            }();
+            const YamlNode *uap = unit->find("attributes");
+            const YamlNode &ua = (uap && uap->kind != YamlNode::Null) ? *uap : empty_map;
+            for (int64_t i = range.first; i <= range.second; i++)
+            {
+                const std::string n = ranged ? base_name(uname) + "[" + std::to_string(i) + "]" : uname;
+                const std::string sec(section);
+                if (sec == "axon_in") core.create_axon_in(n, req_double(ua, "energy_message_in"), req_double(ua, "latency_message_in"));
+                else if (sec == "axon_out") core.create_axon_out(n, req_double(ua, "energy_message_out"), req_double(ua, "latency_message_out"));
+                else
+                {
+                    std::vector<std::pair<std::string, const YamlNode *>> raw;
+                    model_attributes(ua, raw);
+                    std::map<std::string, AttrValue> attrs;
+                    for (const auto &kv : raw)
+                    {
+                        AttrValue a;
+                        if (typed_attr(*kv.second, a)) attrs[kv.first] = a;
+                    }
+                    const YamlNode *pl = ua.find("plugin");
+                    const YamlNode *le = ua.find("log_energy"), *ll = ua.find("log_latency"), *ue = ua.find("update_every_timestep");
+                    core.create_unit(sec, n, req(ua, "model", "unit attributes").scalar, attrs, pl ? pl->scalar : "",
+                            le && as_bool_text(le->scalar), ll && as_bool_text(ll->scalar), ue && as_bool_text(ue->scalar));
+                }
+            }
+        }
+    }
+}
+} // namespace
+
+Architecture load_arch(const std::string &path)
+{
+    const YamlNode top = yaml_parse_file(path);
+    const YamlNode *an = top.find("architecture");
+    if (!an) throw std::invalid_argument("No architecture section defined");
+    const YamlNode *nm = an->find("name");
+    const std::string name = nm ? nm->scalar : "";
+    if (name.find('[') != std::string::npos) throw std::invalid_argument("Multiple architectures not supported");
+    const YamlNode &att = req(*an, "attributes", "architecture");
+    const YamlNode *sm = att.find("sync_model");
+    const std::string model = sm ? sm->scalar : "fixed";
+    std::map<int64_t, double> table;
+    const YamlNode *ls = att.find("latency_sync");
+    if (model == "fixed") table[0] = ls ? std::strtod(ls->scalar.c_str(), nullptr) : 0.0;
+    else if (model == "table")
+    {
+        if (!ls) throw std::invalid_argument("Attribute 'latency_sync' required when 'table' synchronization model is chosen.");
+        if (ls->is_seq())
+            for (size_t i = 0; i < ls->seq.size(); i++) table[static_cast<int64_t>(i)] = std::strtod(ls->seq[i].scalar.c_str(), nullptr);
+        else if (ls->is_map())
+            for (const auto &kv : ls->map) table[std::stoll(kv.first)] = std::strtod(kv.second.scalar.c_str(), nullptr);
+        else table[0] = std::strtod(ls->scalar.c_str(), nullptr);
+    }
+    else throw std::invalid_argument("Unknown sync_model: " + model);
+    Architecture arch(name, std::stoi(req(att, "width", "architecture attributes").scalar),
+            std::stoi(req(att, "height", "architecture attributes").scalar),
+            std::stoi(req(att, "link_buffer_size", "architecture attributes").scalar), table);
+    const YamlNode *tiles = an->find("tile");
+    if (!tiles) throw std::invalid_argument("No tile section defined");
+    std::map<const YamlNode *, std::shared_ptr<CoreTemplate>> shared;
+    for (const YamlNode *tn : seq_or_single(*tiles))
+    {
+        const std::string tname = req(*tn, "name", "tile").scalar;
+        const auto range = tname.find("..") != std::string::npos ? parse_range(tname) : std::make_pair<int64_t, int64_t>(0, 0);
+        const YamlNode &ta = req(*tn, "attributes", "tile");
+        for (int64_t t = range.first; t <= range.second; t++)
+        {
+            const std::array<double, 4> he = {req_double(ta, "energy_north_hop"), req_double(ta, "energy_east_hop"),
+                    req_double(ta, "energy_south_hop"), req_double(ta, "energy_west_hop")};
+            const std::array<double, 4> hl = {req_double(ta, "latency_north_hop"), req_double(ta, "latency_east_hop"),
+                    req_double(ta, "latency_south_hop"), req_double(ta, "latency_west_hop")};
+            const YamlNode *lg = ta.find("log_energy");
+            const int tile_id = arch.create_tile(base_name(tname) + "[" + std::to_string(t) + "]", he, hl, lg && as_bool_text(lg->scalar)).id;
+            const YamlNode *cs = tn->find("core");
+            if (!cs) throw std::invalid_argument("No core section defined");
+            for (const YamlNode *cn : seq_or_single(*cs))
+            {
+                const std::string cname = req(*cn, "name", "core").scalar;
+                const auto cr = cname.find("..") != std::string::npos ? parse_range(cname) : std::make_pair<int64_t, int64_t>(0, 0);
+                for (int64_t c = cr.first; c <= cr.second; c++)
+                    parse_core(arch, tile_id, *cn, base_name(cname) + "[" + std::to_string(c) + "]", shared);
+            }
+        }
+    }
+    return arch;
+}
+
+namespace
+{
+struct NeuronCfg // NeuronConfiguration (src/network.hpp:26-34)
+{
+    std::optional<std::string> soma, synapse, dendrite;
+    std::optional<bool> log_spikes, log_potential;
+    std::map<std::string, std::pair<AttrValue, int>> attrs;
+};
+void neuron_attributes(const YamlNode &n, NeuronCfg &cfg) // yaml_parse_neuron_attributes, src/yaml_snn.cpp:331-394
+{
+    if (n.is_seq())
+    {
+        for (const YamlNode &c : n.seq) neuron_attributes(c, cfg);
+        return;
+    }
+    if (!n.is_map()) return;
+    if (const YamlNode *c = n.find("log_potential")) cfg.log_potential = as_bool_text(c->scalar);
+    if (const YamlNode *c = n.find("log_spikes")) cfg.log_spikes = as_bool_text(c->scalar);
+    if (const YamlNode *c = n.find("synapse_hw_name")) cfg.synapse = c->scalar;
+    if (const YamlNode *c = n.find("dendrite_hw_name")) cfg.dendrite = c->scalar;
+    if (const YamlNode *c = n.find("soma_hw_name")) cfg.soma = c->scalar;
+    auto take = [&](const YamlNode &src, int fwd) {
+        std::vector<std::pair<std::string, const YamlNode *>> raw;
+        model_attributes(src, raw);
+        for (const auto &kv : raw)
+        {
+            AttrValue a;
+            if (!typed_attr(*kv.second, a)) throw std::invalid_argument("nested attribute values are not supported (" + kv.first + ")");
+            cfg.attrs[kv.first] = {a, fwd};
+        }
+    };
+    take(n, 7);
+    if (const YamlNode *c = n.find("dendrite"))
+        if (c->is_map() || c->is_seq()) take(*c, SANAFE_FWD_DENDRITE);
+    if (const YamlNode *c = n.find("soma"))
+        if (c->is_map() || c->is_seq()) take(*c, SANAFE_FWD_SOMA);
+}
+int64_t count_neurons(const YamlNode &neurons) // description_count_neurons, src/yaml_snn.cpp:226-278
+{
+    if (!neurons.is_seq()) throw std::invalid_argument("Invalid neuron format, should be list");
+    int64_t n = 0;
+    auto add = [&](const std::string &id) {
+        if (id.find("..") != std::string::npos)
+        {
+            const auto r = parse_range(id);
+            n += r.second - r.first + 1;
+        }
+        else n++;
+    };
+    for (const YamlNode &e : neurons.seq)
+    {
+        if (e.is_map())
+            for (const auto &kv : e.map) add(kv.first);
+        else if (e.is_seq())
+            for (const YamlNode &m : e.seq)
+                for (const auto &kv : m.map) add(kv.first);
+        else add(e.scalar);
+    }
+    return n;
+}
+void edge_attr_lists(const YamlNode &attrs, std::map<std::string, const YamlNode *> &out)
+{
+    std::vector<std::pair<std::string, const YamlNode *>> raw;
+    model_attributes(attrs, raw);
+    for (const auto &kv : raw) out[kv.first] = kv.second;
+    for (const char *sect : {"synapse", "dendrite"}) // description_parse_edge_attributes, src/yaml_snn.cpp:831-878
+        for (const YamlNode *e : seq_or_single(attrs))
+            if (e->is_map())
+                if (const YamlNode *sub = e->find(sect))
+                {
+                    std::vector<std::pair<std::string, const YamlNode *>> r2;
+                    model_attributes(*sub, r2);
+                    for (const auto &kv : r2) out[kv.first] = kv.second;
+                }
+}
+std::vector<double> number_list(const YamlNode &n, const std::string &key)
+{
+    if (!n.is_seq()) throw std::invalid_argument("Attribute must be a list with an entry for each connection (name: " + key + ")");
+    std::vector<double> v;
+    v.reserve(n.seq.size());
+    for (const YamlNode &c : n.seq) v.push_back(scalar_attr(c.scalar).num);
+    return v;
+}
+void parse_edge(SpikingNetwork &net, const std::string &desc, const YamlNode &attrs)
+{
+    const size_t arrow = desc.find("->");
+    if (arrow == std::string::npos) throw std::invalid_argument("Edge is not formatted correctly: " + desc);
+    const std::string sp = trim(desc.substr(0, arrow)), tp = trim(desc.substr(arrow + 2));
+    const size_t sd = sp.find('.'), td = tp.find('.');
+    if ((sd != std::string::npos) != (td != std::string::npos)) throw std::invalid_argument("No target neuron defined in edge:" + desc);
+    const std::string sg = sp.substr(0, sd), tg = tp.substr(0, td);
+    if (!net.groups.count(sg)) throw std::invalid_argument("Invalid source neuron group:" + sg);
+    if (!net.groups.count(tg)) throw std::invalid_argument("Invalid target neuron group:" + tg);
+    NeuronGroup &src = *net.groups[sg], &dst = *net.groups[tg];
+    std::map<std::string, const YamlNode *> ea;
+    edge_attr_lists(attrs, ea);
+    if (sd != std::string::npos)
+    {
+        const int64_t so = std::stoll(sp.substr(sd + 1)), to = std::stoll(tp.substr(td + 1));
+        if (so >= src.count) throw std::invalid_argument("Invalid source neuron id: " + sp);
+        if (to >= dst.count) throw std::invalid_argument("Invalid target neuron id: " + tp);
+        double w = 0.0;
+        int delay = -1;
+        for (const auto &kv : ea)
+        {
+            AttrValue a;
+            if (!typed_attr(*kv.second, a)) continue;
+            if (kv.first == "w" || kv.first == "weight") w = a.num;
+            else if (kv.first == "d" || kv.first == "delay") delay = static_cast<int>(a.num);
+        }
+        net.add_edge(src.base + so, dst.base + to, w, delay, dst.synapse_hw[to]);
+        return;
+    }
+    std::string type;
+    if (ea.count("type")) type = ea["type"]->scalar;
+    if (type.empty()) throw std::invalid_argument("No hyperedge type specified.");
+    std::vector<double> weight;
+    std::vector<int> delay;
+    std::map<std::string, int> conv;
+    std::vector<std::pair<int64_t, int64_t>> pairs;
+    for (const auto &kv : ea)
+    {
+        const std::string &k = kv.first;
+        if (k == "type") continue;
+        static const std::set<std::string> conv_keys = {"input_height", "input_width", "input_channels", "kernel_width", "kernel_height",
+                "kernel_count", "stride_width", "stride_height"};
+        if (type == "conv2d" && conv_keys.count(k)) conv[k] = std::stoi(kv.second->scalar);
+        else if (type == "sparse" && k == "source_target_pairs")
+        {
+            if (!kv.second->is_seq()) throw std::invalid_argument("Source/target pair must be a list of pairs");
+            for (const YamlNode &p : kv.second->seq)
+            {
+                if (!p.is_seq() || p.seq.size() != 2) throw std::invalid_argument("Invalid source/target format: expected [source, target]");
+                pairs.emplace_back(std::stoll(p.seq[0].scalar), std::stoll(p.seq[1].scalar));
+            }
+        }
+        else if (k == "w" || k == "weight") weight = number_list(*kv.second, k);
+        else if (k == "d" || k == "delay")
+        {
+            const std::vector<double> dl = number_list(*kv.second, k);
+            delay.assign(dl.begin(), dl.end());
+        }
+        else
+        {
+            (void) number_list(*kv.second, k); // must be a list; other per-edge attributes are ignored by the built-in units
+        }
+    }
+    auto cv = [&](const char *k, int dflt) { return conv.count(k) ? conv[k] : dflt; };
+    if (type == "conv2d")
+        src.connect_neurons_conv2d(dst, weight, delay, cv("input_width", 0), cv("input_height", 0), cv("input_channels", 0),
+                cv("kernel_width", 0), cv("kernel_height", 0), cv("kernel_count", 1), cv("stride_width", 1), cv("stride_height", 1));
+    else if (type == "dense") src.connect_neurons_dense(dst, weight, delay);
+    else if (type == "sparse") src.connect_neurons_sparse(dst, pairs, weight, delay);
+    else throw std::invalid_argument("Invalid hyperedge type: " + type);
+}
+void parse_mapping(SpikingNetwork &net, Architecture &arch, const std::string &address, const YamlNode &info)
+{
+    const size_t dot = address.find('.');
+    const std::string gname = address.substr(0, dot);
+    if (!net.groups.count(gname)) throw std::invalid_argument("While mapping, group not found (" + gname + ")");
+    NeuronGroup &g = *net.groups[gname];
+    int64_t lo = 0, hi = g.count - 1;
+    if (dot != std::string::npos)
+    {
+        const std::string ns = address.substr(dot + 1);
+        if (ns.find("..") != std::string::npos) std::tie(lo, hi) = parse_range(ns);
+        else lo = hi = std::stoll(ns);
+    }
+    if (hi >= g.count) throw std::invalid_argument("Invalid neuron id: " + gname + "." + std::to_string(hi));
+    std::map<std::string, std::string> fields;
+    for (const YamlNode *e : seq_or_single(info))
+    {
+        if (!e->is_map()) throw std::invalid_argument("Expected attributes to be map");
+        for (const auto &kv : e->map) fields[kv.first] = kv.second.scalar;
+    }
+    if (fields.count("synapse")) std::fill(g.synapse_hw.begin() + lo, g.synapse_hw.begin() + hi + 1, net.intern(fields["synapse"]));
+    if (fields.count("dendrite")) std::fill(g.dendrite_hw.begin() + lo, g.dendrite_hw.begin() + hi + 1, net.intern(fields["dendrite"]));
+    if (fields.count("soma")) std::fill(g.soma_hw.begin() + lo, g.soma_hw.begin() + hi + 1, net.intern(fields["soma"]));
+    const std::string ca = fields["core"];
+    const size_t cd = ca.find('.');
+    const int64_t t = std::stoll(ca.substr(0, cd)), c = std::stoll(ca.substr(cd + 1));
+    if (t >= static_cast<int64_t>(arch.tiles.size())) throw std::invalid_argument("Tile ID >= tile count");
+    if (c >= static_cast<int64_t>(arch.tiles[t].cores.size())) throw std::invalid_argument("Core ID >= core count");
+    g.map_to_core(arch.cores[arch.tiles[t].cores[c]], lo, hi + 1);
+}
+} // namespace
+
+std::unique_ptr<SpikingNetwork> load_net(const std::string &path, Architecture &arch)
+{
+    const YamlNode top = yaml_parse_file(path);
+    const YamlNode *nn = top.find("network");
+    if (!nn) throw std::invalid_argument("No network section defined");
+    const YamlNode *nm = nn->find("name");
+    auto net = std::make_unique<SpikingNetwork>(nm ? nm->scalar : "");
+    const YamlNode *groups = nn->find("groups");
+    if (!groups) throw std::invalid_argument("No neuron groups specified");
+    const YamlNode *edges = nn->find("edges");
+    if (!edges) throw std::invalid_argument("No edges section specified");
+    if (!groups->is_seq()) throw std::invalid_argument("Neuron group section does not define a list of groups");
+    for (const YamlNode &g : groups->seq)
+    {
+        const std::string gname = req(g, "name", "group").scalar;
+        const YamlNode *neurons = g.find("neurons");
+        if (!neurons) throw std::invalid_argument("No neurons section defined.");
+        NeuronCfg dflt;
+        if (const YamlNode *ga = g.find("attributes")) neuron_attributes(*ga, dflt);
+        NeuronGroup &grp = net->create_neuron_group(gname, count_neurons(*neurons), dflt.attrs, dflt.synapse.value_or(""),
+                dflt.dendrite.value_or(""), dflt.log_potential.value_or(false), dflt.log_spikes.value_or(false), dflt.soma.value_or(""));
+        for (const YamlNode &entry : neurons->seq)
+        {
+            auto handle = [&](const std::string &id, const YamlNode &attrs) {
+                NeuronCfg cfg = dflt;
+                neuron_attributes(attrs, cfg);
+                int64_t lo = 0, hi = 0;
+                if (id.find("..") != std::string::npos) std::tie(lo, hi) = parse_range(id);
+                else lo = hi = std::stoll(id);
+                if (hi >= grp.count) throw std::out_of_range("neuron id out of range: " + gname + "." + id);
+                grp.apply_config(lo, hi + 1, cfg.soma, cfg.synapse, cfg.dendrite, cfg.log_spikes, cfg.log_potential, cfg.attrs);
+            };
+            if (entry.is_map())
+                for (const auto &kv : entry.map) handle(kv.first, kv.second);
+            else if (entry.is_seq())
+                for (const YamlNode &m : entry.seq)
+                    for (const auto &kv : m.map) handle(kv.first, kv.second);
+        }
+    }
+    if (edges->is_seq())
+        for (const YamlNode &entry : edges->seq)
+            for (const auto &kv : entry.map) parse_edge(*net, kv.first, kv.second);
+    else if (edges->kind != YamlNode::Null) throw std::invalid_argument("Edges section does not define a list of edges");
+    if (const YamlNode *maps = top.find("mappings"))
+    {
+        if (maps->kind != YamlNode::Null)
+        {
+            if (!maps->is_seq()) throw std::invalid_argument("Mappings must be given as a sequence / list.");
+            for (const YamlNode &m : maps->seq)
+            {
+                if (!m.is_map() || m.map.size() != 1) throw std::invalid_argument("Should be one entry per mapping");
+                parse_mapping(*net, arch, m.map[0].first, m.map[0].second);
+            }
+        }
+    }
+    return net;
+}
+} // namespace sanafe_amd

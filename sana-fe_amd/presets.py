@@ -8,6 +8,14 @@ reference YAML whenever the reference is present.
 """
 from . import description as D
 
+
+def _api(api):
+    """The description API to build with: the C++/PyBind11 module by default, or the Python twin."""
+    if api is not None:
+        return api
+    from .chip import cpp
+    return cpp if cpp is not None else D
+
 # arch/loihi.yaml:19-27, arch/loihi_large.yaml:12-20 -- Loihi hop costs (Davies et al. 2018)
 _LOIHI_TILE = dict(energy_north_hop=4.2e-12, latency_north_hop=6.5e-9, energy_east_hop=3.0e-12, latency_east_hop=4.1e-9,
                    energy_south_hop=4.2e-12, latency_south_hop=6.5e-9, energy_west_hop=3.0e-12, latency_west_hop=4.1e-9)
@@ -15,15 +23,15 @@ _LOIHI_SYNC = {1: 0.6e-6, 2: 1.0e-6, 4: 1.4e-6, 29: 1.8e-6}  # arch/loihi.yaml:1
 
 
 def _f(**kw):
-    return {k: (D.ATTR_DOUBLE, float(v), None, None) for k, v in kw.items()}
+    return {k: float(v) for k, v in kw.items()}
 
 
 def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared, n_inputs=1024):
     core = arch.create_core("loihi_core[%d]" % idx, tile_id, buffer_position, buffer_inside_unit, 1024,
-                            template=shared.get("t"))
-    if "t" in shared:
+                            share_units_with=shared.get("c"))
+    if "c" in shared:
         return core
-    shared["t"] = core.template
+    shared["c"] = core
     core.create_axon_in("loihi_in", 0.0e-12, 16.0e-9)
     # unit sections are always visited synapse, dendrite, soma (src/yaml_arch.cpp:260-266);
     # inside a section the file order is kept, which differs between loihi.yaml and loihi_large.yaml
@@ -43,9 +51,9 @@ def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared,
     return core
 
 
-def loihi(n_inputs=1024):
+def loihi(n_inputs=1024, api=None):
     """arch/loihi.yaml: 8x4 mesh, 32 tiles x 4 cores, buffer before soma."""
-    arch = D.Architecture("loihi_chip", 8, 4, 16, _LOIHI_SYNC)
+    arch = _api(api).Architecture("loihi_chip", 8, 4, 16, _LOIHI_SYNC)
     shared = {}
     for t in range(32):
         tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
@@ -54,9 +62,9 @@ def loihi(n_inputs=1024):
     return arch
 
 
-def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128):
+def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128, api=None):
     """arch/loihi_large.yaml: 256x128 mesh, 1024 tiles x 4 cores, buffer inside the dendrite unit."""
-    arch = D.Architecture("loihi_chip", width, height, 16, _LOIHI_SYNC)
+    arch = _api(api).Architecture("loihi_chip", width, height, 16, _LOIHI_SYNC)
     shared = {}
     for t in range(n_tiles):
         tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
@@ -65,16 +73,16 @@ def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128):
     return arch
 
 
-def truenorth(n_tiles=4096, width=64, height=64):
+def truenorth(n_tiles=4096, width=64, height=64, api=None):
     """arch/truenorth.yaml: 64x64 mesh, one 256-neuron core per tile, all costs zero."""
-    arch = D.Architecture("truenorth_chip", width, height, 1, {0: 0.0})
-    tmpl = None
+    arch = _api(api).Architecture("truenorth_chip", width, height, 1, {0: 0.0})
+    first = None
     for t in range(n_tiles):
         tile = arch.create_tile("truenorth_tile[%d]" % t)
-        core = arch.create_core("truenorth_core[0]", tile.id, "soma", False, 256, template=tmpl)
-        if tmpl is not None:
+        core = arch.create_core("truenorth_core[0]", tile.id, "soma", False, 256, share_units_with=first)
+        if first is not None:
             continue
-        tmpl = core.template
+        first = core
         core.create_axon_in("core_in", 0.0, 0.0)
         core.create_synapse("core_synapses", "current_based", _f(energy_process_spike=0.0, latency_process_spike=0.0))
         core.create_dendrite("core_dendrites", "accumulator", _f(energy_update=0.0, latency_update=0.0))
@@ -85,19 +93,19 @@ def truenorth(n_tiles=4096, width=64, height=64):
     return arch
 
 
-def example_chip():
+def example_chip(api=None):
     """arch/example_chip.yaml: 2 tiles x 4 cores demo chip."""
-    arch = D.Architecture("demo", 2, 1, 4, {0: 0.0})
-    tmpl = None
+    arch = _api(api).Architecture("demo", 2, 1, 4, {0: 0.0})
+    first = None
     for t in range(2):
         tile = arch.create_tile("demo_tile[%d]" % t, energy_north_hop=2.0e-12, latency_north_hop=1.4e-9,
                                 energy_east_hop=2.5e-12, latency_east_hop=1.2e-9, energy_south_hop=2.0e-12,
                                 latency_south_hop=1.5e-9, energy_west_hop=1.8e-12, latency_west_hop=2.0e-9)
         for c in range(4):
-            core = arch.create_core("demo_core[%d]" % c, tile.id, "soma", False, 100, template=tmpl)
-            if tmpl is not None:
+            core = arch.create_core("demo_core[%d]" % c, tile.id, "soma", False, 100, share_units_with=first)
+            if first is not None:
                 continue
-            tmpl = core.template
+            first = core
             core.create_axon_in("demo_in", 0.0, 0.0)
             core.create_synapse("demo_synapse", "current_based", _f(energy_process_spike=20.0e-12, latency_process_spike=3.0e-9))
             core.create_dendrite("demo_dendrite", "accumulator", _f(energy_update=0.0, latency_update=0.0),
@@ -116,7 +124,8 @@ def example_chip():
 
 
 def example_snn(arch):
-    """snn/example_snn.yaml restated through the API (4 neurons, 5 synapses)."""
+    """snn/example_snn.yaml restated with the Python twin's typed setters, so that the description is
+    identical to what the YAML front-end reads (4 neurons, 5 synapses)."""
     net = D.Network("example_snn")
     gin = net.create_neuron_group("in", 2, log_spikes=True)
     gin.apply_config(0, 1, log_spikes=False)
@@ -128,7 +137,7 @@ def example_snn(arch):
     import numpy as np
     net._add_edges(np.array([gout.base + 1]), np.array([gout.base + 1]), np.array([-4.0]))
     gin.connect_neurons_dense(gout, {"weight": np.array([-1.0, 2.0, 1.0, 3.0])}, narrow_float=False)
-    cores = arch.tiles[0].cores
+    cores = arch.tile_cores(0)
     gin.apply_config(0, 1, soma_hw_name="demo_input")
     gin.map_to_core(cores[0], 0, 1)
     gin.apply_config(1, 2, soma_hw_name="demo_input")
@@ -137,16 +146,14 @@ def example_snn(arch):
     return net
 
 
-def loihi_with_plugin_somas(k, plugin_path, model="hodgkin_huxley", n_inputs=4):
+def loihi_with_plugin_somas(k, plugin_path, model="hodgkin_huxley", n_inputs=4, api=None):
     """Config C5: the Loihi architecture plus `k` plugin soma units `hh[0..k-1]` on every core
     (one neuron per unit instance, like plugins/hodgkin_huxley.cpp), with the soma default costs the
     plugin does not simulate itself (src/pipeline.hpp:698-713)."""
-    arch = loihi(n_inputs=n_inputs)
-    tmpl = arch.cores()[0].template
+    arch = loihi(n_inputs=n_inputs, api=api)
     core = arch.cores()[0]
     costs = _f(energy_access_neuron=51.2e-12, latency_access_neuron=6.0e-9, energy_update_neuron=21.6e-12,
                latency_update_neuron=3.7e-9, energy_spike_out=69.3e-12, latency_spike_out=30.0e-9)
     for i in range(k):
         core.create_soma("hh[%d]" % i, model, dict(costs), plugin=plugin_path)
-    assert core.template is tmpl
     return arch

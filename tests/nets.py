@@ -13,7 +13,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def example(S):
     """Config C1: arch/example_chip.yaml + snn/example_snn.yaml."""
-    arch = S.presets.example_chip()
+    arch = S.presets.example_chip(api=S.description)
     return arch, S.presets.example_snn(arch)
 
 
@@ -21,10 +21,10 @@ def tutorial5_dvs(S, core_counts=(1, 4, 16, 16, 4, 1)):
     """The network tutorial/tutorial_5_dvs.ipynb builds with sanafe.layers (sanafe/layers.py:85-330)
     from sanafe/examples/dvs_challenge.npz on the Loihi architecture; the notebook asserts
     results["neurons_fired"] == 365277 after chip.sim(1000)."""
-    arch = S.presets.loihi()
+    arch = S.presets.loihi(api=S.description)
     d = np.load(os.path.join(GOLDEN, "dvs_challenge.npz"))
     th = d["thresholds"]
-    net = S.Network()
+    net = S.description.Network()
     g0 = net.create_neuron_group("input_0", 32 * 32, {"threshold": th[0]})
     layers = [(g0, 32, 32, 1)]
     for i, (name, stride) in enumerate((("conv1", 2), ("conv2", 1), ("conv3", 1), ("conv4", 1))):
@@ -55,10 +55,10 @@ def tutorial5_dvs(S, core_counts=(1, 4, 16, 16, 4, 1)):
 def dvs_yaml(S):
     """Config C2: arch/loihi.yaml + snn/dvs.yaml, rebuilt from tests/golden/dvs_yaml.npz."""
     D, Y = S.description, S.yaml_io
-    arch = S.presets.loihi()
+    arch = S.presets.loihi(api=S.description)
     f = np.load(os.path.join(GOLDEN, "dvs_yaml.npz"))
     meta = json.loads(bytes(f["meta"]).decode())
-    net = S.Network(meta["name"])
+    net = S.description.Network(meta["name"])
     for g in meta["groups"]:
         a = dict(g["attributes"])
         typed = {}
@@ -98,17 +98,17 @@ def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=
     rng = np.random.default_rng(seed)
     if arch_kind == "large":
         w = max(1, int(np.ceil(np.sqrt(n_tiles))))
-        arch = S.presets.loihi_large(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), n_inputs=4)
+        arch = S.presets.loihi_large(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), n_inputs=4, api=S.description)
         dend = "loihi_dendrites_delay"  # quirk 1: plain accumulator loses all input inside the dendrite
     else:
-        arch = S.presets.loihi(n_inputs=4)
+        arch = S.presets.loihi(n_inputs=4, api=S.description)
         arch.tiles = arch.tiles[:n_tiles]
         arch._cores = arch._cores[:4 * n_tiles]
         dend = "loihi_dendrites"
     cores = arch.cores()
     cores_used = cores_used or len(cores)
     n = cores_used * neurons_per_core
-    net = S.Network("random")
+    net = S.description.Network("random")
     attrs = {"threshold": 64, "reset": 0, "force_update": True}
     if refractory:
         attrs["refractory_delay"] = 2
@@ -139,10 +139,10 @@ def truenorth_net(S, n_tiles=16, neurons_per_core=256, remote_fraction=0.8, seed
     80 % of them to another core."""
     rng = np.random.default_rng(seed)
     w = max(1, int(np.ceil(np.sqrt(n_tiles))))
-    arch = S.presets.truenorth(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)))
+    arch = S.presets.truenorth(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), api=S.description)
     cores = arch.cores()
     n = n_tiles * neurons_per_core
-    net = S.Network("tn")
+    net = S.description.Network("tn")
     g = net.create_neuron_group("tn", n, {"threshold": 0, "reset": -1, "leak": 0, "force_update": True},
                                 "core_synapses", "core_dendrites", False, True, "core_soma")
     src = np.arange(n, dtype=np.int64)
@@ -166,9 +166,9 @@ def hodgkin_huxley(S, k=12, lif=24, seed=4):
     h=0.5961, a distinct `current` each) driving a small LIF population on the Loihi architecture."""
     D = S.description
     rng = np.random.default_rng(seed)
-    arch = S.presets.loihi_with_plugin_somas(k, hh_plugin_path())
+    arch = S.presets.loihi_with_plugin_somas(k, hh_plugin_path(), api=S.description)
     cores = arch.cores()
-    net = S.Network("hh")
+    net = S.description.Network("hh")
     g = net.create_neuron_group("hh", k, {"m": 0.0529, "n": 0.3177, "h": 0.5961}, "loihi_sparse_synapse", "", True, True)
     for i in range(k):
         g.apply_config(i, i + 1, soma_hw_name="hh[%d]" % i,

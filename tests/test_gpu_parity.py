@@ -230,3 +230,51 @@ def test_hodgkin_huxley_plugin_c5(S, timing):
         assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-6, atol=0), t
         fired_any += a["neurons_fired"]
     assert fired_any > 0
+
+
+def test_cpp_frontend_yaml_on_gpu(S):
+    """The product front-end end to end: C++ YAML reader -> C++ description -> mapper -> HIP, against the oracle
+    fed by the independent Python twin (PyYAML) reading the same files."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    arch = S.load_arch(os.path.join(g, "mini_arch.yaml"))
+    net = S.load_net(os.path.join(g, "mini_snn.yaml"), arch)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    t_arch = S.yaml_io.load_arch(os.path.join(g, "mini_arch.yaml"))
+    t_net = S.yaml_io.load_net(os.path.join(g, "mini_snn.yaml"), t_arch)
+    orc = OracleChip(S.to_desc(t_arch, t_net))
+    fired = 0
+    for t in range(60):
+        a, b = chip.run(1, "detailed", record=True), orc.step("detailed")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka)
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        assert np.array_equal(chip.status(), orc.status()), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
+        ma, mb = chip.step_messages(0), orc.messages()
+        for name in ma.dtype.names:
+            assert np.array_equal(ma[name], mb[name]), (t, name)
+        fired += a["neurons_fired"]
+    assert fired > 20
+
+
+def test_cpp_frontend_sim_result_dict(S):
+    """`sim()` result keys and trace shapes of the reference's Python API (src/pymodule.cpp:268-288, 692-705)."""
+    import os
+    g = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    arch = S.load_arch(os.path.join(g, "mini_arch.yaml"))
+    net = S.load_net(os.path.join(g, "mini_snn.yaml"), arch)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    r = chip.sim(10, timing_model="simple", spike_trace=True, potential_trace=True, perf_trace=True)
+    assert set(r) == {"timestep_start", "timesteps_executed", "energy", "sim_time", "spikes", "packets_sent", "neurons_updated",
+                      "neurons_fired", "spike_trace", "potential_trace", "neuron_trace", "perf_trace", "message_trace"}
+    assert set(r["energy"]) == {"total", "synapse", "dendrite", "soma", "network"}
+    assert (r["timestep_start"], r["timesteps_executed"]) == (1, 10)
+    assert len(r["spike_trace"]) == 10 and len(r["potential_trace"]) == 10 and len(r["perf_trace"]["fired"]) == 10
+    assert len(r["potential_trace"][0]) == 16 + 3  # grid + out log potentials
+    r2 = chip.sim(5)  # cumulative: continues at step 11 with the default detailed model
+    assert r2["timestep_start"] == 11 and r2["sim_time"] > 0
+    assert chip.get_power() > 0

@@ -61,7 +61,7 @@ def test_float_weights_within_tolerance(S):
 
 
 def test_unsupported_configs_fail_loudly(S):
-    arch = S.presets.example_chip()
+    arch = S.presets.example_chip(api=S.description)
     for c in arch.cores():
         c.buffer_position = S.description.BUF_BEFORE_DENDRITE
     net = S.presets.example_snn(arch)

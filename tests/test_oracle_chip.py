@@ -73,8 +73,8 @@ def test_dvs_yaml_fixture_matches_reference_file(S):
     if not have_reference():
         pytest.skip("reference not present")
     arch, net = nets.dvs_yaml(S)
-    arch2 = S.load_arch(REFERENCE + "/arch/loihi.yaml")
-    net2 = S.load_net(REFERENCE + "/snn/dvs.yaml", arch2)
+    arch2 = S.yaml_io.load_arch(REFERENCE + "/arch/loihi.yaml")
+    net2 = S.yaml_io.load_net(REFERENCE + "/snn/dvs.yaml", arch2)
     ba, bb = S.to_desc(arch, net), S.to_desc(arch2, net2)  # keep the owners of the buffers alive
     a, b = ba.desc, bb.desc
     assert (a.n_neurons, a.n_edges) == (b.n_neurons, b.n_edges) == (18678, 3564441)

@@ -12,7 +12,7 @@ def arch_view(S, arch, n_tiles=2):
     ncores = sum(len(t.cores) for t in arch.tiles[:n_tiles])
     arch.tiles = arch.tiles[:n_tiles]
     arch._cores = arch._cores[:ncores]
-    d = S.description.describe(S.to_desc(arch, S.Network()))
+    d = S.description.describe(S.to_desc(arch, S.description.Network()))
     return {k: d[k] for k in ("noc", "sync", "tiles", "cores")}
 
 
@@ -22,7 +22,7 @@ def arch_view(S, arch, n_tiles=2):
     ("truenorth", "truenorth.yaml", {"n_tiles": 4096}),
 ])
 def test_preset_equals_yaml(S, preset, yaml_name, kw):
-    pa, ya = getattr(S.presets, preset)(**kw), S.load_arch(REFERENCE + "/arch/" + yaml_name)
+    pa, ya = getattr(S.presets, preset)(api=S.description, **kw), S.yaml_io.load_arch(REFERENCE + "/arch/" + yaml_name)
     assert (len(pa.tiles), pa.core_count) == (len(ya.tiles), ya.core_count)
     a, b = arch_view(S, pa), arch_view(S, ya)
     # unit attribute dicts from YAML additionally carry the keys the parser forwards verbatim
@@ -36,16 +36,16 @@ def test_preset_equals_yaml(S, preset, yaml_name, kw):
 
 def test_loihi_large_preset_sample(S):
     # 1024 tiles x 4 cores x 1031 units is large: compare a 2-tile slice, unit for unit
-    y = S.load_arch(REFERENCE + "/arch/loihi_large.yaml")
+    y = S.yaml_io.load_arch(REFERENCE + "/arch/loihi_large.yaml")
     assert (y.noc_width, y.noc_height, len(y.tiles), y.core_count) == (256, 128, 1024, 4096)
-    a, b = arch_view(S, S.presets.loihi_large(n_tiles=2)), arch_view(S, y)
+    a, b = arch_view(S, S.presets.loihi_large(n_tiles=2, api=S.description)), arch_view(S, y)
     assert a == b
 
 
 def test_example_snn_preset(S):
-    arch = S.presets.example_chip()
+    arch = S.presets.example_chip(api=S.description)
     a = S.description.describe(S.to_desc(arch, S.presets.example_snn(arch)))
-    arch2 = S.load_arch(REFERENCE + "/arch/example_chip.yaml")
-    b = S.description.describe(S.to_desc(arch2, S.load_net(REFERENCE + "/snn/example_snn.yaml", arch2)))
+    arch2 = S.yaml_io.load_arch(REFERENCE + "/arch/example_chip.yaml")
+    b = S.description.describe(S.to_desc(arch2, S.yaml_io.load_net(REFERENCE + "/snn/example_snn.yaml", arch2)))
     assert a["groups"] == b["groups"]
     assert a["edges"] == b["edges"]
