@@ -59,6 +59,9 @@ int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron);
 /* SpikingChip::sim(timesteps, timing_model): returns the RunData of this call.
  * record != 0 keeps per-step totals / spike lists / (detailed) messages for the getters. */
 int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *run_data);
+/* Number of host threads that run the detailed NoC schedule of finished timesteps while the GPU
+ * simulates ahead (SpikingChip::sim `scheduler_threads`, src/chip.cpp:291-349; 0 = inline). */
+int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_threads);
 int sanafe_chip_reset(sanafe_chip *chip);
 double sanafe_chip_get_power(sanafe_chip *chip);
 

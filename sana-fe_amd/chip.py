@@ -103,6 +103,7 @@ def lib():
     L.sanafe_chip_device.argtypes = [C.c_void_p]
     L.sanafe_chip_device.restype = C.c_void_p
     L.sanafe_chip_sim.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.POINTER(Totals)]
+    L.sanafe_chip_set_scheduler_threads.argtypes = [C.c_void_p, C.c_int]
     L.sanafe_chip_reset.argtypes = [C.c_void_p]
     L.sanafe_chip_get_power.argtypes = [C.c_void_p]
     L.sanafe_chip_get_power.restype = C.c_double
@@ -295,6 +296,7 @@ class SpikingChip:
             raise RuntimeError("no network loaded")
         if timing_model not in TIMING:
             timing_model = "detailed"  # parse_timing_model falls back to detailed, src/chip.cpp:1833-1858
+        self._check(self._L.sanafe_chip_set_scheduler_threads(self._h, int(scheduler_threads)))
         start = self.total_timesteps + 1
         want_steps = any(t is not None and t is not False for t in (spike_trace, perf_trace, message_trace))
         want_state = any(t is not None and t is not False for t in (potential_trace, neuron_trace))
@@ -507,9 +509,9 @@ def map_only(arch, net, n_ranks=1, rank=0):
     L = lib()
     L.sanafe_chip_get_image.argtypes = [C.c_void_p, C.POINTER(HipImage)]
     L.sanafe_chip_get_slot_map.argtypes = [C.c_void_p, C.c_void_p]
-    built = D.to_desc(arch, net)
+    built = _Lowered(arch, net)
     h = C.c_void_p()
-    if L.sanafe_chip_create(C.addressof(built.desc), -1, n_ranks, rank, C.byref(h)) != 0:
+    if L.sanafe_chip_create(built.address, -1, n_ranks, rank, C.byref(h)) != 0:
         msg = L.sanafe_last_error().decode()
         if msg.startswith("HardwareMappingError"):
             raise D.HardwareMappingError(msg)
@@ -543,7 +545,7 @@ def map_only(arch, net, n_ranks=1, rank=0):
                           for i in range(im.n_cost_classes)]
             else:
                 out[n] = v
-        slot_of = np.zeros(int(built.desc.n_neurons), dtype=np.uint32)
+        slot_of = np.zeros(built.n_neurons, dtype=np.uint32)
         L.sanafe_chip_get_slot_map(h, slot_of.ctypes.data)
         return out, slot_of
     finally:

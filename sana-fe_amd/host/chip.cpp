@@ -20,7 +20,11 @@
 #include <vector>
 
 #include <dlfcn.h>
+
+#include <condition_variable>
+#include <deque>
 #include <map>
+#include <mutex>
 
 #include "../../include/sanafe_host.h"
 #include "mapper.hpp"
@@ -59,6 +63,7 @@ struct sanafe_chip
     int64_t n_neurons{0};
     int64_t total_timesteps{0};
     int64_t total_messages_sent{0};
+    int scheduler_threads{0}; // schedule_create_threads, src/schedule.cpp:169-179
     double total_energy{0.0}, total_sim_time{0.0};
     // records of the last sim()
     bool have_records{false};
@@ -197,8 +202,10 @@ struct sanafe_chip
     // 694-708, 802-834: per core, neurons in mapped order; latencies accumulate into
     // next_message_generation_delay; the first message of a firing neuron carries it.
     // ------------------------------------------------------------------------------
-    void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<Msg>> &per_core)
+    void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<Msg>> &per_core,
+            int64_t mid_base) const
     {
+        int64_t next_mid = mid_base;
         per_core.assign(mc.n_cores, {});
         for (uint32_t c = 0; c < mc.n_cores; c++)
         {
@@ -220,7 +227,7 @@ struct sanafe_chip
                     const uint64_t a = mc.out_axon[o];
                     Msg m{};
                     m.timestep = timestep;
-                    m.mid = total_messages_sent++;
+                    m.mid = next_mid++;
                     m.src_neuron = mc.gid_of_slot[s];
                     m.src_tile = st;
                     m.src_core_id = c;
@@ -325,7 +332,7 @@ struct sanafe_chip
     {
         bool operator()(const Msg &a, const Msg &b) const noexcept { return a.sent_timestamp > b.sent_timestamp; }
     };
-    double schedule_detailed(std::vector<std::vector<Msg>> &per_core)
+    double schedule_detailed(std::vector<std::vector<Msg>> &per_core) const
     {
         Noc noc;
         noc.w = mc.noc_width;
@@ -571,7 +578,70 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         const bool detailed = (timing_model == SANAFE_TIMING_DETAILED);
         if (detailed && mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing needs a single-rank chip");
         std::vector<uint8_t> status(mc.n_slots);
-        std::vector<std::vector<Msg>> per_core;
+        struct Job
+        {
+            sanafe_hip_totals ts{};
+            int64_t mid_base{0};
+            std::vector<uint8_t> status;
+            std::vector<uint32_t> bits;
+            std::vector<Msg> flat;
+            std::string error;
+        };
+        std::deque<Job> jobs; // stable addresses
+        std::deque<Job *> ready;
+        std::mutex qmutex;
+        std::condition_variable qcv;
+        bool done_submitting = false;
+        auto run_job = [&](Job &job) {
+            try
+            {
+                std::vector<std::vector<Msg>> per_core;
+                chip->build_messages(job.ts.timesteps, job.status, per_core, job.mid_base);
+                job.ts.sim_time = chip->schedule_detailed(per_core);
+                if (record)
+                    for (auto &q : per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
+            }
+            catch (const std::exception &e)
+            {
+                job.error = e.what();
+            }
+            std::vector<uint8_t>().swap(job.status);
+        };
+        std::vector<std::thread> pool;
+        // plugin units update slot latencies every step, so their runs schedule inline
+        const int n_workers = (detailed && !host_units) ? chip->scheduler_threads : 0;
+        for (int w = 0; w < n_workers; w++)
+            pool.emplace_back([&] {
+                for (;;)
+                {
+                    Job *job = nullptr;
+                    {
+                        std::unique_lock<std::mutex> lock(qmutex);
+                        qcv.wait(lock, [&] { return !ready.empty() || done_submitting; });
+                        if (ready.empty()) return;
+                        job = ready.front();
+                        ready.pop_front();
+                    }
+                    run_job(*job);
+                }
+            });
+        struct PoolGuard // never leave joinable threads behind on an error return
+        {
+            std::vector<std::thread> &pool;
+            std::mutex &m;
+            std::condition_variable &cv;
+            bool &done;
+            ~PoolGuard()
+            {
+                {
+                    std::lock_guard<std::mutex> lock(m);
+                    done = true;
+                }
+                cv.notify_all();
+                for (std::thread &th : pool)
+                    if (th.joinable()) th.join();
+            }
+        } guard{pool, qmutex, qcv, done_submitting};
         for (int64_t s = 0; s < timesteps; s++)
         {
             DEV(sanafe_hip_reset_totals(chip->dev));
@@ -600,34 +670,68 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
             DEV(sanafe_hip_read_status(chip->dev, status.data()));
             chip->total_timesteps += 1;
-            if (detailed)
+            ts.timesteps = chip->total_timesteps;
+            const int64_t mid_base = chip->total_messages_sent;
+            chip->total_messages_sent += ts.packets_sent;
+            std::vector<uint32_t> bits;
+            if (record)
             {
-                chip->build_messages(chip->total_timesteps, status, per_core);
-                try
+                bits.assign(mc.n_slots / 32, 0);
+                for (uint32_t k = 0; k < mc.n_slots; k++)
+                    if (status[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
+            }
+            if (!detailed)
+            {
+                add_totals(run, ts);
+                if (record)
                 {
-                    ts.sim_time = chip->schedule_detailed(per_core);
+                    chip->rec_totals.push_back(ts);
+                    chip->rec_messages.emplace_back();
+                    chip->rec_spike_bits.push_back(std::move(bits));
                 }
-                catch (const std::exception &e)
-                {
-                    return fail(SANAFE_HIP_ERR_INVALID, e.what());
-                }
+                continue;
+            }
+            // The NoC model of one timestep depends only on that timestep's messages (NocInfo is rebuilt per
+            // step, src/schedule.cpp:208-222), so timesteps are handed to scheduler threads like the
+            // reference's `-S n` does (src/schedule.cpp:182-206, 622-661) while the GPU simulates ahead.
+            jobs.emplace_back();
+            Job &job = jobs.back();
+            job.ts = ts;
+            job.mid_base = mid_base;
+            job.status = status;
+            job.bits = std::move(bits);
+            if (pool.empty())
+            {
+                run_job(job);
+                if (!job.error.empty()) return fail(SANAFE_HIP_ERR_INVALID, job.error);
             }
             else
             {
-                per_core.clear();
+                {
+                    std::lock_guard<std::mutex> lock(qmutex);
+                    ready.push_back(&job);
+                }
+                qcv.notify_one();
             }
-            ts.timesteps = chip->total_timesteps;
-            add_totals(run, ts);
-            if (record)
+        }
+        if (detailed)
+        {
             {
-                chip->rec_totals.push_back(ts);
-                std::vector<Msg> flat;
-                for (auto &q : per_core) flat.insert(flat.end(), q.begin(), q.end());
-                chip->rec_messages.push_back(std::move(flat));
-                std::vector<uint32_t> bits(mc.n_slots / 32, 0);
-                for (uint32_t k = 0; k < mc.n_slots; k++)
-                    if (status[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
-                chip->rec_spike_bits.push_back(std::move(bits));
+                std::lock_guard<std::mutex> lock(qmutex);
+                done_submitting = true;
+            }
+            qcv.notify_all();
+            for (std::thread &th : pool) th.join();
+            for (Job &job : jobs) // retire in timestep order: deterministic accumulation (flush_timestep_data)
+            {
+                if (!job.error.empty()) return fail(SANAFE_HIP_ERR_INVALID, job.error);
+                add_totals(run, job.ts);
+                if (record)
+                {
+                    chip->rec_totals.push_back(job.ts);
+                    chip->rec_messages.push_back(std::move(job.flat));
+                    chip->rec_spike_bits.push_back(std::move(job.bits));
+                }
             }
         }
         if (record)
@@ -640,6 +744,14 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->total_sim_time += run.sim_time;
     run.timesteps = timesteps;
     if (rd) *rd = run;
+    return 0;
+}
+
+extern "C" int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_threads)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (n_threads < 0 || n_threads > 256) return fail(SANAFE_HIP_ERR_INVALID, "scheduler_threads must be in 0..256");
+    chip->scheduler_threads = n_threads;
     return 0;
 }
 

@@ -6,7 +6,9 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <exception>
 #include <optional>
+#include <thread>
 #include <tuple>
 #include <chrono>
 #include <cstdio>
@@ -168,13 +170,69 @@ int find_unit(const Template &t, const std::string &name, bool syn, bool dend, b
             std::to_string(int(syn)) + ", dendrite:" + std::to_string(int(dend)) + ", soma:" + std::to_string(int(soma)));
 }
 
-template <typename K> void counting_sort(std::vector<uint64_t> &order, const K &key_of, size_t n_keys, std::vector<uint64_t> &tmp)
+// Runs fn(t) for t in [0, T) on T threads; the exception of the lowest task wins, which for
+// contiguous blocks is the error a serial scan would have hit first.
+template <typename F> void parallel_tasks(int T, const F &fn)
 {
-    std::vector<uint64_t> count(n_keys + 1, 0);
-    for (uint64_t e : order) count[key_of(e) + 1]++;
-    for (size_t k = 0; k < n_keys; k++) count[k + 1] += count[k];
-    tmp.resize(order.size());
-    for (uint64_t e : order) tmp[count[key_of(e)]++] = e;
+    if (T <= 1)
+    {
+        fn(0);
+        return;
+    }
+    std::vector<std::exception_ptr> errors(T);
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; t++)
+        pool.emplace_back([&, t] {
+            try
+            {
+                fn(t);
+            }
+            catch (...)
+            {
+                errors[t] = std::current_exception();
+            }
+        });
+    for (std::thread &th : pool) th.join();
+    for (const std::exception_ptr &e : errors)
+        if (e) std::rethrow_exception(e);
+}
+
+int block_count(int n_threads, uint64_t n) { return static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(n_threads, n / 65536 + 1))); }
+
+// Stable counting sort of `order` by key_of(order[i]); blocks of the input are counted and scattered
+// by separate threads, block b's elements of one key landing before block b+1's.
+template <typename K>
+void counting_sort(std::vector<uint64_t> &order, const K &key_of, size_t n_keys, std::vector<uint64_t> &tmp, int n_threads)
+{
+    const uint64_t n = order.size();
+    int T = block_count(n_threads, n);
+    while (T > 1 && static_cast<uint64_t>(T) * n_keys > n / 2 + (uint64_t{1} << 26)) T--; // histogram memory stays modest
+    std::vector<std::vector<uint64_t>> count(T);
+    tmp.resize(n);
+    auto range = [&](int t) { return std::pair<uint64_t, uint64_t>(n * t / T, n * (t + 1) / T); };
+    parallel_tasks(T, [&](int t) {
+        std::vector<uint64_t> &c = count[t];
+        c.assign(n_keys, 0);
+        const auto r = range(t);
+        for (uint64_t i = r.first; i < r.second; i++) c[key_of(order[i])]++;
+    });
+    uint64_t run = 0;
+    for (size_t k = 0; k < n_keys; k++)
+        for (int t = 0; t < T; t++)
+        {
+            const uint64_t c = count[t][k];
+            count[t][k] = run;
+            run += c;
+        }
+    parallel_tasks(T, [&](int t) {
+        std::vector<uint64_t> &c = count[t];
+        const auto r = range(t);
+        for (uint64_t i = r.first; i < r.second; i++)
+        {
+            const uint64_t e = order[i];
+            tmp[c[key_of(e)]++] = e;
+        }
+    });
     order.swap(tmp);
 }
 
@@ -252,6 +310,9 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         t_last = now;
     };
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) throw std::invalid_argument("bad rank / n_ranks");
+    // host threads of the edge passes (results do not depend on the count)
+    int n_threads = static_cast<int>(std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency())));
+    if (const char *env = std::getenv("SANAFE_MAP_THREADS")) n_threads = std::max(1, std::min(256, std::atoi(env)));
     // ------------------------------------------------------------------ architecture
     mc.n_tiles = d.n_tiles;
     mc.n_cores = d.n_cores;
@@ -654,29 +715,32 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     const int64_t E = d.n_edges;
     std::vector<int32_t> edge_syn_unit(E);  // unit index inside the destination core's template
     std::vector<uint8_t> edge_delay_eff;     // effective delay seen by the delay dendrite
-    int32_t memo_name = -2, memo_tmpl = -1, memo_unit = -1; // consecutive edges nearly always repeat the lookup
-    for (int64_t e = 0; e < E; e++)
-    {
-        const int64_t dst = d.edge_dst[e];
-        if (d.edge_src[e] < 0 || d.edge_src[e] >= N || dst < 0 || dst >= N) throw std::invalid_argument("edge endpoint out of range");
-        int32_t hw_id = d.edge_synapse_hw[e]; // get_synapse_hw_name, src/chip.cpp:308-332
-        if (hw_id < 0) hw_id = d.neuron_synapse_hw[dst];
-        const int32_t tm = d.core_template[d.neuron_core[dst]];
-        const Template &t = templates[tm];
-        if (hw_id != memo_name || tm != memo_tmpl)
+    parallel_tasks(block_count(n_threads, E), [&](int t) {
+        const int T = block_count(n_threads, E);
+        int32_t memo_name = -2, memo_tmpl = -1, memo_unit = -1; // consecutive edges nearly always repeat the lookup
+        for (int64_t e = E * t / T; e < E * (t + 1) / T; e++)
         {
-            memo_unit = find_unit(t, S(d, hw_id), true, false, false);
-            memo_name = hw_id;
-            memo_tmpl = tm;
+            const int64_t dst = d.edge_dst[e];
+            if (d.edge_src[e] < 0 || d.edge_src[e] >= N || dst < 0 || dst >= N) throw std::invalid_argument("edge endpoint out of range");
+            int32_t hw_id = d.edge_synapse_hw[e]; // get_synapse_hw_name, src/chip.cpp:308-332
+            if (hw_id < 0) hw_id = d.neuron_synapse_hw[dst];
+            const int32_t tm = d.core_template[d.neuron_core[dst]];
+            const Template &tp = templates[tm];
+            if (hw_id != memo_name || tm != memo_tmpl)
+            {
+                memo_unit = find_unit(tp, S(d, hw_id), true, false, false);
+                memo_name = hw_id;
+                memo_tmpl = tm;
+            }
+            const int su = memo_unit;
+            const UnitInfo &u = tp.units[su];
+            if (u.model != M_CURRENT_BASED) throw UnsupportedError("synapse unit '" + u.name + "' (plugin) is not implemented on the MI355X backend");
+            if (u.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
+            if (!u.e_spike) throw std::runtime_error("Synapse unit does not simulate energy or provide a default energy cost in the architecture description.");
+            if (!u.l_spike) throw std::runtime_error("Synapse unit does not simulate latency or provide a default latency cost in the architecture description.");
+            edge_syn_unit[e] = su;
         }
-        const int su = memo_unit;
-        const UnitInfo &u = t.units[su];
-        if (u.model != M_CURRENT_BASED) throw UnsupportedError("synapse unit '" + u.name + "' (plugin) is not implemented on the MI355X backend");
-        if (u.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
-        if (!u.e_spike) throw std::runtime_error("Synapse unit does not simulate energy or provide a default energy cost in the architecture description.");
-        if (!u.l_spike) throw std::runtime_error("Synapse unit does not simulate latency or provide a default latency cost in the architecture description.");
-        edge_syn_unit[e] = su;
-    }
+    });
     if (d.edge_delay && any_delay_dendrite)
     {
         // The delay dendrite stores delays[] indexed by the SYNAPSE unit's address of the
@@ -693,7 +757,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const int g = group_of[s];
             return rank_base[lex_rank[g]] + (s - d.group_ptr[g]);
         };
-        counting_sort(eo, src_key, N, tmp);
+        counting_sort(eo, src_key, N, tmp, n_threads);
         std::map<std::pair<uint32_t, int>, uint64_t> syn_count;            // (core, synapse unit) -> next address
         std::map<std::pair<uint32_t, int>, std::vector<uint8_t>> delays;   // (core, dendrite unit) -> delays[]
         std::vector<uint64_t> syn_addr(E);
@@ -730,16 +794,145 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     // order) = (pre slot, creation order): two stable counting sorts.
     std::vector<uint64_t> eo(E), tmp;
     std::iota(eo.begin(), eo.end(), 0);
-    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(mc.slot_of_gid[d.edge_src[e]]); }, mc.n_global_slots, tmp);
-    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(d.neuron_core[d.edge_dst[e]]); }, d.n_cores, tmp);
+    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(mc.slot_of_gid[d.edge_src[e]]); }, mc.n_global_slots, tmp, n_threads);
+    counting_sort(eo, [&](uint64_t e) { return static_cast<size_t>(d.neuron_core[d.edge_dst[e]]); }, d.n_cores, tmp, n_threads);
     tmp.clear();
     tmp.shrink_to_fit();
     lap("edge sorts");
-    if (rank >= 0)
+    // The edges of the local cores are one contiguous run [local_beg, local_end) of the sorted order, so a
+    // synapse's place in the image is known before its axon is: position in the run.
+    auto dest_core_at = [&](int64_t k) { return static_cast<uint32_t>(d.neuron_core[d.edge_dst[eo[k]]]); };
+    auto first_at_or_after = [&](uint32_t core) { // first sorted position whose destination core is >= core
+        int64_t lo = 0, hi = E;
+        while (lo < hi)
+        {
+            const int64_t mid = lo + (hi - lo) / 2;
+            if (dest_core_at(mid) < core) lo = mid + 1;
+            else hi = mid;
+        }
+        return lo;
+    };
+    const int64_t local_beg = first_at_or_after(mc.first_core), local_end = first_at_or_after(mc.last_core);
+    mc.syn_meta.resize(static_cast<size_t>(local_end - local_beg));
+    mc.syn_weight.resize(static_cast<size_t>(local_end - local_beg));
+
+    // Pass 1 (threads, blocks of whole axons): everything about an axon that depends only on its own
+    // edges.  Pass 2 (serial, below) numbers the axons and accumulates the per-neuron aggregates in
+    // delivery order, so floating-point sums do not depend on the thread count.
+    struct AxonBlock
     {
-        mc.syn_meta.reserve(n_ranks == 1 ? E : E / n_ranks + E / 8);
-        mc.syn_weight.reserve(n_ranks == 1 ? E : E / n_ranks + E / 8);
-    }
+        std::vector<uint32_t> pre, nsyn, hops, dc;
+        std::vector<uint8_t> uniform;
+        std::vector<double> proc, first_lat, min_hop, e_net, e_syn, e_dend;
+    };
+    const int T = block_count(n_threads, static_cast<uint64_t>(E));
+    std::vector<AxonBlock> blocks(T);
+    auto axon_start = [&](int64_t k) { // first position >= k that starts an axon
+        while (k > 0 && k < E && dest_core_at(k) == dest_core_at(k - 1) &&
+                mc.slot_of_gid[d.edge_src[eo[k]]] == mc.slot_of_gid[d.edge_src[eo[k - 1]]])
+            k++;
+        return k;
+    };
+    parallel_tasks(T, [&](int t) {
+        AxonBlock &B = blocks[t];
+        int64_t i = axon_start(E * t / T);
+        const int64_t end = axon_start(E * (t + 1) / T);
+        const size_t guess = static_cast<size_t>((end - i) / 4 + 16);
+        for (auto *v : {&B.pre, &B.nsyn, &B.hops, &B.dc}) v->reserve(guess);
+        for (auto *v : {&B.proc, &B.first_lat, &B.min_hop, &B.e_net, &B.e_syn, &B.e_dend}) v->reserve(guess);
+        B.uniform.reserve(guess);
+        while (i < end)
+        {
+            const uint64_t e0 = eo[i];
+            const uint32_t dc = d.neuron_core[d.edge_dst[e0]];
+            const uint32_t pre = mc.slot_of_gid[d.edge_src[e0]];
+            int64_t j = i;
+            while (j < E && static_cast<uint32_t>(d.neuron_core[d.edge_dst[eo[j]]]) == dc && mc.slot_of_gid[d.edge_src[eo[j]]] == pre) j++;
+            const Template &dt = tmpl_of(dc);
+            const int bp = d.core_buffer_pos[dc];
+            const bool local = dc >= mc.first_core && dc < mc.last_core;
+            // processing delay of the message: pipeline_process_axon_in + process_message, src/chip.cpp:738-800
+            if (dt.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
+            double proc = dt.ain_l[0];
+            double e_syn = 0.0, e_dend = 0.0;
+            double first_lat = 0.0;
+            bool uniform_lat = true;
+            for (int64_t k = i; k < j; k++)
+            {
+                const uint64_t e = eo[k];
+                const UnitInfo &su = dt.units[edge_syn_unit[e]];
+                const int64_t dst = d.edge_dst[e];
+                double lat = 0.0; // execute_pipeline: total_latency
+                lat += *su.l_spike;
+                e_syn += *su.e_spike;
+                if (bp > SANAFE_BUF_BEFORE_DENDRITE)
+                {
+                    const UnitInfo &du = dt.units[dend_unit[dst]];
+                    if (!du.e_update) throw std::runtime_error("Dendrite unit does not simulate energy or provide a default energy cost in the architecture description.");
+                    if (!du.l_update) throw std::runtime_error("Dendrite unit does not simulate latency or provide a default latency cost in the architecture description.");
+                    lat += *du.l_update;
+                    e_dend += *du.e_update;
+                }
+                proc += lat;
+                if (k == i) first_lat = lat;
+                else if (lat != first_lat) uniform_lat = false;
+                if (local)
+                {
+                    const uint32_t post = offset_in_core[dst];
+                    if (post > 0xffffu) throw UnsupportedError("more than 65536 neurons on one core");
+                    uint32_t meta = post;
+                    if (neuron_dend_kind[dst] == 2) meta |= static_cast<uint32_t>(edge_delay_eff.empty() ? 0 : edge_delay_eff[e]) << 16;
+                    if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
+                    mc.syn_meta[static_cast<size_t>(k - local_beg)] = meta;
+                    mc.syn_weight[static_cast<size_t>(k - local_beg)] = d.edge_weight[e];
+                }
+            }
+            // network costs: sim_estimate_network_costs, src/chip.cpp:1127-1169
+            const uint32_t sc = mc.core_of_slot[pre];
+            const uint32_t st = mc.core_tile[sc], dtile = mc.core_tile[dc];
+            const uint32_t sx = mc.tile_x[st], sy = mc.tile_y[st], dx = mc.tile_x[dtile], dy = mc.tile_y[dtile];
+            const uint32_t xh = sx > dx ? sx - dx : dx - sx, yh = sy > dy ? sy - dy : dy - sy;
+            double min_hop = 0.0, e_hop = 0.0;
+            if (sx < dx)
+            {
+                min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_EAST];
+                e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_EAST];
+            }
+            else
+            {
+                min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_WEST];
+                e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_WEST];
+            }
+            if (sy < dy)
+            {
+                min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_NORTH];
+                e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_NORTH];
+            }
+            else
+            {
+                min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_SOUTH];
+                e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_SOUTH];
+            }
+            // axon energies count only when the core has exactly one such unit: the counters live on
+            // unit 0 but the energy is read from the LAST unit (src/chip.cpp:1215-1221, 1248-1253)
+            const Template &stt = tmpl_of(sc);
+            const double e_aout = stt.aout_e.size() == 1 ? stt.aout_e[0] : 0.0;
+            const double e_ain = dt.ain_e.size() == 1 ? dt.ain_e[0] : 0.0;
+            B.pre.push_back(pre);
+            B.nsyn.push_back(static_cast<uint32_t>(j - i));
+            B.hops.push_back(xh + yh);
+            B.dc.push_back(dc);
+            B.uniform.push_back(uniform_lat ? 1 : 0);
+            B.proc.push_back(proc);
+            B.first_lat.push_back(first_lat);
+            B.min_hop.push_back(min_hop);
+            B.e_net.push_back((e_aout + e_hop) + e_ain);
+            B.e_syn.push_back(e_syn);
+            B.e_dend.push_back(e_dend);
+            i = j;
+        }
+    });
+    lap("axons + synapses (threads)");
 
     std::vector<uint32_t> g_packets(mc.n_global_slots, 0), g_hops(mc.n_global_slots, 0), g_events(mc.n_global_slots, 0);
     std::vector<double> g_e_net(mc.n_global_slots, 0.0), g_e_syn(mc.n_global_slots, 0.0), g_e_dend(mc.n_global_slots, 0.0);
@@ -748,129 +941,69 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     std::vector<uint32_t> dest_axon_count(d.n_cores, 0);
     std::vector<uint64_t> out_count(static_cast<size_t>(mc.n_global_slots) + 1, 0);
     const bool keep_out_tables = (n_ranks == 1);
-
-    int64_t i = 0;
-    while (i < E)
     {
-        const uint64_t e0 = eo[i];
-        const uint32_t dc = d.neuron_core[d.edge_dst[e0]];
-        const uint32_t pre = mc.slot_of_gid[d.edge_src[e0]];
-        int64_t j = i;
-        while (j < E && static_cast<uint32_t>(d.neuron_core[d.edge_dst[eo[j]]]) == dc && mc.slot_of_gid[d.edge_src[eo[j]]] == pre) j++;
-        const uint32_t nsyn = static_cast<uint32_t>(j - i);
-        const Template &dt = tmpl_of(dc);
-        const int bp = d.core_buffer_pos[dc];
-        const bool local = dc >= mc.first_core && dc < mc.last_core;
-        // processing delay of the message: pipeline_process_axon_in + process_message, src/chip.cpp:738-800
-        if (dt.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
-        double proc = dt.ain_l[0];
-        double e_syn = 0.0, e_dend = 0.0;
-        double first_lat = 0.0;
-        bool uniform_lat = true;
-        for (int64_t k = i; k < j; k++)
+        size_t n_local_axons = 0;
+        for (const AxonBlock &B : blocks)
+            for (uint32_t dc : B.dc) n_local_axons += (dc >= mc.first_core && dc < mc.last_core);
+        mc.ax_pre.reserve(n_local_axons);
+        mc.ax_syn_beg.reserve(n_local_axons);
+        mc.ax_nsyn.reserve(n_local_axons);
+        mc.ax_proc_delay.reserve(n_local_axons);
+        mc.ax_lat_class.reserve(n_local_axons);
+        if (keep_out_tables)
         {
-            const uint64_t e = eo[k];
-            const UnitInfo &su = dt.units[edge_syn_unit[e]];
-            const int64_t dst = d.edge_dst[e];
-            double lat = 0.0; // execute_pipeline: total_latency
-            lat += *su.l_spike;
-            e_syn += *su.e_spike;
-            if (bp > SANAFE_BUF_BEFORE_DENDRITE)
-            {
-                const UnitInfo &du = dt.units[dend_unit[dst]];
-                if (!du.e_update) throw std::runtime_error("Dendrite unit does not simulate energy or provide a default energy cost in the architecture description.");
-                if (!du.l_update) throw std::runtime_error("Dendrite unit does not simulate latency or provide a default latency cost in the architecture description.");
-                lat += *du.l_update;
-                e_dend += *du.e_update;
-            }
-            proc += lat;
-            if (k == i) first_lat = lat;
-            else if (lat != first_lat) uniform_lat = false;
+            mc.ax_dest_core.reserve(n_local_axons);
+            mc.ax_dest_axon_id.reserve(n_local_axons);
+            mc.ax_hops.reserve(n_local_axons);
+            mc.ax_min_hop_delay.reserve(n_local_axons);
         }
-        // network costs: sim_estimate_network_costs, src/chip.cpp:1127-1169
-        const uint32_t sc = mc.core_of_slot[pre];
-        const uint32_t st = mc.core_tile[sc], dtile = mc.core_tile[dc];
-        const uint32_t sx = mc.tile_x[st], sy = mc.tile_y[st], dx = mc.tile_x[dtile], dy = mc.tile_y[dtile];
-        const uint32_t xh = sx > dx ? sx - dx : dx - sx, yh = sy > dy ? sy - dy : dy - sy;
-        double min_hop = 0.0, e_hop = 0.0;
-        if (sx < dx)
+    }
+    uint64_t syn0 = 0; // synapses of the local axons numbered so far
+    for (AxonBlock &B : blocks)
+    {
+        for (size_t a = 0; a < B.pre.size(); a++)
         {
-            min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_EAST];
-            e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_EAST];
-        }
-        else
-        {
-            min_hop += static_cast<double>(xh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_WEST];
-            e_hop += static_cast<double>(xh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_WEST];
-        }
-        if (sy < dy)
-        {
-            min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_NORTH];
-            e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_NORTH];
-        }
-        else
-        {
-            min_hop += static_cast<double>(yh) * d.tile_hop_latency[st * 4 + SANAFE_DIR_SOUTH];
-            e_hop += static_cast<double>(yh) * d.tile_hop_energy[dtile * 4 + SANAFE_DIR_SOUTH];
-        }
-        // axon energies count only when the core has exactly one such unit: the counters live on
-        // unit 0 but the energy is read from the LAST unit (src/chip.cpp:1215-1221, 1248-1253)
-        const Template &stt = tmpl_of(sc);
-        const double e_aout = stt.aout_e.size() == 1 ? stt.aout_e[0] : 0.0;
-        const double e_ain = dt.ain_e.size() == 1 ? dt.ain_e[0] : 0.0;
-        g_packets[pre] += 1;
-        g_hops[pre] += xh + yh;
-        g_events[pre] += nsyn;
-        g_e_net[pre] += (e_aout + e_hop) + e_ain;
-        g_e_syn[pre] += e_syn;
-        g_e_dend[pre] += e_dend;
-        const uint32_t axon_id = dest_axon_count[dc]++;
-        if (local)
-        {
+            const uint32_t pre = B.pre[a], dc = B.dc[a], nsyn = B.nsyn[a];
+            g_packets[pre] += 1;
+            g_hops[pre] += B.hops[a];
+            g_events[pre] += nsyn;
+            g_e_net[pre] += B.e_net[a];
+            g_e_syn[pre] += B.e_syn[a];
+            g_e_dend[pre] += B.e_dend[a];
+            const uint32_t axon_id = dest_axon_count[dc]++;
+            if (dc < mc.first_core || dc >= mc.last_core) continue;
             const uint32_t lc = dc - mc.first_core;
-            const uint64_t syn0 = mc.syn_meta.size();
             if (core_axon_beg[lc + 1] == 0) mc.core_syn_base[lc] = syn0;
             if (syn0 - mc.core_syn_base[lc] > 0xffffffffull) throw UnsupportedError("more than 2^32 synapses on one core");
             mc.ax_pre.push_back(pre);
             mc.ax_syn_beg.push_back(static_cast<uint32_t>(syn0 - mc.core_syn_base[lc]));
             mc.ax_nsyn.push_back(nsyn);
-            mc.ax_proc_delay.push_back(proc);
+            mc.ax_proc_delay.push_back(B.proc[a]);
+            uint8_t cls = 255;
+            if (B.uniform[a])
             {
-                uint8_t cls = 255;
-                if (uniform_lat)
-                {
-                    size_t q = 0;
-                    while (q < mc.lat_class_per_event.size() && mc.lat_class_per_event[q] != first_lat) q++;
-                    if (q == mc.lat_class_per_event.size() && q < 255) mc.lat_class_per_event.push_back(first_lat);
-                    if (q < 255) cls = static_cast<uint8_t>(q);
-                }
-                mc.ax_lat_class.push_back(cls);
+                const double first_lat = B.first_lat[a];
+                size_t q = 0;
+                while (q < mc.lat_class_per_event.size() && mc.lat_class_per_event[q] != first_lat) q++;
+                if (q == mc.lat_class_per_event.size() && q < 255) mc.lat_class_per_event.push_back(first_lat);
+                if (q < 255) cls = static_cast<uint8_t>(q);
             }
+            mc.ax_lat_class.push_back(cls);
             if (keep_out_tables)
             {
                 mc.ax_dest_core.push_back(dc);
                 mc.ax_dest_axon_id.push_back(axon_id);
-                mc.ax_hops.push_back(xh + yh);
-                mc.ax_min_hop_delay.push_back(min_hop);
+                mc.ax_hops.push_back(B.hops[a]);
+                mc.ax_min_hop_delay.push_back(B.min_hop[a]);
                 out_count[pre + 1]++;
             }
             core_axon_beg[lc + 1]++;
-            for (int64_t k = i; k < j; k++)
-            {
-                const uint64_t e = eo[k];
-                const int64_t dst = d.edge_dst[e];
-                const uint32_t post = offset_in_core[dst];
-                if (post > 0xffffu) throw UnsupportedError("more than 65536 neurons on one core");
-                uint32_t meta = post;
-                if (neuron_dend_kind[dst] == 2) meta |= static_cast<uint32_t>(edge_delay_eff.empty() ? 0 : edge_delay_eff[e]) << 16;
-                if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
-                mc.syn_meta.push_back(meta);
-                mc.syn_weight.push_back(d.edge_weight[e]);
-            }
+            syn0 += nsyn;
         }
-        i = j;
+        B = AxonBlock(); // release as we go
     }
-    lap("axons + synapses");
+    if (syn0 != static_cast<uint64_t>(local_end - local_beg)) throw std::logic_error("mapper: synapse numbering out of step");
+    lap("axon numbering + aggregates");
     mc.lat_class_per_event.resize(255, 0.0);
     for (uint32_t k = 0; k < LC; k++) core_axon_beg[k + 1] += core_axon_beg[k];
     // cores without inbound axons still need a valid synapse base

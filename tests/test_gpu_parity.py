@@ -119,6 +119,23 @@ def test_random_loihi_detailed_messages(S):
         assert a["sim_time"] == b["sim_time"]
 
 
+def test_detailed_scheduler_threads_match_inline(S):
+    """`scheduler_threads=n` (src/chip.cpp:291-349, src/schedule.cpp:182-206) overlaps the NoC schedule of finished
+    steps with the GPU; every timestep's schedule is independent, so results equal the inline run bit for bit."""
+    arch, net = nets.random_loihi(S, n_tiles=6, neurons_per_core=50, out_degree=16, arch_kind="loihi", seed=3)
+    chip, orc = make(S, arch, net)
+    chip2, _ = make(S, arch, net)
+    a = chip.sim(40, timing_model="detailed", scheduler_threads=0, perf_trace=True, message_trace=True)
+    b = chip2.sim(40, timing_model="detailed", scheduler_threads=4, perf_trace=True, message_trace=True)
+    assert a["sim_time"] == b["sim_time"] and a["energy"] == b["energy"]
+    assert a["perf_trace"] == b["perf_trace"]
+    assert a["message_trace"] == b["message_trace"]
+    total = 0.0
+    for _ in range(40):
+        total += orc.step("detailed")["sim_time"]
+    assert a["sim_time"] == total
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

@@ -74,3 +74,21 @@ def test_unmapped_neuron_raises(S):
     net.groups["out"].core[1] = -1
     with pytest.raises(S.HardwareMappingError, match="not mapped"):
         S.map_only(arch, net)
+
+
+def test_image_independent_of_mapper_thread_count(S, monkeypatch):
+    """The edge passes of the mapper run on host threads; the lowered image must not depend on how many."""
+    arch, net = nets.random_loihi(S, n_tiles=8, neurons_per_core=256, out_degree=40, arch_kind="large", delays=True, seed=11)
+    images = []
+    for n in ("1", "3", "8"):
+        monkeypatch.setenv("SANAFE_MAP_THREADS", n)
+        im, slot = S.chip.map_only(arch, net)
+        images.append((im, slot))
+    assert images[0][0]["n_synapses"] > 65536 * 3  # enough edges for several blocks
+    for im, slot in images[1:]:
+        assert np.array_equal(slot, images[0][1])
+        for k, v in images[0][0].items():
+            if isinstance(v, np.ndarray):
+                assert np.array_equal(v, im[k]), k
+            else:
+                assert v == im[k], k
