@@ -131,6 +131,15 @@ typedef struct sanafe_hip_image
     const int64_t *in_rate_period;/* (long)(1.0/rate), 0 = no rate input */
     const uint32_t *in_train_bits;/* [n_train_words] packed LSB first */
 
+    /* ---- external per-step value streams (optional; host-generated, sanafe_hip_write_ext) ----
+     * Three models consume a sequential host-side source on every update, which makes the
+     * values a static schedule of (timestep, neuron): the input model's Poisson draw
+     * (std::mt19937 per unit, src/models.cpp:883), TrueNorth's `std::rand() & random_mask`
+     * (src/models.cpp:749-759) and the LIF noise file (src/models.cpp:535-539, 589-651).
+     * slot_ext[s] = column of slot s in a row of stream values, or 0xffffffff. */
+    uint32_t n_ext;               /* columns per timestep; 0 = none */
+    const uint32_t *slot_ext;     /* [n_slots], may be NULL when n_ext == 0 */
+
     /* ---- delivery slices [n_slices] ---- */
     const uint32_t *slice_core;   /* destination core (local) */
     const uint64_t *slice_axon_beg, *slice_axon_end; /* axon range */
@@ -179,6 +188,11 @@ void sanafe_hip_chip_destroy(sanafe_hip_chip *chip);
  * sanafe_hip_read_step_*; `simple_timing` != 0 evaluates the simple timing
  * model on the device (src/schedule.cpp:61-102). */
 int sanafe_hip_step(sanafe_hip_chip *chip, int64_t n_steps, int simple_timing, int record);
+/* Queues the external stream values of the next n_steps timesteps: values[step][column], int32:
+ * input model 1 = "poisson_probability > U(0,1)" held, TrueNorth `rand() & mask`, LIF the sign-extended
+ * noise value.  Every step of a chip with n_ext > 0 consumes one row; stepping past the queued rows
+ * fails with SANAFE_HIP_ERR_INVALID (no default values are invented). */
+int sanafe_hip_write_ext(sanafe_hip_chip *chip, int64_t n_steps, const int32_t *values);
 int sanafe_hip_synchronize(sanafe_hip_chip *chip);
 
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)

@@ -62,6 +62,13 @@ int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int 
 /* Number of host threads that run the detailed NoC schedule of finished timesteps while the GPU
  * simulates ahead (SpikingChip::sim `scheduler_threads`, src/chip.cpp:291-349; 0 = inline). */
 int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_threads);
+/* Generates the next `steps` rows of the external value streams (include/sanafe_hip.h: slot_ext,
+ * sanafe_hip_write_ext) into out[steps][image.n_ext], advancing the host-side sources (Poisson
+ * generators, the rand() sequence, noise files).  sim() does this itself; the call exists for mapped-only
+ * chips and for callers that drive sanafe_hip_* directly. */
+int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out);
+/* Self-check hook: the first n values of the host's restatement of glibc rand() for `seed`. */
+void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out);
 int sanafe_chip_reset(sanafe_chip *chip);
 double sanafe_chip_get_power(sanafe_chip *chip);
 

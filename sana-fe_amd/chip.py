@@ -495,6 +495,7 @@ class HipImage(C.Structure):
         ("slot_e_dend", _p(C.c_double)),
         ("in_train_beg", _p(C.c_uint32)), ("in_train_len", _p(C.c_uint32)), ("in_rate_period", _p(C.c_int64)),
         ("in_train_bits", _p(C.c_uint32)),
+        ("n_ext", C.c_uint32), ("slot_ext", _p(C.c_uint32)),
         ("slice_core", _p(C.c_uint32)), ("slice_axon_beg", _p(C.c_uint64)), ("slice_axon_end", _p(C.c_uint64)),
         ("core_syn_base", _p(C.c_uint64)), ("core_axon_in_latency", _p(C.c_double)),
         ("ax_pre", _p(C.c_uint32)), ("ax_syn_beg", _p(C.c_uint32)), ("ax_nsyn", _p(C.c_uint32)),
@@ -503,9 +504,10 @@ class HipImage(C.Structure):
     ]
 
 
-def map_only(arch, net, n_ranks=1, rank=0):
+def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
     """Maps and lowers without touching a device; returns (image dict of numpy arrays, slot_of_neuron).
-    The arrays are copies, so they outlive the temporary chip."""
+    The arrays are copies, so they outlive the temporary chip.  ``ext_steps`` > 0 also generates that many rows
+    of the external value streams (``ext_rows``: [ext_steps, n_ext] int32)."""
     L = lib()
     L.sanafe_chip_get_image.argtypes = [C.c_void_p, C.POINTER(HipImage)]
     L.sanafe_chip_get_slot_map.argtypes = [C.c_void_p, C.c_void_p]
@@ -532,6 +534,7 @@ def map_only(arch, net, n_ranks=1, rank=0):
         for n in ("slot_cls", "slot_bias", "slot_v0", "slot_aux", "slot_packets", "slot_hops", "slot_events",
                   "slot_e_net", "slot_e_syn", "slot_e_dend"):
             counts[n] = im.n_slots
+        counts["slot_ext"] = im.n_slots if im.n_ext else 0
         out = {}
         for n, _t in HipImage._fields_:
             v = getattr(im, n)
@@ -547,6 +550,12 @@ def map_only(arch, net, n_ranks=1, rank=0):
                 out[n] = v
         slot_of = np.zeros(built.n_neurons, dtype=np.uint32)
         L.sanafe_chip_get_slot_map(h, slot_of.ctypes.data)
+        rows = np.zeros((int(ext_steps), int(im.n_ext)), dtype=np.int32)
+        if rows.size:
+            L.sanafe_chip_generate_ext.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+            if L.sanafe_chip_generate_ext(h, int(ext_steps), rows.ctypes.data) != 0:
+                raise RuntimeError(L.sanafe_last_error().decode())
+        out["ext_rows"] = rows
         return out, slot_of
     finally:
         L.sanafe_chip_destroy(h)

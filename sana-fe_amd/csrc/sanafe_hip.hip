@@ -86,6 +86,8 @@ struct DevImage
     const double *slot_bias, *slot_e_net, *slot_e_syn, *slot_e_dend;
     const uint32_t *in_train_beg, *in_train_len, *in_train_bits;
     const long long *in_rate_period;
+    const uint32_t *slot_ext; // column of the slot in a row of external stream values (0xffffffff: none)
+    uint32_t n_ext;
     const uint32_t *slice_core;
     const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
     const uint32_t *core_slice_beg; // [n_cores+1]
@@ -147,7 +149,7 @@ __device__ __forceinline__ int cvt_int_x86(double x)
 // workgroup's 4 wavefronts (a 256-neuron TrueNorth core is one chunk per wave, a 1024-neuron
 // Loihi core four), every wave owns whole 64-slot chunks so the spike ballot maps 1:1 to bitmap words.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record)
+__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record, const int *ext_row)
 {
     __shared__ double s_d[NEURON_BLOCK / WAVE][5];
     __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
@@ -197,6 +199,16 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 }
             }
             const double bias = im.slot_bias[g];
+            // host-generated value of a sequential source this neuron consumes at every update
+            // (Poisson draw, std::rand() & mask, noise file): include/sanafe_hip.h, slot_ext
+            bool has_ext = false;
+            int ext = 0;
+            if (ext_row != nullptr)
+            {
+                const uint32_t col = im.slot_ext[g];
+                has_ext = col != 0xffffffffu;
+                if (has_ext) ext = ext_row[col];
+            }
             if (model == SANAFE_SOMA_LIF)
             {
                 // LoihiLifModel::update, src/models.cpp:497-567
@@ -212,6 +224,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                     v *= p.leak_decay;
                 }
                 v = (double) cvt_int_x86(v * 64.0) / 64.0;
+                if (has_ext) v += (double) ext; // loihi_generate_noise, src/models.cpp:535-539
                 if (!(rc > 0))
                 {
                     v += bias;
@@ -240,7 +253,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             }
             else if (model == SANAFE_SOMA_TRUENORTH)
             {
-                // TrueNorthModel::update, src/models.cpp:724-830 (random_range_mask == 0)
+                // TrueNorthModel::update, src/models.cpp:724-830
                 const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
                 double v = st.v[g];
                 status = 1;
@@ -256,14 +269,16 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 }
                 v += bias;
                 if (has_in) v += cur;
-                if (v >= p.threshold)
+                // the randomised threshold test sees V + (rand() & mask); the resets act on V (src/models.cpp:745-797)
+                const double vt = has_ext ? v + (double) ext : v;
+                if (vt >= p.threshold)
                 {
                     if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
                     else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
                     else if (p.reset_mode == SANAFE_RESET_SATURATE) v = p.threshold;
                     status = 3;
                 }
-                else if (v <= p.reverse_threshold)
+                else if (vt <= p.reverse_threshold)
                 {
                     if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
                     else if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v += p.reverse_threshold;
@@ -271,7 +286,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 }
                 st.v[g] = v;
             }
-            else // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903 (poisson == 0)
+            else // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903
             {
                 const uint32_t a = im.slot_aux[g];
                 const uint32_t pos = st.in_pos[a];
@@ -282,6 +297,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                     send = (im.in_train_bits[b >> 5] >> (b & 31u)) & 1u;
                     st.in_pos[a] = pos + 1;
                 }
+                if (ext != 0) send = true; // poisson_probability > uniform_distribution(gen)
                 const long long period = im.in_rate_period[a];
                 if (period > 0 && (t % period) == 0) send = true;
                 status = send ? 3 : 1;
@@ -789,6 +805,9 @@ struct sanafe_hip_chip
     uint8_t *d_host_status{nullptr};
     double *d_host_a{nullptr}, *d_host_b{nullptr};
     uint32_t host_cap{0};
+    // external stream rows queued by sanafe_hip_write_ext
+    int *d_ext{nullptr};
+    long long ext_cap{0}, ext_rows{0}, ext_next{0};
 };
 
 namespace
@@ -884,6 +903,13 @@ int validate(const sanafe_hip_image *im)
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
     }
+    if (im->n_ext > 0)
+    {
+        if (!im->slot_ext) return fail(SANAFE_HIP_ERR_INVALID, "n_ext > 0 but slot_ext is NULL");
+        for (uint32_t g = 0; g < im->n_slots; g++)
+            if (im->slot_ext[g] != 0xffffffffu && im->slot_ext[g] >= im->n_ext)
+                return fail(SANAFE_HIP_ERR_INVALID, "slot %u: external stream column out of range", g);
+    }
     for (uint32_t i = 0; i < im->n_input; i++)
         if ((uint64_t) im->in_train_beg[i] + im->in_train_len[i] > im->n_train_words * 32ull)
             return fail(SANAFE_HIP_ERR_INVALID, "input %u: spike train outside in_train_bits", i);
@@ -960,6 +986,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(upload(c, h.in_train_len, h.n_input, &im.in_train_len));
     TRYC(upload(c, reinterpret_cast<const long long *>(h.in_rate_period), h.n_input, &im.in_rate_period));
     TRYC(upload(c, h.in_train_bits, h.n_train_words, &im.in_train_bits));
+    im.n_ext = h.n_ext;
+    im.slot_ext = nullptr;
+    if (h.n_ext > 0) TRYC(upload(c, h.slot_ext, h.n_slots, &im.slot_ext));
     TRYC(upload(c, h.slice_core, h.n_slices, &im.slice_core));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_beg), h.n_slices, &im.slice_axon_beg));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_end), h.n_slices, &im.slice_axon_end));
@@ -1066,7 +1095,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
-                 (void *) c->d_host_b})
+                 (void *) c->d_host_b, (void *) c->d_ext})
         if (p) (void) hipFree(p);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -1088,7 +1117,15 @@ static int ensure_log(sanafe_hip_chip *c, long long steps)
 
 static int launch_neurons(sanafe_hip_chip *c, int record)
 {
-    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record);
+    const int *ext_row = nullptr;
+    if (c->im.n_ext > 0)
+    {
+        if (c->ext_next >= c->ext_rows)
+            return fail(SANAFE_HIP_ERR_INVALID, "external value streams exhausted: queue rows with sanafe_hip_write_ext before stepping");
+        ext_row = c->d_ext + (size_t) c->ext_next * c->im.n_ext;
+        c->ext_next++;
+    }
+    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record, ext_row);
     HIPCHK(hipGetLastError());
     return 0;
 }
@@ -1156,6 +1193,26 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     }
     c->t_launches += n_steps;
     for (auto &e : ev) (void) hipEventDestroy(e);
+    return 0;
+}
+
+extern "C" int sanafe_hip_write_ext(sanafe_hip_chip *c, int64_t n_steps, const int32_t *values)
+{
+    if (!c || n_steps < 0 || (n_steps > 0 && !values)) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    if (c->im.n_ext == 0) return fail(SANAFE_HIP_ERR_INVALID, "this chip has no external value streams");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // steps still in flight read the rows being replaced
+    if (n_steps > c->ext_cap)
+    {
+        if (c->d_ext) HIPCHK(hipFree(c->d_ext));
+        c->d_ext = nullptr;
+        c->ext_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_ext), (size_t) n_steps * c->im.n_ext * sizeof(int)));
+        c->ext_cap = n_steps;
+    }
+    if (n_steps > 0) HIPCHK(hipMemcpy(c->d_ext, values, (size_t) n_steps * c->im.n_ext * sizeof(int), hipMemcpyHostToDevice));
+    c->ext_rows = n_steps;
+    c->ext_next = 0;
     return 0;
 }
 

@@ -16,6 +16,7 @@
 #include <list>
 #include <memory>
 #include <queue>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -49,6 +50,121 @@ int fail(int code, const std::string &msg)
 
 constexpr double NEG_INF = -std::numeric_limits<double>::infinity();
 
+// glibc's rand() (TYPE_3 additive feedback generator, r[i] = r[i-3] + r[i-31], seed 1 unless srand was
+// called -- the reference never calls it): the sequence std::rand() yields in the reference's process
+// (src/models.cpp:752-758), kept private so the host process's own rand() state is left alone.
+class GlibcRand
+{
+public:
+    explicit GlibcRand(uint32_t seed = 1)
+    {
+        int32_t word = seed == 0 ? 1 : static_cast<int32_t>(seed);
+        r_[0] = static_cast<uint32_t>(word);
+        for (int i = 1; i < 31; i++)
+        {
+            const long hi = word / 127773, lo = word % 127773; // 16807 * word % 2147483647 without overflow
+            long w = 16807 * lo - 2836 * hi;
+            if (w < 0) w += 2147483647;
+            word = static_cast<int32_t>(w);
+            r_[i] = static_cast<uint32_t>(word);
+        }
+        f_ = 3;
+        b_ = 0;
+        for (int i = 0; i < 310; i++) (void) next();
+    }
+    uint32_t next()
+    {
+        r_[f_] += r_[b_];
+        const uint32_t out = r_[f_] >> 1;
+        f_ = (f_ + 1) % 31;
+        b_ = (b_ + 1) % 31;
+        return out;
+    }
+
+private:
+    uint32_t r_[31];
+    int f_, b_;
+};
+
+// Host-side sources of the external value streams (include/sanafe_hip.h, slot_ext): one row of values
+// per timestep, generated in the order the reference's sweep would have consumed them.
+struct ExtStreams
+{
+    const MappedChip *mc{nullptr};
+    std::vector<std::mt19937> poisson_gen; // per Poisson column (src/models.hpp:366-374)
+    std::uniform_real_distribution<double> uni{0.0, 1.0};
+    GlibcRand rand;
+    std::vector<std::vector<int>> noise_values; // per stream: the file's entries
+    std::vector<size_t> noise_pos;
+
+    void init(const MappedChip &m)
+    {
+        mc = &m;
+        for (const MappedChip::ExtColumn &c : m.ext)
+            if (c.kind == MappedChip::ExtColumn::Poisson) poisson_gen.emplace_back(c.seed);
+        for (const MappedChip::NoiseStream &ns : m.noise_streams)
+        {
+            // LoihiLifModel::set_attribute_hw "noise", src/models.cpp:354-366
+            FILE *f = std::fopen(ns.path.c_str(), "rb");
+            if (!f) throw std::runtime_error("Failed to open noise stream");
+            std::string text;
+            char buf[65536];
+            size_t n;
+            while ((n = std::fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, n);
+            std::fclose(f);
+            // loihi_read_noise_stream, src/models.cpp:589-627: one getline per update, `iss >> int`
+            // (0 when the entry does not parse), rewinding at end of file
+            std::vector<int> vals;
+            size_t pos = 0;
+            while (pos < text.size())
+            {
+                size_t nl = text.find('\n', pos);
+                if (nl == std::string::npos) nl = text.size();
+                int v = 0;
+                std::istringstream iss(text.substr(pos, nl - pos));
+                if (!(iss >> v)) v = 0;
+                vals.push_back(v);
+                pos = nl + 1;
+            }
+            noise_values.push_back(std::move(vals));
+            noise_pos.push_back(0);
+        }
+    }
+    void fill_row(int32_t *row)
+    {
+        size_t pg = 0;
+        uint64_t rand_cursor = 0;
+        for (size_t k = 0; k < mc->ext.size(); k++)
+        {
+            const MappedChip::ExtColumn &c = mc->ext[k];
+            if (c.kind == MappedChip::ExtColumn::Poisson)
+            {
+                row[k] = (c.poisson > uni(poisson_gen[pg++])) ? 1 : 0;
+            }
+            else if (c.kind == MappedChip::ExtColumn::TrueNorthRand)
+            {
+                for (; rand_cursor < c.rand_index; rand_cursor++) (void) rand.next(); // neurons of other ranks
+                row[k] = static_cast<int32_t>(rand.next() & c.mask);
+                rand_cursor++;
+            }
+            else
+            {
+                std::vector<int> &vals = noise_values[c.stream];
+                if (vals.empty()) throw std::runtime_error("Couldn't read noise entry from file");
+                size_t &p = noise_pos[c.stream];
+                if (p >= vals.size()) p = 0;
+                const MappedChip::NoiseStream &ns = mc->noise_streams[c.stream];
+                long r = vals[p++]; // loihi_generate_noise, src/models.cpp:629-651
+                const long sign = r & ns.sign_mask;
+                r &= ns.random_mask;
+                if (sign != 0) r |= ~ns.random_mask;
+                row[k] = static_cast<int32_t>(r);
+            }
+        }
+        for (; rand_cursor < mc->n_rand_global; rand_cursor++) (void) rand.next();
+    }
+};
+
 struct Msg : sanafe_message
 {
     bool in_noc{false};
@@ -64,6 +180,25 @@ struct sanafe_chip
     int64_t total_timesteps{0};
     int64_t total_messages_sent{0};
     int scheduler_threads{0}; // schedule_create_threads, src/schedule.cpp:169-179
+    ExtStreams ext;
+    std::vector<int32_t> ext_rows;
+    // Generates and queues the external stream values of the next `steps` timesteps.
+    int queue_ext(int64_t steps)
+    {
+        const size_t n = mc.ext.size();
+        if (n == 0 || steps <= 0) return 0;
+        ext_rows.resize(static_cast<size_t>(steps) * n);
+        try
+        {
+            for (int64_t s = 0; s < steps; s++) ext.fill_row(ext_rows.data() + static_cast<size_t>(s) * n);
+        }
+        catch (const std::exception &e)
+        {
+            return fail(SANAFE_HIP_ERR_INVALID, e.what());
+        }
+        if (sanafe_hip_write_ext(dev, steps, ext_rows.data()) != 0) return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+        return 0;
+    }
     double total_energy{0.0}, total_sim_time{0.0};
     // records of the last sim()
     bool have_records{false};
@@ -439,6 +574,14 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
         return fail(SANAFE_HIP_ERR_INVALID, e.what());
     }
     chip->n_neurons = desc->n_neurons;
+    try
+    {
+        chip->ext.init(chip->mc); // opens the LIF noise files: a missing file fails the load, as in the reference
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
     const sanafe_hip_image im = chip->mc.image();
     if (device >= 0) DEV(sanafe_hip_chip_create(&im, device, &chip->dev)); // device < 0: map only (CPU-side checks)
     // per-slot neuron-pipeline latency by status, for the host-side generation delays
@@ -550,21 +693,34 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     const bool host_units = !chip->mc.host_neurons.empty();
     if (timing_model == SANAFE_TIMING_SIMPLE && !host_units)
     {
-        // Whole run stays on the device; nothing comes back per step unless recorded.
+        // Whole run stays on the device; nothing comes back per step unless recorded.  With external value
+        // streams the run is cut into chunks whose stream rows fit a bounded upload (<= 64 MiB).
         DEV(sanafe_hip_reset_totals(chip->dev));
-        DEV(sanafe_hip_step(chip->dev, timesteps, 1, record));
-        DEV(sanafe_hip_synchronize(chip->dev));
+        const size_t n_ext = mc.ext.size();
+        int64_t chunk_cap = n_ext == 0 ? std::max<int64_t>(timesteps, 1) : std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext));
+        if (const char *env = std::getenv("SANAFE_EXT_CHUNK_STEPS")) // tests: force several chunks
+            if (n_ext != 0) chunk_cap = std::max<int64_t>(1, std::atol(env));
+        for (int64_t done = 0, m = 0; done < timesteps; done += m)
+        {
+            m = std::min(chunk_cap, timesteps - done);
+            if (int rc = chip->queue_ext(m)) return rc;
+            DEV(sanafe_hip_step(chip->dev, m, 1, record));
+            DEV(sanafe_hip_synchronize(chip->dev));
+            if (record && m > 0)
+            {
+                chip->rec_totals.resize(done + m);
+                DEV(sanafe_hip_read_step_totals(chip->dev, 0, m, chip->rec_totals.data() + done));
+                chip->rec_spike_bits.resize(done + m);
+                for (int64_t s = 0; s < m; s++)
+                {
+                    chip->rec_spike_bits[done + s].resize(mc.n_slots / 32);
+                    DEV(sanafe_hip_read_step_spikes(chip->dev, s, chip->rec_spike_bits[done + s].data()));
+                }
+            }
+        }
         DEV(sanafe_hip_read_totals(chip->dev, &run));
         if (record && timesteps > 0)
         {
-            chip->rec_totals.resize(timesteps);
-            DEV(sanafe_hip_read_step_totals(chip->dev, 0, timesteps, chip->rec_totals.data()));
-            chip->rec_spike_bits.resize(timesteps);
-            for (int64_t s = 0; s < timesteps; s++)
-            {
-                chip->rec_spike_bits[s].resize(mc.n_slots / 32);
-                DEV(sanafe_hip_read_step_spikes(chip->dev, s, chip->rec_spike_bits[s].data()));
-            }
             chip->have_records = true;
             chip->rec_count = timesteps;
         }
@@ -645,6 +801,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         for (int64_t s = 0; s < timesteps; s++)
         {
             DEV(sanafe_hip_reset_totals(chip->dev));
+            if (int rc = chip->queue_ext(1)) return rc;
             if (host_units)
             {
                 const uint32_t n = static_cast<uint32_t>(chip->h_slots.size());
@@ -755,6 +912,28 @@ extern "C" int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_thread
     return 0;
 }
 
+// Self-check hook: the first n values of the host's rand() restatement (tests compare with libc).
+extern "C" void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out)
+{
+    GlibcRand g(seed);
+    for (int64_t i = 0; i < n; i++) out[i] = g.next();
+}
+
+extern "C" int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out)
+{
+    if (!chip || steps < 0 || (steps > 0 && !out && !chip->mc.ext.empty())) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    const size_t n = chip->mc.ext.size();
+    try
+    {
+        for (int64_t s = 0; s < steps && n > 0; s++) chip->ext.fill_row(out + static_cast<size_t>(s) * n);
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    return 0;
+}
+
 extern "C" int sanafe_chip_reset(sanafe_chip *chip)
 {
     if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
@@ -857,6 +1036,7 @@ extern "C" int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int6
 extern "C" int sanafe_chip_step_neurons(sanafe_chip *chip)
 {
     if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (int rc = chip->queue_ext(1)) return rc;
     DEV(sanafe_hip_step_neurons(chip->dev));
     return 0;
 }

@@ -71,6 +71,9 @@ struct UnitInfo // one pipeline unit of a core template
     bool has_soma_e{false}, has_soma_l{false};
     double se[3]{}, sl[3]{}; // access, update, spike_out
     size_t capacity{SIZE_MAX};
+    std::string noise_path; // LIF `noise` file (src/models.cpp:354-366)
+    long noise_random_mask{0x7f};
+    int input_rank{0};      // `input` units before this one in the template (seed order, src/models.hpp:347)
 };
 
 struct Template
@@ -150,8 +153,16 @@ Template read_template(const sanafe_desc &d, int tm)
             }
             ui.has_soma_l = true;
         }
-        if (ui.model == M_LIF && (has("noise") || has("noise_bits")))
-            throw UnsupportedError("LIF file noise stream (unit '" + ui.name + "') is not implemented on the MI355X backend");
+        if (ui.model == M_LIF)
+        {
+            // set_attribute_hw runs in attribute (key) order, src/models.cpp:351-373
+            if (has("noise")) ui.noise_path = m.at("noise").as_string();
+            if (has("noise_bits")) ui.noise_random_mask = (1L << m.at("noise_bits").as_int()) - 1L;
+        }
+        if (ui.model == M_INPUT)
+        {
+            for (const UnitInfo &prev : t.units) ui.input_rank += (prev.model == M_INPUT);
+        }
         t.units.push_back(std::move(ui));
     }
     return t;
@@ -283,6 +294,8 @@ sanafe_hip_image MappedChip::image() const
     im.in_train_len = in_train_len.data();
     im.in_rate_period = in_rate_period.data();
     im.in_train_bits = in_train_bits.data();
+    im.n_ext = static_cast<uint32_t>(ext.size());
+    im.slot_ext = ext.empty() ? nullptr : slot_ext.data();
     im.slice_core = slice_core.data();
     im.slice_axon_beg = slice_axon_beg.data();
     im.slice_axon_end = slice_axon_end.data();
@@ -494,6 +507,21 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     std::map<CostKey, uint32_t> cost_ids;
     bool any_delay_dendrite = false;
     std::vector<uint8_t> neuron_dend_kind(N, 0); // 0 buffered accumulator, 1 zero, 2 delay line
+    // InputModel seeds: every unit of every core is constructed up front, cores in id order, units in
+    // template order (src/chip.cpp:83-87), and each `input` instance takes ++counter (src/models.hpp:347).
+    // The counter is process-wide in the reference; this build numbers from a fresh process.
+    std::vector<uint32_t> core_input_base(d.n_cores + 1, 0);
+    for (int c = 0; c < d.n_cores; c++)
+    {
+        uint32_t n_in = 0;
+        for (const UnitInfo &u : tmpl_of(c).units) n_in += (u.model == M_INPUT);
+        core_input_base[c + 1] = core_input_base[c] + n_in;
+    }
+    int32_t random_mask_key = -1;
+    for (int32_t k = 0; k < d.n_strings; k++)
+        if (std::strcmp(d.strings[k], "random_mask") == 0) random_mask_key = k;
+    std::vector<uint32_t> rand_slots; // global slots of all TrueNorth neurons with random_mask != 0
+    std::map<std::pair<int32_t, int>, uint32_t> noise_stream_ids; // (core, unit) -> stream
     for (int64_t gid = 0; gid < N; gid++)
     {
         const int32_t c = d.neuron_core[gid];
@@ -517,6 +545,17 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             neuron_dend_kind[gid] = 2;
         }
         const uint32_t s = mc.slot_of_gid[gid];
+        if (su.model == M_TRUENORTH && random_mask_key >= 0)
+        {
+            // std::rand() is one process-wide sequence (src/models.cpp:757): every rank needs the position of its
+            // neurons among all consumers of the chip
+            long mask = 0;
+            for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+                if (d.neuron_attrs.key[i] == random_mask_key && ((d.neuron_attrs.fwd ? d.neuron_attrs.fwd[i] : 7) & SANAFE_FWD_SOMA) &&
+                        d.neuron_attrs.type[i] == SANAFE_ATTR_INT)
+                    mask = static_cast<long>(d.neuron_attrs.num[i]);
+            if (mask > 0) rand_slots.push_back(s);
+        }
         if (s < SO || s >= SO + LS) continue; // not ours
         const uint32_t ls = s - SO;
         // ---- cost class (src/pipeline.hpp:574-714) ----
@@ -562,6 +601,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         else model = SANAFE_SOMA_HOST;
         std::vector<double> train;
         double rate = 0.0, poisson = 0.0;
+        uint32_t tn_mask = 0;
         for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
         {
             const Attr a{&d.neuron_attrs, i, &d};
@@ -602,7 +642,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 {
                     const int m = a.as_int();
                     if (m < 0) throw std::invalid_argument("random_mask < 0; must be unsigned.");
-                    if (m != 0) throw UnsupportedError("TrueNorth random_mask (libc rand stream) is not implemented on the MI355X backend");
+                    tn_mask = static_cast<uint32_t>(m);
                 }
             }
             else
@@ -649,7 +689,15 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         }
         else if (model == SANAFE_SOMA_INPUT)
         {
-            if (poisson > 0.0) throw UnsupportedError("poisson input (std::mt19937 stream) is not implemented on the MI355X backend");
+            if (poisson > 0.0) // the draw happens at every update; it can only matter when p > 0
+            {
+                MappedChip::ExtColumn col;
+                col.slot = ls;
+                col.kind = MappedChip::ExtColumn::Poisson;
+                col.poisson = poisson;
+                col.seed = core_input_base[c] + static_cast<uint32_t>(su.input_rank) + 1u;
+                mc.ext.push_back(col);
+            }
             mc.slot_aux[ls] = static_cast<uint32_t>(mc.in_train_beg.size());
             const uint32_t beg = static_cast<uint32_t>(mc.in_train_bits.size()) * 32u;
             mc.in_train_beg.push_back(beg);
@@ -667,6 +715,32 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         }
         else
         {
+            if (model == SANAFE_SOMA_TRUENORTH && tn_mask != 0)
+            {
+                MappedChip::ExtColumn col;
+                col.slot = ls;
+                col.kind = MappedChip::ExtColumn::TrueNorthRand;
+                col.mask = tn_mask;
+                mc.ext.push_back(col);
+            }
+            if (model == SANAFE_SOMA_LIF && !su.noise_path.empty())
+            {
+                const auto key2 = std::make_pair(c, soma_unit[gid]);
+                auto sit = noise_stream_ids.find(key2);
+                if (sit == noise_stream_ids.end())
+                {
+                    sit = noise_stream_ids.emplace(key2, static_cast<uint32_t>(mc.noise_streams.size())).first;
+                    MappedChip::NoiseStream ns;
+                    ns.path = su.noise_path;
+                    ns.random_mask = su.noise_random_mask;
+                    mc.noise_streams.push_back(ns);
+                }
+                MappedChip::ExtColumn col;
+                col.slot = ls;
+                col.kind = MappedChip::ExtColumn::LifNoise;
+                col.stream = sit->second;
+                mc.ext.push_back(col);
+            }
             ClassKey key;
             std::memset(&key, 0, sizeof(key));
             sanafe_hip_soma_class canon{};
@@ -705,6 +779,21 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         });
         std::vector<uint32_t> next(mc.host_units.size(), 0);
         for (size_t i : idx) mc.host_neurons[i].addr = next[mc.host_neurons[i].unit]++;
+    }
+    if (!mc.ext.empty())
+    {
+        // columns in slot order: the order the reference's sweep reaches the neurons (core id, map order)
+        std::sort(mc.ext.begin(), mc.ext.end(), [](const MappedChip::ExtColumn &a, const MappedChip::ExtColumn &b) { return a.slot < b.slot; });
+        std::sort(rand_slots.begin(), rand_slots.end());
+        mc.n_rand_global = rand_slots.size();
+        mc.slot_ext.assign(LS, 0xffffffffu);
+        for (size_t k = 0; k < mc.ext.size(); k++)
+        {
+            MappedChip::ExtColumn &col = mc.ext[k];
+            mc.slot_ext[col.slot] = static_cast<uint32_t>(k);
+            if (col.kind == MappedChip::ExtColumn::TrueNorthRand)
+                col.rand_index = static_cast<uint64_t>(std::lower_bound(rand_slots.begin(), rand_slots.end(), col.slot + SO) - rand_slots.begin());
+        }
     }
     if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});

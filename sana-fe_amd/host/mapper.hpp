@@ -60,6 +60,28 @@ struct MappedChip
     std::vector<double> slot_bias, slot_v0, slot_e_net, slot_e_syn, slot_e_dend;
     std::vector<uint32_t> in_train_beg, in_train_len, in_train_bits;
     std::vector<int64_t> in_rate_period;
+    // ---- external per-step value streams (include/sanafe_hip.h: slot_ext, sanafe_hip_write_ext) ----
+    // One column per neuron that consumes a sequential host-side source at every update.
+    struct ExtColumn
+    {
+        enum Kind : uint8_t { Poisson = 1, TrueNorthRand = 2, LifNoise = 3 };
+        uint32_t slot{0};          // local slot
+        uint8_t kind{0};
+        double poisson{0.0};       // InputModel::poisson_probability
+        uint32_t seed{0};          // std::mt19937 seed of the unit instance (src/models.hpp:347)
+        uint32_t mask{0};          // TrueNorth random_range_mask
+        uint64_t rand_index{0};    // position of the neuron among ALL rand()-consuming neurons of the chip
+        uint32_t stream{0};        // LIF noise: index into noise_streams
+    };
+    struct NoiseStream // one per (core, LIF unit with a `noise` file): every instance opens its own stream
+    {
+        std::string path;
+        long random_mask{0x7f}, sign_mask{0x100}; // src/models.hpp:271-272, src/models.cpp:367-371
+    };
+    std::vector<ExtColumn> ext;        // in column order == ascending slot
+    std::vector<uint32_t> slot_ext;    // [n_slots] column or 0xffffffff; empty when there is no column
+    std::vector<NoiseStream> noise_streams;
+    uint64_t n_rand_global{0};         // rand() calls per timestep on the whole chip
     uint32_t ring_slots{1};
     std::vector<uint32_t> slice_core;
     std::vector<uint64_t> slice_axon_beg, slice_axon_end, core_syn_base;

@@ -26,7 +26,8 @@ def _f(**kw):
     return {k: float(v) for k, v in kw.items()}
 
 
-def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared, n_inputs=1024):
+def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared, n_inputs=1024, noise_file=None,
+                noise_bits=None):
     core = arch.create_core("loihi_core[%d]" % idx, tile_id, buffer_position, buffer_inside_unit, 1024,
                             share_units_with=shared.get("c"))
     if "c" in shared:
@@ -43,6 +44,14 @@ def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared,
     core.create_soma("loihi_lif", "leaky_integrate_fire",
                      _f(energy_access_neuron=51.2e-12, latency_access_neuron=6.0e-9, energy_update_neuron=21.6e-12,
                         latency_update_neuron=3.7e-9, energy_spike_out=69.3e-12, latency_spike_out=30.0e-9))
+    if noise_file is not None:
+        # arch/loihi_with_noise.yaml:46-61 (its `noise:` path is private to the authors' machine; pass your own)
+        at = _f(energy_access_neuron=51.2e-12, latency_access_neuron=6.0e-9, energy_update_neuron=27.6e-12,
+                latency_update_neuron=3.7e-9, energy_spike_out=69.3e-12, latency_spike_out=30.0e-9)
+        at["noise"] = str(noise_file)
+        if noise_bits is not None:
+            at["noise_bits"] = int(noise_bits)
+        core.create_soma("loihi_stochastic_lif", "leaky_integrate_fire", at)
     zero = _f(energy_access_neuron=0.0, latency_access_neuron=0.0, energy_update_neuron=0.0, latency_update_neuron=0.0,
               energy_spike_out=0.0, latency_spike_out=0.0)
     for i in range(n_inputs):
@@ -51,14 +60,15 @@ def _loihi_core(arch, tile_id, idx, buffer_position, buffer_inside_unit, shared,
     return core
 
 
-def loihi(n_inputs=1024, api=None):
-    """arch/loihi.yaml: 8x4 mesh, 32 tiles x 4 cores, buffer before soma."""
+def loihi(n_inputs=1024, api=None, noise_file=None, noise_bits=None):
+    """arch/loihi.yaml: 8x4 mesh, 32 tiles x 4 cores, buffer before soma.  With ``noise_file`` the cores also get the
+    `loihi_stochastic_lif` soma of arch/loihi_with_noise.yaml reading that file."""
     arch = _api(api).Architecture("loihi_chip", 8, 4, 16, _LOIHI_SYNC)
     shared = {}
     for t in range(32):
         tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
         for c in range(4):
-            _loihi_core(arch, tile.id, c, "soma", False, shared, n_inputs)
+            _loihi_core(arch, tile.id, c, "soma", False, shared, n_inputs, noise_file, noise_bits)
     return arch
 
 

@@ -19,6 +19,7 @@ class ImageEmulator:
         self.valid = np.zeros((self.R, n), dtype=bool)
         self.in_pos = np.zeros(max(1, im["n_input"]), dtype=np.int64)
         self.t = 0
+        self.ext_next = 0
         cls = im["slot_cls"]
         self.model = cls & 7
         self.inkind = (cls >> 3) & 7
@@ -53,6 +54,16 @@ class ImageEmulator:
         self.valid[rs][buf] = False
         bias = im["slot_bias"]
         sc = im["soma_classes"]
+        # external value streams: one row per step (sanafe_hip_write_ext); stepping past the rows is an error
+        has_ext = np.zeros(n, dtype=bool)
+        ext = np.zeros(n, dtype=np.int64)
+        if im.get("n_ext", 0):
+            rows = im["ext_rows"]
+            if self.ext_next >= len(rows):
+                raise RuntimeError("external value streams exhausted")
+            has_ext = im["slot_ext"] != 0xffffffff
+            ext[has_ext] = rows[self.ext_next][im["slot_ext"][has_ext]]
+            self.ext_next += 1
 
         def col(name):
             return np.array([c[name] for c in sc])[np.minimum(self.pcls, len(sc) - 1)]
@@ -67,6 +78,7 @@ class ImageEmulator:
                     ic = ic * col("input_decay")
                     v = v * col("leak_decay")
                 v = self._cvt(v * 64.0) / 64.0
+                v = np.where(has_ext, v + ext, v)
                 active = ~(rc > 0)
                 v2 = v + bias
                 ic2 = ic + np.where(has_in, cur, 0.0)
@@ -97,8 +109,9 @@ class ImageEmulator:
                 v = np.where(has_in, v + cur, v)
                 th, rth = col("threshold"), col("reverse_threshold")
                 rm, rrm = col("reset_mode"), col("reverse_reset_mode")
-                fired = v >= th
-                low = (~fired) & (v <= rth)
+                vt = np.where(has_ext, v + ext, v)
+                fired = vt >= th
+                low = (~fired) & (vt <= rth)
                 vf = np.where(rm == 2, col("reset"), np.where(rm == 1, v - th, np.where(rm == 3, th, v)))
                 vl = np.where(rrm == 2, col("reverse_reset"), np.where(rrm == 1, v + rth, np.where(rrm == 3, rth, v)))
                 v = np.where(fired, vf, np.where(low, vl, v))
@@ -114,6 +127,8 @@ class ImageEmulator:
                 b = int(im["in_train_beg"][a]) + int(pos)
                 send = bool((int(im["in_train_bits"][b >> 5]) >> (b & 31)) & 1)
                 self.in_pos[a] = pos + 1
+            if ext[g] != 0:
+                send = True
             period = im["in_rate_period"][a]
             if period > 0 and t % period == 0:
                 send = True

@@ -156,6 +156,59 @@ def truenorth_net(S, n_tiles=16, neurons_per_core=256, remote_fraction=0.8, seed
     return arch, net
 
 
+def stochastic(S, tmp_path, n_lif=96, n_in=6, n_tn=0, seed=9, noise_bits=None):
+    """Every sequential host-side source the models consume: Poisson inputs
+    (std::mt19937 per input unit), LIF neurons on a soma unit that reads a noise file, spread over several cores."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    noise = os.path.join(str(tmp_path), "noise.csv")
+    vals = rng.integers(0, 512, size=157)
+    with open(noise, "w") as f:
+        for i, v in enumerate(vals):
+            f.write("%d\n" % v if i != 40 else "oops\n")  # an entry that does not parse reads as 0
+    arch = S.presets.loihi(n_inputs=8, api=S.description, noise_file=noise, noise_bits=noise_bits)
+    cores = arch.cores()
+    net = D.Network("stoch")
+    gin = net.create_neuron_group("in", n_in, {}, "loihi_sparse_synapse", "loihi_dendrites", False, True)
+    for i in range(n_in):
+        attrs = {"poisson": ((D.ATTR_DOUBLE, 0.15 + 0.1 * i, None, None), D.FWD_ALL)}
+        if i == 1:
+            attrs["spikes"] = ((D.ATTR_LIST, 0.0, None, [0.0, 1.0, 1.0, 0.0, 1.0]), D.FWD_ALL)
+        gin.apply_config(i, i + 1, soma_hw_name="loihi_inputs[%d]" % (i % 3), attrs=attrs)
+    g = net.create_neuron_group("lif", n_lif, {"threshold": 90, "reset": 0, "leak_decay": 0.9, "refractory_delay": 1},
+                                "loihi_sparse_synapse", "loihi_dendrites", True, True, "loihi_stochastic_lif")
+    plain = net.create_neuron_group("plain", 16, {"threshold": 20, "reset": 0}, "loihi_sparse_synapse", "loihi_dendrites",
+                                    False, True, "loihi_lif")
+    pairs = np.stack([rng.integers(0, n_in, size=400), rng.integers(0, n_lif, size=400)], axis=1)
+    gin.connect_neurons_sparse(g, {"weight": rng.integers(1, 30, size=400).astype(np.float64)}, pairs, narrow_float=False)
+    pairs = np.stack([rng.integers(0, n_lif, size=300), rng.integers(0, 16, size=300)], axis=1)
+    g.connect_neurons_sparse(plain, {"weight": rng.integers(1, 9, size=300).astype(np.float64)}, pairs, narrow_float=False)
+    # inputs: two per core on cores 0..2 (each input unit holds one neuron); stochastic LIF over 3 cores
+    for i in range(n_in):
+        gin.map_to_core(cores[i // 3 + 5 * (i % 3 == 2)], i, i + 1)
+    third = n_lif // 3
+    g.map_to_core(cores[1], 0, third)
+    g.map_to_core(cores[0], third, 2 * third)
+    g.map_to_core(cores[7], 2 * third, n_lif)
+    plain.map_to_core(cores[1], 0, 16)
+    return arch, net
+
+
+def stochastic_truenorth(S, n_tiles=6, neurons_per_core=64, seed=2):
+    """TrueNorth neurons whose threshold test adds `std::rand() & random_mask` (src/models.cpp:745-759)."""
+    D = S.description
+    arch, net = truenorth_net(S, n_tiles=n_tiles, neurons_per_core=neurons_per_core, seed=seed)
+    g = net._order[0]
+    rng = np.random.default_rng(seed)
+    n = g.count
+    mask = np.where(rng.random(n) < 0.6, rng.choice([1, 3, 7, 15, 255], size=n), 0).astype(np.int64)
+    g.set_attribute_column("random_mask", mask, D.ATTR_INT)
+    g.set_attribute_column("threshold", rng.integers(2, 12, size=n).astype(np.int64), D.ATTR_INT)
+    g.set_attribute_column("leak", np.ones(n, dtype=np.int64), D.ATTR_INT)
+    g.set_attribute_column("leak_towards_zero", np.zeros(n, dtype=np.int64), D.ATTR_INT)
+    return arch, net
+
+
 def hh_plugin_path():
     return os.path.join(os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0], "sana-fe_amd", "plugins",
                         "libhodgkin_huxley.so")

@@ -136,6 +136,31 @@ def test_detailed_scheduler_threads_match_inline(S):
     assert a["sim_time"] == total
 
 
+def _srand1():
+    import ctypes
+    ctypes.CDLL(None).srand(1)  # the oracle draws from the process-wide std::rand(), like the reference
+
+
+def test_poisson_inputs_and_lif_noise_file(S, tmp_path):
+    """Rows a22/a24 on the GPU: host-generated value streams (std::mt19937 Poisson draws, LIF noise file)."""
+    arch, net = nets.stochastic(S, tmp_path)
+    check_stepwise(S, arch, net, steps=150)
+
+
+def test_truenorth_random_mask(S):
+    """Row a23 on the GPU: `std::rand() & random_mask` in the TrueNorth threshold test."""
+    _srand1()
+    check_stepwise(S, *nets.stochastic_truenorth(S), steps=40)
+
+
+def test_value_streams_batched_in_chunks(S, tmp_path, monkeypatch):
+    """A batched run uploads the value streams in chunks; totals and spikes equal the step-by-step run."""
+    monkeypatch.setenv("SANAFE_EXT_CHUNK_STEPS", "7")
+    arch, net = nets.stochastic(S, tmp_path)
+    chip, orc, tot = check_batched(S, arch, net, steps=45)
+    assert tot["neurons_fired"] > 0
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

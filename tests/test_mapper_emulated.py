@@ -12,9 +12,13 @@ INT_KEYS = (("spikes", "spike_count"), ("packets_sent", "packets_sent"), ("neuro
 DBL_KEYS = ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy", "network_energy", "sim_time")
 
 
-def compare(S, arch, net, steps, exact_v=True):
-    im, slot_of = S.map_only(arch, net)
+def compare(S, arch, net, steps, exact_v=True, ext=False):
+    im, slot_of = S.map_only(arch, net, ext_steps=steps if ext else 0)
     emu = ImageEmulator(im)
+    if ext:
+        import ctypes
+        ctypes.CDLL(None).srand(1)  # the oracle (like the reference) draws from the process-wide std::rand()
+        assert im["n_ext"] > 0
     orc = OracleChip(S.to_desc(arch, net))
     for t in range(steps):
         a, b = emu.step(), orc.step("simple")
@@ -92,3 +96,54 @@ def test_image_independent_of_mapper_thread_count(S, monkeypatch):
                 assert np.array_equal(v, im[k]), k
             else:
                 assert v == im[k], k
+
+
+def test_poisson_inputs_and_lif_noise_file(S, tmp_path):
+    """Rows a22/a24: std::mt19937 Poisson draws per input unit (seeded by construction order) and the LIF noise
+    file, both generated on the host as per-step value streams."""
+    arch, net = nets.stochastic(S, tmp_path)
+    compare(S, arch, net, steps=400, ext=True)
+
+
+def test_lif_noise_bits(S, tmp_path):
+    arch, net = nets.stochastic(S, tmp_path, noise_bits=4)
+    compare(S, arch, net, steps=60, ext=True)
+
+
+def test_truenorth_random_mask(S):
+    """Row a23: `std::rand() & random_mask` in the threshold test; the glibc sequence is restated on the host."""
+    arch, net = nets.stochastic_truenorth(S)
+    compare(S, arch, net, steps=50, ext=True)
+
+
+def test_truenorth_random_mask_two_ranks(S):
+    """rand() is one sequence for the whole chip: each rank skips the draws of the other ranks' neurons."""
+    arch, net = nets.stochastic_truenorth(S)
+    im, slot_of = S.map_only(arch, net, ext_steps=5)
+    parts = [S.map_only(arch, net, n_ranks=2, rank=r, ext_steps=5)[0] for r in range(2)]
+    assert parts[0]["n_ext"] + parts[1]["n_ext"] == im["n_ext"] > 0
+    joined = np.concatenate([parts[0]["ext_rows"], parts[1]["ext_rows"]], axis=1)
+    assert np.array_equal(joined, im["ext_rows"])
+
+
+def test_missing_noise_file_fails_the_load(S, tmp_path):
+    arch, net = nets.stochastic(S, tmp_path)
+    import os
+    os.remove(os.path.join(str(tmp_path), "noise.csv"))
+    with pytest.raises(RuntimeError, match="Failed to open noise stream"):
+        S.map_only(arch, net)
+
+
+def test_host_rand_matches_libc():
+    """The private restatement of glibc's rand() yields the sequence the reference's std::rand() does (seed 1)."""
+    import ctypes
+    libc = ctypes.CDLL(None)
+    libc.srand(1)
+    expect = [libc.rand() for _ in range(2000)]
+    import _sanafe_pkg
+    S = _sanafe_pkg.load()
+    L = S.chip.lib()
+    out = np.zeros(2000, dtype=np.uint32)
+    L.sanafe_test_glibc_rand.argtypes = [ctypes.c_uint32, ctypes.c_int64, ctypes.c_void_p]
+    L.sanafe_test_glibc_rand(1, 2000, out.ctypes.data)
+    assert out.tolist() == expect
