@@ -55,6 +55,63 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
     return arch, net
 
 
+def build_c2(S):
+    """BASELINE configs[1]: arch/loihi.yaml + snn/dvs.yaml (18 678 neurons, 3.56 M synapses), rebuilt from the
+    committed fixture tests/golden/dvs_yaml.npz (the reference tree does not travel to the GPU box)."""
+    import nets
+    arch, net = nets.dvs_yaml(S)
+    return arch, net
+
+
+def build_c4(S, n_gpus, rank, tiles_per_gpu, seed):
+    """BASELINE configs[3]: arch/truenorth.yaml + synthetic TrueNorth SNN (recipe after
+    scripts/tcad2025/compare_nemo_perf.py:52-101): 256 `truenorth` neurons per core, threshold 0,
+    reset -1, leak 0, force_update, weight 1, one out-edge per neuron, 80 % of them to another core."""
+    n_tiles = tiles_per_gpu * n_gpus
+    w = 64 if n_tiles % 64 == 0 else int(np.ceil(np.sqrt(n_tiles)))
+    arch = S.presets.truenorth(n_tiles=n_tiles, width=w, height=(n_tiles + w - 1) // w)
+    cores = arch.cores()
+    npc = 256
+    n = n_tiles * npc
+    net = S.Network("tn")
+    g = net.create_neuron_group("tn", n, {"threshold": 0, "reset": -1, "leak": 0, "force_update": True},
+                                "core_synapses", "core_dendrites", False, True, "core_soma")
+    rng = np.random.default_rng(seed)
+    src = np.arange(n, dtype=np.int64)
+    core_of = src // npc
+    remote = rng.random(n) < 0.8
+    dst_core = np.where(remote, (core_of + 1 + rng.integers(0, max(1, n_tiles - 1), size=n)) % n_tiles, core_of)
+    dst = dst_core * npc + rng.integers(0, npc, size=n)
+    if n_gpus > 1:  # a rank only needs the edges that start or end in its own tiles
+        lo, hi = rank * tiles_per_gpu * npc, (rank + 1) * tiles_per_gpu * npc
+        keep = ((src >= lo) & (src < hi)) | ((dst >= lo) & (dst < hi))
+        src, dst = src[keep], dst[keep]
+    net.add_edges(src, dst, np.ones(len(src)), "core_synapses")
+    for c in range(n_tiles):
+        g.map_to_core(cores[c], c * npc, (c + 1) * npc)
+    return arch, net
+
+
+def cpu_baseline_same_net(S, args, arch, net, what):
+    """The oracle on the very network the GPU ran (small configurations), for about --cpu-seconds."""
+    from oracle.oracle import OracleChip
+    lower = S.cpp.to_desc if isinstance(net, S.cpp.Network) else S.to_desc
+    chip = OracleChip(lower(arch, net))
+    timing = args.timing
+    for _ in range(3):
+        chip.step(timing)
+    steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < args.cpu_seconds:
+        r = chip.step(timing)
+        steps += 1
+        events += r["spike_count"]
+        updates += r["neurons_updated"]
+    dt = time.perf_counter() - t0
+    return {"value": steps / dt, "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": "oracle (scalar C++ port, 1 thread), %s timing, on %s: %d steps in %.1f s" % (timing, what, steps, dt),
+            "measured": {"synaptic_events_per_s": events / dt, "neuron_updates_per_s": updates / dt}}
+
+
 def cpu_baseline(S, args):
     """The oracle (a scalar CPU port of the reference loop) on a bounded sample of the same recipe."""
     import nets  # noqa: F401
@@ -93,6 +150,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=("c3", "c2", "c4"), default="c3",
+                    help="c3 (default, the bench line of record): loihi_large + 256k-neuron random SNN per GPU; "
+                         "c2: loihi + dvs.yaml (1 GPU); c4: truenorth + 256 neurons x --tiles-per-gpu tiles per GPU")
+    ap.add_argument("--tiles-per-gpu", type=int, default=4096, help="c4: TrueNorth tiles (= cores) per GPU")
+    ap.add_argument("--timing", choices=("simple", "detailed"), default="simple",
+                    help="detailed: NoC schedule on host scheduler threads (1 GPU; reported, not the line of record)")
+    ap.add_argument("--scheduler-threads", type=int, default=8)
     ap.add_argument("--cores-per-gpu", type=int, default=512)
     ap.add_argument("--neurons-per-core", type=int, default=512)
     ap.add_argument("--out-degree", type=int, default=2621)
@@ -125,8 +189,25 @@ def main():
     S = _sanafe_pkg.load()
 
     t_setup = time.perf_counter()
-    arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire, args.seed,
-                               rank)
+    if args.workload == "c2":
+        if world > 1:
+            raise SystemExit("workload c2 is a single-GPU configuration")
+        arch, net = build_c2(S)
+        n_total = 18678
+        workload = "arch/loihi.yaml + snn/dvs.yaml (BASELINE configs[1]): 18678 LIF neurons on 49 cores, 3564441 synapses"
+    elif args.workload == "c4":
+        arch, net = build_c4(S, world, rank, args.tiles_per_gpu, args.seed)
+        n_total = args.tiles_per_gpu * 256 * world
+        workload = ("arch/truenorth.yaml + synthetic TrueNorth SNN (BASELINE configs[3]): %d neurons (%d tiles x 256 per GPU), "
+                    "one out-edge per neuron, 80%% remote" % (n_total, args.tiles_per_gpu))
+    else:
+        arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire,
+                                   args.seed, rank)
+        n_total = args.cores_per_gpu * args.neurons_per_core * world
+        workload = ("arch/loihi_large.yaml + synthetic random SNN (BASELINE configs[2]): %d LIF neurons (%d cores x %d per "
+                    "GPU), out-degree %d, %.0f%% biased to fire every step, loihi_dendrites_delay"
+                    % (n_total, args.cores_per_gpu, args.neurons_per_core, args.out_degree, 100 * args.p_fire))
+    workload += ", %s timing" % args.timing
     t_net = time.perf_counter() - t_setup
     chip = S.SpikingChip(arch, device=0 if args.same_device else local_rank, n_ranks=world, rank=rank)
     chip.load(net)
@@ -182,6 +263,17 @@ def main():
 
         def sync():
             torch.cuda.synchronize()
+    elif args.timing == "detailed":
+        L = S.chip.lib()
+        L.sanafe_chip_set_scheduler_threads(chip._h, args.scheduler_threads)
+
+        def run_steps(k):
+            # GPU steps + host NoC schedule on scheduler threads; returns when both are done.  The stepwise
+            # loop restarts the device totals every step, so the counts come from the returned RunData.
+            return chip.run(k, "detailed")
+
+        def sync():
+            chip.synchronize()
     else:
         def run_steps(k):
             if H.sanafe_hip_step(dev, k, 1, 0) != 0:
@@ -197,13 +289,15 @@ def main():
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    run_steps(args.steps)
+    run_data = run_steps(args.steps)
     sync()
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     after = chip.read_totals()
     local = {k: after[k] - before[k] for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")}
+    if run_data is not None:
+        local = {k: run_data[k] for k in local}
     if dist:
         import torch
         t = torch.tensor([elapsed] + [float(local[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")],
@@ -244,7 +338,7 @@ def main():
                                "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
 
     cpu = None
-    if rank == 0 and not multi and not args.no_cpu_baseline:
+    if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3" and args.timing == "simple":
         c = cpu_baseline(S, args)
         events_per_step = agg["spikes"] / args.steps
         est = c["events_per_s"] / events_per_step if events_per_step > 0 else c["steps_per_s"]
@@ -254,19 +348,21 @@ def main():
                "measured": {"timesteps_per_s_on_sample": c["steps_per_s"], "synaptic_events_per_s": c["events_per_s"],
                             "neuron_updates_per_s": c["updates_per_s"]}}
 
+    if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c2":
+        cpu = cpu_baseline_same_net(S, args, arch, net, "the same network")
+    if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c4":
+        a2, n2 = build_c4(S, 1, 0, 256, args.seed)
+        cpu = cpu_baseline_same_net(S, args, a2, n2, "a 256-tile (65536-neuron) sample of the same recipe")
+        cpu["value"] *= 256.0 / (args.tiles_per_gpu * world)  # per-step cost of this recipe is linear in tiles
+        cpu["sample"] += "; value scaled by 256 / %d tiles" % (args.tiles_per_gpu * world)
     if rank == 0:
-        n_total = args.cores_per_gpu * args.neurons_per_core * world
         out = {
             "metric": "simulated timesteps/sec", "value": args.steps / elapsed, "unit": "timesteps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "arch/loihi_large.yaml + synthetic random SNN (BASELINE configs[2]): %d LIF neurons "
-                                   "(%d cores x %d per GPU), out-degree %d, %.0f%% biased to fire every step, "
-                                   "loihi_dendrites_delay, simple timing" % (n_total, args.cores_per_gpu,
-                                                                             args.neurons_per_core, args.out_degree,
-                                                                             100 * args.p_fire),
+            "config": {"workload": workload,
                        "neurons": n_total, "synapses_per_gpu": int(info["n_synapses"]), "axons_per_gpu": int(info["n_axons"]),
-                       "timing_model": "simple",
+                       "timing_model": args.timing,
                        "exchange": ("rccl all_gather of spike bitmaps" if args.exchange == "nccl" else "gloo via host") if world > 1 else "none"},
             "totals_in_timed_region": agg,
             "neuron_updates_per_s": agg["neurons_updated"] / elapsed,

@@ -194,6 +194,10 @@ int sanafe_hip_step(sanafe_hip_chip *chip, int64_t n_steps, int simple_timing, i
  * fails with SANAFE_HIP_ERR_INVALID (no default values are invented). */
 int sanafe_hip_write_ext(sanafe_hip_chip *chip, int64_t n_steps, const int32_t *values);
 int sanafe_hip_synchronize(sanafe_hip_chip *chip);
+/* How the image was packed for the device (diagnostics, tests): synapse format 0 = 2+1 bytes (12-bit post,
+ * int8 weight), 1 = 4 bytes (12-bit integer weight), 2 = 4+8 bytes (fp64 weight); number of delivery slices
+ * whose axon records use the 2-byte delta form instead of the 8-byte form. */
+int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_compact_slices);
 
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)
  * soma units: neurons -> [exchange spike bitmaps] -> deliver. */

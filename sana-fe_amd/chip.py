@@ -435,6 +435,15 @@ class SpikingChip:
         return self._L.sanafe_chip_get_power(self._h)
 
     # -- multi-GPU split step ------------------------------------------------------------------
+    def device_layout(self):
+        """(synapse format, compact axon slices) the device image was packed with (sanafe_hip_get_layout)."""
+        H = hip_lib()
+        fmt, n = C.c_int(), C.c_uint32()
+        H.sanafe_hip_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
+        if H.sanafe_hip_get_layout(self.device_handle(), C.byref(fmt), C.byref(n)) != 0:
+            raise RuntimeError(H.sanafe_hip_last_error().decode())
+        return {"syn_format": fmt.value, "n_compact_slices": n.value}
+
     def step_neurons(self):
         self._check(self._L.sanafe_chip_step_neurons(self._h))
 

@@ -28,11 +28,15 @@
 // reference's scalar C++ (no fused multiply-add).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sanafe_hip.h"
@@ -91,15 +95,31 @@ struct DevImage
     const uint32_t *slice_core;
     const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
     const uint32_t *core_slice_beg; // [n_cores+1]
-    // Device layout of the inbound axons: one 8-byte record per axon, streamed once per step
-    //   bits 0-31 pre-synaptic GLOBAL slot | 32-47 synapse count | 48-55 latency class (255: read ax_proc_delay)
-    const unsigned long long *ax_rec;
-    const uint32_t *ax_syn_beg;   // first synapse (relative to the core); read once per 256-axon chunk
+    // Device layout of the inbound axons, chosen per delivery slice (slice_mode):
+    //   wide    8 bytes/axon: bits 0-31 pre-synaptic GLOBAL slot | 32-47 synapse count | 48-55 latency class
+    //           (255: read ax_proc_delay)
+    //   compact 2 bytes/axon: bits 0-7 pre slot minus the previous axon's pre slot (0 for the first axon of a
+    //           256-axon chunk, whose pre slot is chunk_pre0) | 8-15 synapse count; one latency class per slice.
+    //           Used when the slice's axons are dense in pre-slot order (gaps < 256), have < 256 synapses each
+    //           and share a latency class -- the normal case of a large recurrent network.
+    const unsigned char *ax_bytes;            // all slices' records, each slice 16-byte aligned
+    const unsigned long long *slice_rec_off;  // [n_slices] byte offset of the slice's records
+    const uint8_t *slice_mode;                // [n_slices] 0 wide, 1 compact
+    const uint8_t *slice_lat_class;           // [n_slices] latency class of a compact slice
+    const uint32_t *slice_chunk0;             // [n_slices] first entry of the slice in the chunk tables
+    const uint32_t *chunk_syn0;               // per 256-axon chunk: first synapse (relative to the core)
+    const uint32_t *chunk_pre0;               // per 256-axon chunk: pre slot of its first axon
     const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
     const double *lat_class;      // [256] per-event latency of each class
-    // synapses: post (16b) | delay (3b) << 16 | drop << 19 | [packed weights: 12-bit signed weight << 20]
-    const uint32_t *syn_meta;
-    const double *syn_weight;     // NULL when the weights are packed into syn_meta
+    // Synapses, one of three formats (chip-wide):
+    //   0: 4 bytes      post (12b) | delay (3b) << 12 | drop << 15 | axon code (8b) << 16 | int8 weight << 24
+    //                   axon code = ((a & 3) << 6) | (a >> 2), a = index of the synapse's axon inside its 256-axon
+    //                   chunk: lets a chunk with many spikes be STREAMED (every synapse word read once, in order,
+    //                   fired or not decided from the word itself) instead of gathered
+    //   1: 4 bytes      post (16b) | delay (3b) << 16 | drop << 19 | 12-bit signed weight << 20
+    //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64
+    const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
+    const double *syn_weight;
 };
 
 struct DevState
@@ -400,16 +420,21 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
 constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
 constexpr int EXPAND_UNROLL = 4;
 constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bitmap
+constexpr int STREAM_DEPTH = 4;             // 16-byte groups per lane in flight in the stream path
+constexpr uint32_t STREAM_MIN_ACTIVE = 16; // spiking axons in a 256-axon chunk from which streaming beats gathering
+constexpr unsigned long long ACC_UNTOUCHED = 0x8000000000000000ull; // -0.0: no sum of additions yields it
 
+// Inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips): Hillis-Steele inside each
+// 16-lane row (row_shr 1/2/4/8), then row_bcast:15 carries a row's total into the next row (rows 1 and 3) and
+// row_bcast:31 the first half's total into rows 2 and 3.  Lanes without a source read `old` = 0.
 __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
 {
-    const int lane = threadIdx.x & (WAVE - 1);
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1)
-    {
-        const uint32_t y = __shfl_up(x, o, WAVE);
-        if (lane >= o) x += y;
-    }
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
     return x;
 }
 
@@ -424,11 +449,11 @@ __device__ __forceinline__ void wave_lds_fence()
 
 extern __shared__ __align__(16) unsigned char deliver_lds[];
 
-template <bool PACKED_W>
+template <int SYN_FMT, bool HAS_DELAY>
 __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
-    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE_CHUNK + 4];  // lane-local event prefixes, then the head bitmap (+2 guard words)
+    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE + 4];        // head bitmap of the event window (+2 guard words)
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
@@ -438,31 +463,63 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
     const uint32_t npad = (ncount + 63u) & ~63u;
     const uint32_t nbase = im.core_nbase[core];
     const uint32_t R = im.ring_slots;
-    const uint32_t D = im.delay_slots; // LDS holds one accumulator row per delay value in use
+    const uint32_t D = HAS_DELAY ? im.delay_slots : 1u; // LDS holds one accumulator row per delay value in use
+    // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
+    // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
+    const uint32_t RS = (SYN_FMT == 0) ? npad + 1u : npad;
     const long long t = *st.t + 1;
-    const unsigned long long a_beg = im.slice_axon_beg[slice], a_end = im.slice_axon_end[slice];
+    const unsigned long long a_beg = im.slice_axon_beg[slice];
+    const uint32_t n_ax = (uint32_t) (im.slice_axon_end[slice] - a_beg); // slices hold < 2^32 axons
     const unsigned long long syn_base = im.core_syn_base[core];
     const double ain_lat = im.core_axon_in_latency[core];
+    const bool compact = im.slice_mode[slice] != 0; // workgroup-uniform
+    const unsigned char *rec = im.ax_bytes + im.slice_rec_off[slice];
+    const uint32_t *chunk_syn0 = im.chunk_syn0 + im.slice_chunk0[slice];
+    const uint32_t *chunk_pre0 = im.chunk_pre0 + im.slice_chunk0[slice];
+    const double slice_lat = im.lat_class[im.slice_lat_class[slice]];
     double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
-    uint8_t *touched = deliver_lds + (size_t) im.delay_slots * im.max_core_slots * sizeof(double); // [D][npad]
+    // Which accumulators received a synaptic event (the buffer holds a value, even a zero one: src/chip.cpp:759)?
+    // Integer-weight formats start every accumulator at -0.0, which no addition of weights can produce again;
+    // fp64 weights (format 2) could be -0.0 themselves and keep a byte per accumulator instead.
+    constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
+    uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
 
-    for (uint32_t i = threadIdx.x; i < D * npad; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
     {
-        acc[i] = 0.0;
-        touched[i] = 0;
+        if (TOUCH_BYTES)
+        {
+            acc[i] = 0.0;
+            touched[i] = 0;
+        }
+        else
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = ACC_UNTOUCHED;
+        }
     }
     __syncthreads();
 
     double proc = 0.0;
     const uint32_t *bits = st.bits_global;
-    constexpr unsigned long long NONE = ~0ull; // "past the end of the slice"
-    // the 4 consecutive axon records of this lane (two 16-byte loads when aligned)
-    auto load4 = [&](unsigned long long a0, unsigned long long (&r)[AX_PER_THREAD]) {
-        if (a0 + AX_PER_THREAD <= a_end && ((a0 & 1ull) == 0))
+    constexpr unsigned long long NONE = ~0ull; // wide record "past the end of the slice"
+    // The 4 consecutive axon records of this lane.  Wide: two 16-byte loads (r[0..3]).  Compact: one 8-byte
+    // load, kept in r[0] (4 x 16 bits; records past the end read as 0 = no synapses, no advance).
+    auto load4 = [&](uint32_t a0, unsigned long long (&r)[AX_PER_THREAD]) {
+        if (compact)
         {
-            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(im.ax_rec + a0);
-            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(im.ax_rec + a0 + 2);
+            unsigned long long q = 0;
+            if (a0 + AX_PER_THREAD <= n_ax) q = *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0);
+            else
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                    if (a0 + k < n_ax) q |= (unsigned long long) *reinterpret_cast<const uint16_t *>(rec + 2ull * (a0 + k)) << (16 * k);
+            r[0] = q;
+            return;
+        }
+        const unsigned long long *wide = reinterpret_cast<const unsigned long long *>(rec);
+        if (a0 + AX_PER_THREAD <= n_ax)
+        {
+            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(wide + a0);
+            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(wide + a0 + 2);
             r[0] = lo.x;
             r[1] = lo.y;
             r[2] = hi.x;
@@ -470,37 +527,167 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
             return;
         }
 #pragma unroll
-        for (int k = 0; k < AX_PER_THREAD; k++) r[k] = (a0 + k < a_end) ? im.ax_rec[a0 + k] : NONE;
+        for (int k = 0; k < AX_PER_THREAD; k++) r[k] = (a0 + k < n_ax) ? wide[a0 + k] : NONE;
     };
-    const unsigned long long stride = (unsigned long long) (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
-    unsigned long long c0 = a_beg + (unsigned long long) wave * WAVE_CHUNK;
-    unsigned long long cur[AX_PER_THREAD] = {NONE, NONE, NONE, NONE};
-    if (c0 < a_end) load4(c0 + (unsigned long long) lane * AX_PER_THREAD, cur);
-    for (; c0 < a_end; c0 += stride)
+    // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.  A wave whose
+    // previous chunk streamed ("hot") starts the loads of the next chunk before it knows which axons spiked.
+    bool hot = false;
+    uint4 sq[STREAM_DEPTH];
+    const uint4 *st_src = nullptr;
+    uint32_t st_groups = 0;
+    constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
+    uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // axon offset of the chunk inside the slice
+    auto stream_preload = [&]() {
+        const uint32_t ci = c0 / WAVE_CHUNK;
+        const uint32_t s0 = chunk_syn0[ci];
+        st_groups = (chunk_syn0[ci + 1] - s0) >> 2; // chunks are 16-byte aligned and padded (format 0)
+        st_src = reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
+#pragma unroll
+        for (int u = 0; u < STREAM_DEPTH; u++)
+        {
+            const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
+            if (g < st_groups) sq[u] = st_src[g];
+        }
+    };
+    // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
+    // (pre slots) -> spike-bitmap words -> (which axons spiked) -> synapse words.  While chunk i is delivered,
+    // the bitmap words of chunk i+1 and the records of chunk i+2 are in flight.
+    unsigned long long cur[AX_PER_THREAD] = {NONE, NONE, NONE, NONE}; // records of the chunk AFTER the decoded one
+    uint32_t nx_pre[AX_PER_THREAD], nx_nsyn[AX_PER_THREAD], nx_lcls[AX_PER_THREAD], nx_word[AX_PER_THREAD], nx_valid = 0;
+    // decode the records in `cur` (chunk at axon offset cc) and issue the loads of their bitmap words
+    auto decode_and_probe = [&](uint32_t cc) {
+        const uint32_t a0 = cc + (uint32_t) lane * AX_PER_THREAD;
+        nx_valid = 0;
+        if (compact)
+        {
+            const unsigned long long q = cur[0];
+            uint32_t dl[AX_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                dl[k] = (uint32_t) (q >> (16 * k)) & 0xffu;
+                nx_nsyn[k] = (uint32_t) (q >> (16 * k + 8)) & 0xffu;
+                nx_lcls[k] = 0u;
+            }
+            const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+            uint32_t pre = chunk_pre0[cc / WAVE_CHUNK] + wave_inclusive_scan(lane_d) - lane_d;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                pre += dl[k];
+                nx_pre[k] = pre;
+                nx_valid |= (a0 + k < n_ax) ? (1u << k) : 0u;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                const unsigned long long r = cur[k];
+                nx_pre[k] = (r == NONE) ? 0u : (uint32_t) r;
+                nx_nsyn[k] = (r == NONE) ? 0u : (uint32_t) ((r >> 32) & 0xffffu);
+                nx_lcls[k] = (uint32_t) ((r >> 48) & 0xffu);
+                nx_valid |= (r != NONE) ? (1u << k) : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++) nx_word[k] = bits[nx_pre[k] >> 5]; // pad axons read word 0: in bounds
+    };
+    if (c0 < n_ax)
     {
-        // ---- scan: which of my 4 consecutive inbound axons carry a spike this step? ----
-        const unsigned long long a0 = c0 + (unsigned long long) lane * AX_PER_THREAD;
+        load4(c0 + (uint32_t) lane * AX_PER_THREAD, cur);
+        decode_and_probe(c0);
+        if (c0 + stride < n_ax) load4(c0 + stride + (uint32_t) lane * AX_PER_THREAD, cur);
+    }
+    for (; c0 < n_ax; c0 += stride)
+    {
+        if (SYN_FMT == 0 && hot) stream_preload();
+        // ---- this chunk: take over what the previous iteration decoded and probed ----
+        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
         uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
 #pragma unroll
         for (int k = 0; k < AX_PER_THREAD; k++)
         {
-            const unsigned long long r = cur[k];
-            const uint32_t pre = (uint32_t) r;
-            nsyn[k] = (r == NONE) ? 0u : (uint32_t) ((r >> 32) & 0xffffu);
-            lcls[k] = (uint32_t) ((r >> 48) & 0xffu);
-            if (r != NONE) amask |= ((bits[pre >> 5] >> (pre & 31u)) & 1u) << k;
+            nsyn[k] = nx_nsyn[k];
+            lcls[k] = nx_lcls[k];
+            amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
         }
-        // prefetch the next chunk's records: their latency hides behind this chunk's work
-        if (c0 + stride < a_end) load4(a0 + stride, cur);
-        if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
+        // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
+        if (c0 + stride < n_ax)
+        {
+            decode_and_probe(c0 + stride);
+            if (c0 + 2 * stride < n_ax) load4(a0 + 2 * stride, cur);
+        }
+        if (__ballot(amask != 0) == 0ull)
+        {
+            hot = false;
+            continue; // wave-uniform
+        }
+        if (SYN_FMT == 0 && compact)
+        {
+            // ---- STREAM: with many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
+            //      so read them all once, in order (16 bytes per lane), and let each word say whether its axon
+            //      spiked: no compaction, no ownership search, no per-event address arithmetic. ----
+            const unsigned long long b0 = __ballot(amask & 1u), b1 = __ballot(amask & 2u), b2 = __ballot(amask & 4u),
+                                     b3 = __ballot(amask & 8u);
+            const uint32_t n_act = (uint32_t) (__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (n_act >= STREAM_MIN_ACTIVE)
+            {
+                if (lane < 8)
+                {
+                    const unsigned long long b = (lane < 2) ? b0 : (lane < 4) ? b1 : (lane < 6) ? b2 : b3;
+                    w_pref[lane] = (uint32_t) (b >> ((lane & 1) * 32)); // word k*2 + (L >> 5), bit L & 31: axon 4L + k
+                }
+                wave_lds_fence();
+                if (!hot) stream_preload();
+                hot = true;
+                auto add4 = [&](const uint4 &g) {
+                    const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
+                    uint32_t fired[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const uint32_t code = (w4[u] >> 16) & 0xffu;
+                        fired[u] = (w_pref[code >> 5] >> (code & 31u)) & 1u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (fired[u])
+                        {
+                            const uint32_t idx = (HAS_DELAY ? __umul24((w4[u] >> 12) & 7u, RS) : 0u) + (w4[u] & 0xfffu);
+                            atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
+                        }
+                };
+                // rolling window: STREAM_DEPTH 16-byte groups per lane in flight while one is added
+                for (uint32_t g = (uint32_t) lane; g < st_groups; g += WAVE * STREAM_DEPTH)
+                {
+#pragma unroll
+                    for (int u = 0; u < STREAM_DEPTH; u++)
+                    {
+                        const uint4 cur_g = sq[u];
+                        const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
+                        if (nxt < st_groups) sq[u] = st_src[nxt];
+                        if (g + (uint32_t) u * WAVE < st_groups) add4(cur_g);
+                    }
+                }
+                // processing delay of the chunk's messages: axon-in latency per message + per-event latency
+                uint32_t my_events = 0;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++) my_events += (amask & (1u << k)) ? nsyn[k] : 0u;
+                proc += (double) my_events * slice_lat + (double) __popc(amask) * ain_lat;
+                wave_lds_fence(); // w_pref is rewritten by the next chunk
+                continue;
+            }
+        }
+        hot = false;
+        // ---- GATHER: few spiking axons; touch only their synapses ----
         // the chunk's synapses are contiguous: one base + a prefix over ALL its axons' counts
-        const uint32_t chunk_syn0 = im.ax_syn_beg[c0];
         const uint32_t lane_syn = nsyn[0] + nsyn[1] + nsyn[2] + nsyn[3];
-        uint32_t syn_off = chunk_syn0 + wave_inclusive_scan(lane_syn) - lane_syn;
+        uint32_t syn_off = chunk_syn0[c0 / WAVE_CHUNK] + wave_inclusive_scan(lane_syn) - lane_syn;
         // ---- compact the active axons in axon (= reference delivery) order ----
         const uint32_t my_act = (uint32_t) __popc(amask);
         const uint32_t incl_act = wave_inclusive_scan(my_act);
-        const uint32_t n_act = __shfl(incl_act, WAVE - 1, WAVE);
         uint32_t my_ev = 0;
         uint32_t st4[AX_PER_THREAD], sb4[AX_PER_THREAD]; // MY active axons, packed to the front: event start, first synapse
 #pragma unroll
@@ -519,7 +706,8 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
                     else st4[3] = my_ev, sb4[3] = syn_off;
                     j++;
                     my_ev += nsyn[k];
-                    proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a0 + k];
+                    if (compact) proc += ain_lat + (double) nsyn[k] * slice_lat;
+                    else proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a_beg + a0 + k];
                 }
                 syn_off += nsyn[k];
             }
@@ -557,7 +745,7 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
             uint32_t seen = heads_before; // heads before the current tile
             for (uint32_t e0 = 0; e0 < w_end; e0 += WAVE * EXPAND_UNROLL)
             {
-                uint32_t meta[EXPAND_UNROLL];
+                uint32_t meta[EXPAND_UNROLL]; // post (16b) | delay << 16 | drop << 19, whatever the stored format
                 double wgt[EXPAND_UNROLL];
 #pragma unroll
                 for (int u = 0; u < EXPAND_UNROLL; u++)
@@ -575,8 +763,23 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
                         if (e < n_ev)
                         {
                             const unsigned long long s = syn_base + (uint32_t) (w_beg[owner] + e);
-                            meta[u] = im.syn_meta[s];
-                            if (!PACKED_W) wgt[u] = im.syn_weight[s];
+                            if (SYN_FMT == 0)
+                            {
+                                const uint32_t m = im.syn_meta[s];
+                                meta[u] = (m & 0xfffu) | (((m >> 12) & 0xfu) << 16);
+                                wgt[u] = (double) ((int) m >> 24);
+                            }
+                            else if (SYN_FMT == 1)
+                            {
+                                const uint32_t m = im.syn_meta[s];
+                                meta[u] = m & 0xfffffu;
+                                wgt[u] = (double) ((int) m >> 20);
+                            }
+                            else
+                            {
+                                meta[u] = im.syn_meta[s];
+                                wgt[u] = im.syn_weight[s];
+                            }
                         }
                     }
                 }
@@ -584,10 +787,9 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
                 for (int u = 0; u < EXPAND_UNROLL; u++)
                     if (!((meta[u] >> 19) & 1u))
                     {
-                        const uint32_t idx = ((meta[u] >> 16) & 7u) * npad + (meta[u] & 0xffffu);
-                        const double w = PACKED_W ? (double) ((int) meta[u] >> 20) : wgt[u];
-                        atomicAdd(&acc[idx], w); // ds_add_f64
-                        touched[idx] = 1;
+                        const uint32_t idx = (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
+                        atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
+                        if (TOUCH_BYTES) touched[idx] = 1;
                     }
             }
             heads_before = seen;
@@ -597,10 +799,11 @@ __global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, Dev
     __syncthreads();
     // ---- write the accumulated charge back (one RMW per touched neuron and delay value) ----
     const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
-    for (uint32_t i = threadIdx.x; i < D * npad; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
     {
-        if (!touched[i]) continue;
-        const uint32_t d = i / npad, n = i - d * npad;
+        if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
+        const uint32_t d = i / RS, n = i - d * RS;
+        if (n >= npad) continue; // trash entry
         const uint32_t wslot = (uint32_t) ((t + 1 + d) % R);
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
         if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
@@ -720,16 +923,6 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
     }
 }
 
-__global__ void fill_double(double *p, size_t n, double v)
-{
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
-// Host-evaluated soma units (plugins).  Between K1 and K2 the host (1) gathers the synaptic input
-// of those slots -- reading AND clearing the time-step buffer exactly like K1 does for device
-// somas -- (2) calls the plugin's update() and (3) hands back status, energy and latency, which are
-// folded into the per-core partials together with the spike's static downstream totals.
 __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -789,7 +982,9 @@ struct sanafe_hip_chip
     int device{0};
     hipStream_t stream{nullptr};
     bool own_stream{true};
-    bool packed_weights{false};
+    bool has_delay{false};
+    int syn_format{2};        // 0: 2+1 B, 1: 4 B, 2: 4+8 B per synapse (DevImage)
+    uint32_t n_compact_slices{0};
     DevImage im{};
     DevState st{};
     std::vector<void *> allocs;
@@ -812,6 +1007,21 @@ struct sanafe_hip_chip
 
 namespace
 {
+// Host-side packing loops over up to ~10^9 synapses: contiguous blocks on a few threads.
+template <typename F> void parallel_for(uint64_t n, const F &fn)
+{
+    unsigned T = std::min<unsigned>(16, std::max<unsigned>(1, std::thread::hardware_concurrency()));
+    if (n < (1u << 16)) T = 1;
+    if (T == 1)
+    {
+        fn(uint64_t{0}, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < T; t++) pool.emplace_back([&, t] { fn(n * t / T, n * (t + 1) / T); });
+    for (std::thread &th : pool) th.join();
+}
+
 template <typename T> int upload(sanafe_hip_chip *c, const T *src, size_t n, const T **dst)
 {
     *dst = nullptr;
@@ -874,23 +1084,49 @@ int validate(const sanafe_hip_image *im)
             return fail(SANAFE_HIP_ERR_INVALID, "slice %u: bad axon range", s);
     }
     // Bounds of every index the kernels dereference: a bad image must fail here, not fault on the GPU.
-    for (uint64_t s = 0; s < im->n_slices; s++)
     {
-        const uint32_t core = im->slice_core[s];
-        const uint64_t core_syn_end = (core + 1 < im->n_cores) ? im->core_syn_base[core + 1] : im->n_synapses;
-        for (uint64_t a = im->slice_axon_beg[s]; a < im->slice_axon_end[s]; a++)
-        {
-            if (im->ax_pre[a] >= im->n_global_slots) return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: bad pre slot", (unsigned long long) a);
-            if (im->ax_nsyn[a] > 0xffffu) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "axon %llu has more than 65535 synapses", (unsigned long long) a);
-            if (a > im->slice_axon_beg[s] && im->ax_syn_beg[a] != im->ax_syn_beg[a - 1] + im->ax_nsyn[a - 1])
-                return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: synapses of a slice must be contiguous in axon order", (unsigned long long) a);
-            if (im->core_syn_base[core] + im->ax_syn_beg[a] + im->ax_nsyn[a] > core_syn_end)
-                return fail(SANAFE_HIP_ERR_INVALID, "axon %llu: synapse range leaves its core", (unsigned long long) a);
-            const uint64_t sb = im->core_syn_base[core] + im->ax_syn_beg[a];
-            for (uint32_t k = 0; k < im->ax_nsyn[a]; k++)
-                if ((im->syn_meta[sb + k] & 0xffffu) >= im->core_ncount[core])
-                    return fail(SANAFE_HIP_ERR_INVALID, "synapse %llu: post neuron outside its core", (unsigned long long) (sb + k));
-        }
+        std::mutex err_mutex;
+        uint64_t err_slice = ~0ull;
+        std::string err_text;
+        auto report = [&](uint64_t s, const char *what, unsigned long long idx) {
+            std::lock_guard<std::mutex> lock(err_mutex);
+            if (s < err_slice)
+            {
+                err_slice = s;
+                char buf[160];
+                std::snprintf(buf, sizeof(buf), what, idx);
+                err_text = buf;
+            }
+        };
+        parallel_for(im->n_slices, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t s = lo; s < hi; s++)
+            {
+                const uint32_t core = im->slice_core[s];
+                const uint64_t core_syn_end = (core + 1 < im->n_cores) ? im->core_syn_base[core + 1] : im->n_synapses;
+                bool bad = false;
+                for (uint64_t a = im->slice_axon_beg[s]; a < im->slice_axon_end[s] && !bad; a++)
+                {
+                    bad = true;
+                    if (im->ax_pre[a] >= im->n_global_slots) report(s, "axon %llu: bad pre slot", a);
+                    else if (im->ax_nsyn[a] > 0xffffu) report(s, "axon %llu has more than 65535 synapses", a);
+                    else if (a > im->slice_axon_beg[s] && im->ax_syn_beg[a] != im->ax_syn_beg[a - 1] + im->ax_nsyn[a - 1])
+                        report(s, "axon %llu: synapses of a slice must be contiguous in axon order", a);
+                    else if (im->core_syn_base[core] + im->ax_syn_beg[a] + im->ax_nsyn[a] > core_syn_end)
+                        report(s, "axon %llu: synapse range leaves its core", a);
+                    else bad = false;
+                    if (bad) break;
+                    const uint64_t sb = im->core_syn_base[core] + im->ax_syn_beg[a];
+                    for (uint32_t k = 0; k < im->ax_nsyn[a]; k++)
+                        if ((im->syn_meta[sb + k] & 0xffffu) >= im->core_ncount[core])
+                        {
+                            report(s, "synapse %llu: post neuron outside its core", sb + k);
+                            bad = true;
+                            break;
+                        }
+                }
+            }
+        });
+        if (err_slice != ~0ull) return fail(SANAFE_HIP_ERR_INVALID, "%s", err_text.c_str());
     }
     for (uint32_t g = 0; g < im->n_slots; g++)
     {
@@ -992,46 +1228,189 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(upload(c, h.slice_core, h.n_slices, &im.slice_core));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_beg), h.n_slices, &im.slice_axon_beg));
     TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_end), h.n_slices, &im.slice_axon_end));
-    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.core_syn_base), h.n_cores, &im.core_syn_base));
+    // ---- synapse format: the narrowest of the three that holds every weight exactly (see DevImage) ----
+    //   0: post < 4096 and int8 weights; 1: 12-bit integer weights; 2: fp64 weights
     {
-        // pack the axon arrays into the 8-byte records the delivery kernel streams
-        std::vector<unsigned long long> rec(h.n_axons);
+        std::atomic<int> need{0};
+        bool small_cores = true;
+        for (uint32_t k = 0; k < h.n_cores; k++) small_cores = small_cores && h.core_ncount[k] <= 4032u; // post and trash index in 12 bits
+        parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
+            int fmt = 0;
+            for (uint64_t k = lo; k < hi && fmt < 2; k++)
+            {
+                const double w = h.syn_weight[k];
+                const bool integral = (w >= -2048.0 && w <= 2047.0 && w == (double) (int) w && !(w == 0.0 && std::signbit(w)));
+                if (!integral) fmt = 2;
+                else if (w < -128.0 || w > 127.0) fmt = std::max(fmt, 1);
+            }
+            int seen = need.load();
+            while (seen < fmt && !need.compare_exchange_weak(seen, fmt)) {}
+        });
+        int fmt = need.load();
+        if (fmt == 0 && !small_cores) fmt = 1;
+        if (h.n_synapses == 0) fmt = 2;
+        if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // experiments: force a wider format
+            fmt = std::max(fmt, std::min(2, std::atoi(env)));
+        c->syn_format = fmt;
+    }
+    const bool stream_layout = (c->syn_format == 0);
+    {
+        // ---- axon records: per slice, compact (2 B/axon) when its axons allow it, else wide (8 B/axon) ----
+        std::vector<unsigned long long> rec_off(h.n_slices, 0);
+        std::vector<uint8_t> mode(h.n_slices, 0), slat(h.n_slices, 0);
+        std::vector<uint32_t> chunk0(h.n_slices, 0);
+        uint64_t n_chunks = 0, n_bytes = 0;
         bool any_exact = false;
-        for (uint64_t a = 0; a < h.n_axons; a++)
+        parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t sl = lo; sl < hi; sl++)
+            {
+                const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl];
+                bool ok = e0 > b0 && h.ax_lat_class != nullptr && h.ax_lat_class[b0] != 255u;
+                for (uint64_t a = b0; a < e0 && ok; a++)
+                {
+                    ok = h.ax_nsyn[a] < 256u && h.ax_lat_class[a] == h.ax_lat_class[b0];
+                    if (ok && ((a - b0) % WAVE_CHUNK) != 0) ok = h.ax_pre[a] >= h.ax_pre[a - 1] && h.ax_pre[a] - h.ax_pre[a - 1] < 256u;
+                }
+                mode[sl] = ok ? 1 : 0;
+                slat[sl] = ok ? h.ax_lat_class[b0] : 0;
+            }
+        });
+        for (uint32_t sl = 0; sl < h.n_slices; sl++)
         {
-            const uint32_t cls = h.ax_lat_class ? h.ax_lat_class[a] : 255u;
-            any_exact |= (cls == 255u);
-            rec[a] = (unsigned long long) h.ax_pre[a] | ((unsigned long long) h.ax_nsyn[a] << 32) | ((unsigned long long) cls << 48);
+            const uint64_t n = h.slice_axon_end[sl] - h.slice_axon_beg[sl];
+            if (n >= (1ull << 32)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "slice %u holds 2^32 axons or more", sl));
+            rec_off[sl] = n_bytes;
+            n_bytes += ((n * (mode[sl] ? 2ull : 8ull)) + 15ull) & ~15ull;
+            chunk0[sl] = (uint32_t) n_chunks;
+            n_chunks += (n + WAVE_CHUNK - 1) / WAVE_CHUNK + 1; // + end entry: first synapse after the slice
+            if (n_chunks >= (1ull << 32)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "too many axon chunks"));
         }
-        TRYC(upload(c, rec.data(), rec.size(), &im.ax_rec));
-        TRYC(upload(c, h.ax_syn_beg, h.n_axons, &im.ax_syn_beg));
+        // Where each chunk's synapses live on the device.  Formats 1 and 2 keep the image's order.  Format 0 gives
+        // every chunk a 16-byte aligned start and pads its end to 16 bytes with words that drop their charge, so
+        // a chunk can be streamed with aligned 16-byte loads and no boundary tests.
+        std::vector<uint64_t> chunk_pos(n_chunks, 0);  // absolute device position of the chunk's first synapse
+        std::vector<uint64_t> dev_core_base(h.core_syn_base, h.core_syn_base + h.n_cores);
+        uint64_t n_dev_syn = h.n_synapses;
+        auto chunk_syn_count = [&](uint32_t sl, uint64_t k) { // synapses of chunk k of slice sl
+            const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl];
+            const uint64_t a0 = b0 + k * WAVE_CHUNK, a1 = std::min<uint64_t>(a0 + WAVE_CHUNK, e0);
+            return (uint64_t) (h.ax_syn_beg[a1 - 1] + h.ax_nsyn[a1 - 1] - h.ax_syn_beg[a0]);
+        };
+        if (stream_layout)
+        {
+            uint64_t pos = 0;
+            uint32_t prev_core = 0xffffffffu;
+            for (uint32_t k = 0; k < h.n_cores; k++) dev_core_base[k] = 0;
+            for (uint32_t sl = 0; sl < h.n_slices; sl++)
+            {
+                const uint32_t core = h.slice_core[sl];
+                if (core != prev_core) dev_core_base[core] = pos;
+                prev_core = core;
+                const uint64_t nck = (h.slice_axon_end[sl] - h.slice_axon_beg[sl] + WAVE_CHUNK - 1) / WAVE_CHUNK;
+                for (uint64_t k = 0; k < nck; k++)
+                {
+                    chunk_pos[chunk0[sl] + k] = pos;
+                    pos += (chunk_syn_count(sl, k) + 3ull) & ~3ull;
+                }
+                chunk_pos[chunk0[sl] + nck] = pos;
+                if (pos - dev_core_base[core] > 0xffffffffull)
+                    return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "more than 2^32 synapses on core %u", core));
+            }
+            n_dev_syn = pos;
+        }
+        else
+        {
+            for (uint32_t sl = 0; sl < h.n_slices; sl++)
+            {
+                const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl];
+                const uint64_t cbase = h.core_syn_base[h.slice_core[sl]];
+                const uint64_t nck = (e0 - b0 + WAVE_CHUNK - 1) / WAVE_CHUNK;
+                for (uint64_t k = 0; k < nck; k++) chunk_pos[chunk0[sl] + k] = cbase + h.ax_syn_beg[b0 + k * WAVE_CHUNK];
+                chunk_pos[chunk0[sl] + nck] = (e0 > b0) ? cbase + h.ax_syn_beg[e0 - 1] + h.ax_nsyn[e0 - 1] : cbase;
+            }
+        }
+        TRYC(upload(c, reinterpret_cast<const unsigned long long *>(dev_core_base.data()), h.n_cores, &im.core_syn_base));
+        std::vector<unsigned char> bytes(n_bytes + 16, 0);
+        std::vector<uint32_t> csyn(n_chunks, 0), cpre(n_chunks, 0);
+        std::vector<uint8_t> exact(h.n_slices, 0);
+        std::vector<uint32_t> meta; // device synapse words of formats 0 and 1
+        if (c->syn_format != 2) meta.assign(n_dev_syn + 256, 0u);
+        parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t sl = lo; sl < hi; sl++)
+            {
+                const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl];
+                const uint32_t core = h.slice_core[sl];
+                const uint32_t trash_post = (h.core_ncount[core] + 63u) & ~63u; // == npad of the core
+                unsigned char *dst = bytes.data() + rec_off[sl];
+                const uint64_t nck = (e0 - b0 + WAVE_CHUNK - 1) / WAVE_CHUNK;
+                for (uint64_t k = 0; k <= nck; k++) csyn[chunk0[sl] + k] = (uint32_t) (chunk_pos[chunk0[sl] + k] - dev_core_base[core]);
+                if (stream_layout) // padding words of every chunk: weight 0 into the trash entry
+                    for (uint64_t k = 0; k < nck; k++)
+                        for (uint64_t q = chunk_pos[chunk0[sl] + k] + chunk_syn_count((uint32_t) sl, k); q < chunk_pos[chunk0[sl] + k + 1]; q++)
+                            meta[q] = trash_post | 0x8000u;
+                for (uint64_t a = b0; a < e0; a++)
+                {
+                    const uint64_t rel = a - b0;
+                    const uint32_t in_chunk = (uint32_t) (rel % WAVE_CHUNK);
+                    if (in_chunk == 0) cpre[chunk0[sl] + rel / WAVE_CHUNK] = h.ax_pre[a];
+                    if (mode[sl])
+                    {
+                        const uint32_t delta = (in_chunk == 0) ? 0u : h.ax_pre[a] - h.ax_pre[a - 1];
+                        const uint16_t r16 = (uint16_t) (delta | (h.ax_nsyn[a] << 8));
+                        std::memcpy(dst + 2 * rel, &r16, 2);
+                    }
+                    else
+                    {
+                        const uint32_t cls = h.ax_lat_class ? h.ax_lat_class[a] : 255u;
+                        if (cls == 255u) exact[sl] = 1;
+                        const unsigned long long r64 = (unsigned long long) h.ax_pre[a] | ((unsigned long long) h.ax_nsyn[a] << 32) | ((unsigned long long) cls << 48);
+                        std::memcpy(dst + 8 * rel, &r64, 8);
+                    }
+                    if (c->syn_format == 2) continue;
+                    // synapse words: image position -> device position (same offset inside the chunk)
+                    const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
+                    const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[b0 + (rel / WAVE_CHUNK) * WAVE_CHUNK];
+                    const uint64_t dpos = chunk_pos[chunk0[sl] + rel / WAVE_CHUNK] + (src - chunk_first);
+                    const uint32_t code = ((in_chunk & 3u) << 6) | (in_chunk >> 2);
+                    for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
+                    {
+                        const uint32_t m = h.syn_meta[src + k];
+                        const int w = (int) h.syn_weight[src + k];
+                        if (c->syn_format == 0)
+                        {
+                            const bool drop = (m >> 19) & 1u;
+                            const uint32_t post = drop ? trash_post : (m & 0xfffu);
+                            meta[dpos + k] = post | (drop ? 0x8000u : (((m >> 16) & 7u) << 12)) | (code << 16) | ((uint32_t) (w & 0xff) << 24);
+                        }
+                        else
+                            meta[dpos + k] = (m & 0xfffffu) | ((uint32_t) (w & 0xfff) << 20);
+                    }
+                }
+            }
+        });
+        for (uint8_t x : exact) any_exact |= (x != 0);
+        TRYC(upload(c, bytes.data(), bytes.size(), &im.ax_bytes));
+        TRYC(upload(c, rec_off.data(), rec_off.size(), &im.slice_rec_off));
+        TRYC(upload(c, mode.data(), mode.size(), &im.slice_mode));
+        TRYC(upload(c, slat.data(), slat.size(), &im.slice_lat_class));
+        TRYC(upload(c, chunk0.data(), chunk0.size(), &im.slice_chunk0));
+        TRYC(upload(c, csyn.data(), csyn.size(), &im.chunk_syn0));
+        TRYC(upload(c, cpre.data(), cpre.size(), &im.chunk_pre0));
         TRYC(upload(c, h.ax_proc_delay, any_exact ? h.n_axons : 0, &im.ax_proc_delay));
         std::vector<double> lat(256, 0.0);
         if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat.begin());
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
-    }
-    {
-        // weights that are integers in [-2048, 2047] ride in the top 12 bits of syn_meta (4 B/synapse
-        // instead of 12); anything else keeps the separate f64 array
-        bool packable = h.n_synapses > 0;
-        for (uint64_t k = 0; k < h.n_synapses && packable; k++)
-        {
-            const double w = h.syn_weight[k];
-            packable = (w >= -2048.0 && w <= 2047.0 && w == (double) (int) w && !(w == 0.0 && std::signbit(w)));
-        }
-        c->packed_weights = packable;
-        if (packable)
-        {
-            std::vector<uint32_t> meta(h.n_synapses);
-            for (uint64_t k = 0; k < h.n_synapses; k++)
-                meta[k] = (h.syn_meta[k] & 0xfffffu) | ((uint32_t) ((int) h.syn_weight[k] & 0xfff) << 20);
-            TRYC(upload(c, meta.data(), meta.size(), &im.syn_meta));
-            im.syn_weight = nullptr;
-        }
-        else
+        for (uint8_t m : mode) c->n_compact_slices += m;
+        im.syn_meta = nullptr;
+        im.syn_weight = nullptr;
+        if (c->syn_format == 2)
         {
             TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
             TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
+        }
+        else
+        {
+            TRYC(upload(c, meta.data(), meta.size(), &im.syn_meta));
         }
     }
     {
@@ -1068,19 +1447,30 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     c->neuron_grid = h.n_cores;
     {
         // LDS accumulator rows: one per synaptic delay value actually present in the image
-        uint32_t max_delay = 0;
-        for (uint64_t k = 0; k < h.n_synapses; k++) max_delay = std::max(max_delay, (h.syn_meta[k] >> 16) & 7u);
+        std::atomic<uint32_t> max_delay_seen{0};
+        parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
+            uint32_t m = 0;
+            for (uint64_t k = lo; k < hi; k++) m = std::max(m, (h.syn_meta[k] >> 16) & 7u);
+            uint32_t seen = max_delay_seen.load();
+            while (seen < m && !max_delay_seen.compare_exchange_weak(seen, m)) {}
+        });
+        const uint32_t max_delay = max_delay_seen.load();
         if (max_delay >= h.ring_slots) return bail(fail(SANAFE_HIP_ERR_INVALID, "synaptic delay %u needs more than %u ring slots", max_delay, h.ring_slots));
         im.delay_slots = max_delay + 1;
     }
-    c->deliver_lds = (size_t) im.delay_slots * max_pad * (sizeof(double) + 1);
+    c->deliver_lds = (size_t) im.delay_slots * (max_pad + 1) * (sizeof(double) + 1);
+    c->has_delay = im.delay_slots > 1;
     if (c->deliver_lds + 9 * 1024 > 160 * 1024)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu B of LDS (> 160 KiB)",
                 max_pad, im.delay_slots, c->deliver_lds));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            (int) c->deliver_lds));
-    HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-            (int) c->deliver_lds));
+#define SANAFE_SET_LDS(F, DLY) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, DLY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
+    SANAFE_SET_LDS(0, true);
+    SANAFE_SET_LDS(0, false);
+    SANAFE_SET_LDS(1, true);
+    SANAFE_SET_LDS(1, false);
+    SANAFE_SET_LDS(2, true);
+    SANAFE_SET_LDS(2, false);
+#undef SANAFE_SET_LDS
     HIPC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -1133,10 +1523,15 @@ static int launch_deliver(sanafe_hip_chip *c)
 {
     if (c->im.n_slices > 0)
     {
-        if (c->packed_weights)
-            hipLaunchKernelGGL(deliver_kernel<true>, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
-        else
-            hipLaunchKernelGGL(deliver_kernel<false>, dim3(c->im.n_slices), dim3(DELIVER_BLOCK), c->deliver_lds, c->stream, c->im, c->st);
+        const dim3 grid(c->im.n_slices), block(DELIVER_BLOCK);
+#define SANAFE_LAUNCH_DELIVER(F, DLY) hipLaunchKernelGGL((deliver_kernel<F, DLY>), grid, block, c->deliver_lds, c->stream, c->im, c->st)
+        if (c->syn_format == 0 && c->has_delay) SANAFE_LAUNCH_DELIVER(0, true);
+        else if (c->syn_format == 0) SANAFE_LAUNCH_DELIVER(0, false);
+        else if (c->syn_format == 1 && c->has_delay) SANAFE_LAUNCH_DELIVER(1, true);
+        else if (c->syn_format == 1) SANAFE_LAUNCH_DELIVER(1, false);
+        else if (c->has_delay) SANAFE_LAUNCH_DELIVER(2, true);
+        else SANAFE_LAUNCH_DELIVER(2, false);
+#undef SANAFE_LAUNCH_DELIVER
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -1213,6 +1608,14 @@ extern "C" int sanafe_hip_write_ext(sanafe_hip_chip *c, int64_t n_steps, const i
     if (n_steps > 0) HIPCHK(hipMemcpy(c->d_ext, values, (size_t) n_steps * c->im.n_ext * sizeof(int), hipMemcpyHostToDevice));
     c->ext_rows = n_steps;
     c->ext_next = 0;
+    return 0;
+}
+
+extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32_t *n_compact_slices)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (syn_format) *syn_format = c->syn_format;
+    if (n_compact_slices) *n_compact_slices = c->n_compact_slices;
     return 0;
 }
 

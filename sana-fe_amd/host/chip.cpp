@@ -557,7 +557,7 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
         // SANAFE_TARGET_SLICES: delivery work items to aim for (tests use it to force multi-slice cores)
         uint32_t target_slices = 16384; // many more work items than the 2048 resident workgroups: no tail
         if (const char *env = std::getenv("SANAFE_TARGET_SLICES")) target_slices = static_cast<uint32_t>(std::max(1L, std::atol(env)));
-        uint32_t min_slice_axons = 8192;
+        uint32_t min_slice_axons = 1024; // one 256-axon chunk per wavefront: small chips still spread over many CUs
         if (const char *env = std::getenv("SANAFE_MIN_SLICE_AXONS")) min_slice_axons = static_cast<uint32_t>(std::max(4L, std::atol(env)));
         sanafe_amd::map_and_lower(*desc, n_ranks, rank, target_slices, min_slice_axons, chip->mc);
     }

@@ -122,6 +122,8 @@ def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=
         dst[i * out_degree:(i + 1) * out_degree] = rng.choice(n, size=out_degree, replace=False)
     if weights == "int":
         w = rng.integers(1, 9, size=len(src)) * rng.choice([-1, 1], size=len(src))
+    elif weights == "int12":
+        w = rng.integers(-2000, 2001, size=len(src))
     else:
         w = rng.normal(size=len(src)) * 4.0
     at = {"weight": w.astype(np.float64)}

@@ -174,7 +174,30 @@ def test_truenorth(S):
 
 def test_float_weights(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=16, arch_kind="loihi", weights="float")
-    check_stepwise(S, arch, net, steps=20, exact_v=False)
+    chip, _ = check_stepwise(S, arch, net, steps=20, exact_v=False)
+    assert chip.device_layout()["syn_format"] == 2  # 4 + 8 bytes per synapse
+
+
+def test_twelve_bit_integer_weights(S):
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=16, arch_kind="loihi", weights="int12")
+    chip, _ = check_stepwise(S, arch, net, steps=20)
+    assert chip.device_layout()["syn_format"] == 1  # 4 bytes per synapse
+
+
+def test_mixed_axon_record_modes(S):
+    """Dense recurrent cores pack their inbound axons as 2-byte delta records; a slice holding an axon with
+    more than 255 synapses keeps the 8-byte records.  Both forms in one chip, with synaptic delays."""
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=512, out_degree=200, arch_kind="large", delays=True,
+                                  p_fire=0.2, seed=8)
+    g = net._order[0]
+    rng = np.random.default_rng(3)
+    posts = rng.choice(512, size=300, replace=False)
+    pairs = np.stack([np.full(300, 700, dtype=np.int64), posts.astype(np.int64)], axis=1)  # neuron 700 -> 300 neurons of core 0
+    g.connect_neurons_sparse(g, {"weight": np.ones(300), "delay": rng.integers(0, 6, size=300)}, pairs, narrow_float=False)
+    chip, _ = check_stepwise(S, arch, net, steps=12)
+    lay, info = chip.device_layout(), chip.info()
+    assert lay["syn_format"] == 0  # 2 + 1 bytes per synapse
+    assert 0 < lay["n_compact_slices"] < info["n_slices"]
 
 
 def test_multi_slice_core(S, monkeypatch):
@@ -185,6 +208,7 @@ def test_multi_slice_core(S, monkeypatch):
                                   p_fire=0.3)
     chip, orc = check_stepwise(S, arch, net, steps=6)
     assert chip.info()["n_slices"] > 4
+    assert chip.device_layout()["n_compact_slices"] > 4  # dense inbound axon lists: 2-byte delta records
 
 
 def test_batched_run_records(S):
