@@ -337,6 +337,25 @@ def main():
                 "whole_step": {"algorithmic_bytes": 48.0 * upd + deliver_bytes,
                                "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
 
+    if roof is not None:
+        # HBM bytes per launch from the PMC passes of this very workload (profiles/collect.sh, summarize.py):
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE.
+        import glob
+        newest = -1
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
+            try:
+                with open(path) as f:
+                    summ = json.load(f)
+                if summ["bench_line"]["config"]["workload"] == workload and "hbm_bytes_per_launch" in summ["kernels"]["deliver_kernel"] \
+                        and summ.get("collected_unix", 0) > newest:
+                    newest = summ.get("collected_unix", 0)
+                    roof["traffic"] = summ["kernels"]["deliver_kernel"]["hbm_bytes_per_launch"]
+                    roof["traffic_source"] = os.path.relpath(path, ROOT)
+            except (KeyError, TypeError, ValueError, OSError):
+                continue
+        if roof["traffic"]:
+            roof["traffic_GBps"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
+
     cpu = None
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3" and args.timing == "simple":
         c = cpu_baseline(S, args)
@@ -362,7 +381,7 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
                        "neurons": n_total, "synapses_per_gpu": int(info["n_synapses"]), "axons_per_gpu": int(info["n_axons"]),
-                       "timing_model": args.timing,
+                       "timing_model": args.timing, "device_layout": chip.device_layout(),
                        "exchange": ("rccl all_gather of spike bitmaps" if args.exchange == "nccl" else "gloo via host") if world > 1 else "none"},
             "totals_in_timed_region": agg,
             "neuron_updates_per_s": agg["neurons_updated"] / elapsed,

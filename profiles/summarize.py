@@ -20,7 +20,9 @@ def short(name):
     return None
 
 
-summary = {"kernels": {}}
+import time
+
+summary = {"kernels": {}, "collected_unix": int(time.time())}
 stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
     shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))

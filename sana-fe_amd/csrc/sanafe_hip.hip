@@ -420,7 +420,13 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
 constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
 constexpr int EXPAND_UNROLL = 4;
 constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bitmap
-constexpr int STREAM_DEPTH = 4;             // 16-byte groups per lane in flight in the stream path
+#ifndef SANAFE_STREAM_DEPTH
+#define SANAFE_STREAM_DEPTH 3
+#endif
+#ifndef SANAFE_DELIVER_WAVES_PER_EU
+#define SANAFE_DELIVER_WAVES_PER_EU 5
+#endif
+constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
 constexpr uint32_t STREAM_MIN_ACTIVE = 16; // spiking axons in a 256-axon chunk from which streaming beats gathering
 constexpr unsigned long long ACC_UNTOUCHED = 0x8000000000000000ull; // -0.0: no sum of additions yields it
 
@@ -450,10 +456,11 @@ __device__ __forceinline__ void wave_lds_fence()
 extern __shared__ __align__(16) unsigned char deliver_lds[];
 
 template <int SYN_FMT, bool HAS_DELAY>
-__global__ void __launch_bounds__(DELIVER_BLOCK) deliver_kernel(DevImage im, DevState st)
+__global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, SANAFE_DELIVER_WAVES_PER_EU)))
+deliver_kernel(DevImage im, DevState st)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
-    __shared__ uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE + 4];        // head bitmap of the event window (+2 guard words)
+    __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
