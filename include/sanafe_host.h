@@ -62,6 +62,14 @@ int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int 
 /* Number of host threads that run the detailed NoC schedule of finished timesteps while the GPU
  * simulates ahead (SpikingChip::sim `scheduler_threads`, src/chip.cpp:291-349; 0 = inline). */
 int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_threads);
+/* MappedNeuron::set_attributes between sim() calls (src/mapped.cpp:113-166): forwards one attribute to the
+ * neuron's soma unit, exactly as at load().  Built-in LIF / TrueNorth somas: every key of
+ * <Model>::set_attribute_neuron (src/models.cpp:375-439, 664-722) -- the neuron moves to the parameter class with
+ * the new value, `bias` / `potential` are patched in place; plugin somas: set_attribute_neuron of the plugin.
+ * type is a SANAFE_ATTR_* (include/sanafe_desc.h); `str` is read for SANAFE_ATTR_STRING.  Changes reach the
+ * device at the next sim()/step (or sanafe_chip_commit_attributes).  Neurons of other ranks are ignored. */
+int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, const char *key, int type, double num, const char *str);
+int sanafe_chip_commit_attributes(sanafe_chip *chip);
 /* Generates the next `steps` rows of the external value streams (include/sanafe_hip.h: slot_ext,
  * sanafe_hip_write_ext) into out[steps][image.n_ext], advancing the host-side sources (Poisson
  * generators, the rand() sequence, noise files).  sim() does this itself; the call exists for mapped-only

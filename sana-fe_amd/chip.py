@@ -155,14 +155,14 @@ class MappedNeuronRef:
         self._chip, self._gid = chip, gid
 
     def set_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None, log_spikes=None):
+        """MappedNeuron::set_attributes (src/mapped.cpp:113-166): every attribute goes to the neuron's soma unit as at
+        load().  The built-in dendrites (accumulators) have no per-neuron attributes, so ``dendrite_attributes`` and the
+        dendrite copy of ``model_attributes`` change nothing, as in the reference."""
         attrs = dict(model_attributes or {})
         attrs.update(soma_attributes or {})
-        extra = set(attrs) - {"bias"}
-        if extra or dendrite_attributes:
-            raise NotImplementedError("only `bias` can be changed on a mapped neuron on the MI355X backend for now: %s"
-                                      % sorted(extra))
-        if "bias" in attrs:
-            self._chip._set_bias([self._gid], [D.py_to_attr(attrs["bias"])[1]])
+        for key, value in attrs.items():
+            t, num, sval, lst = D.py_to_attr(value)
+            self._chip._set_attribute(self._gid, key, t, num, sval)
         if log_spikes is not None:
             self._chip._log_spikes[self._gid] = bool(log_spikes)
 
@@ -435,6 +435,12 @@ class SpikingChip:
         return self._L.sanafe_chip_get_power(self._h)
 
     # -- multi-GPU split step ------------------------------------------------------------------
+    def _set_attribute(self, gid, key, attr_type, num, sval):
+        L = self._L
+        L.sanafe_chip_set_attribute.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_double, C.c_char_p]
+        self._check(L.sanafe_chip_set_attribute(self._h, int(gid), str(key).encode(), int(attr_type), float(num),
+                                                None if sval is None else str(sval).encode()))
+
     def device_layout(self):
         """(synapse format, compact axon slices) the device image was packed with (sanafe_hip_get_layout)."""
         H = hip_lib()

@@ -1007,6 +1007,8 @@ struct sanafe_hip_chip
     uint8_t *d_host_status{nullptr};
     double *d_host_a{nullptr}, *d_host_b{nullptr};
     uint32_t host_cap{0};
+    sanafe_hip_soma_class *d_soma_classes{nullptr}; // table rewritten after create (sanafe_hip_write_soma_classes)
+    uint32_t soma_class_cap{0};
     // external stream rows queued by sanafe_hip_write_ext
     int *d_ext{nullptr};
     long long ext_cap{0}, ext_rows{0}, ext_next{0};
@@ -1492,7 +1494,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
-                 (void *) c->d_host_b, (void *) c->d_ext})
+                 (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes})
         if (p) (void) hipFree(p);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -1777,12 +1779,19 @@ extern "C" int sanafe_hip_write_soma_classes(sanafe_hip_chip *c, uint32_t n, con
 {
     if (!c || !classes || n == 0 || n > 65536) return fail(SANAFE_HIP_ERR_INVALID, "bad class table");
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    void *p = nullptr;
-    HIPCHK(hipMalloc(&p, (size_t) n * sizeof(sanafe_hip_soma_class)));
-    c->allocs.push_back(p);
-    HIPCHK(hipMemcpy(p, classes, (size_t) n * sizeof(sanafe_hip_soma_class), hipMemcpyHostToDevice));
-    c->im.soma_classes = static_cast<const sanafe_hip_soma_class *>(p);
+    HIPCHK(hipStreamSynchronize(c->stream)); // steps in flight still read the old table
+    if (n > c->soma_class_cap)
+    {
+        // grow geometrically into a table of our own (the one uploaded at create stays in `allocs`)
+        const uint32_t cap = std::min<uint32_t>(65536u, std::max<uint32_t>(n, 2u * c->soma_class_cap + 64u));
+        void *p = nullptr;
+        HIPCHK(hipMalloc(&p, (size_t) cap * sizeof(sanafe_hip_soma_class)));
+        if (c->d_soma_classes) (void) hipFree(c->d_soma_classes);
+        c->d_soma_classes = static_cast<sanafe_hip_soma_class *>(p);
+        c->soma_class_cap = cap;
+    }
+    HIPCHK(hipMemcpy(c->d_soma_classes, classes, (size_t) n * sizeof(sanafe_hip_soma_class), hipMemcpyHostToDevice));
+    c->im.soma_classes = c->d_soma_classes;
     return 0;
 }
 static int ensure_host_staging(sanafe_hip_chip *c, uint32_t count)

@@ -182,6 +182,32 @@ struct sanafe_chip
     int scheduler_threads{0}; // schedule_create_threads, src/schedule.cpp:169-179
     ExtStreams ext;
     std::vector<int32_t> ext_rows;
+    // ---- parameter patches between sim() calls (MappedNeuron::set_attributes, src/mapped.cpp:113-166) ----
+    std::map<std::string, uint32_t> class_ids; // bytes of a canonical soma class -> index in mc.soma_classes
+    std::vector<uint32_t> dirty_slots;
+    bool classes_dirty{false};
+    static std::string class_key(const sanafe_hip_soma_class &c) { return std::string(reinterpret_cast<const char *>(&c), sizeof(c)); }
+    int commit_attributes()
+    {
+        if (classes_dirty)
+        {
+            if (sanafe_hip_write_soma_classes(dev, static_cast<uint32_t>(mc.soma_classes.size()), mc.soma_classes.data()) != 0)
+                return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+            classes_dirty = false;
+        }
+        std::sort(dirty_slots.begin(), dirty_slots.end());
+        dirty_slots.erase(std::unique(dirty_slots.begin(), dirty_slots.end()), dirty_slots.end());
+        for (size_t i = 0; i < dirty_slots.size();)
+        {
+            size_t j = i + 1;
+            while (j < dirty_slots.size() && dirty_slots[j] == dirty_slots[j - 1] + 1) j++;
+            if (sanafe_hip_write_slot_class(dev, dirty_slots[i], static_cast<uint32_t>(j - i), &mc.slot_cls[dirty_slots[i]]) != 0)
+                return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+            i = j;
+        }
+        dirty_slots.clear();
+        return 0;
+    }
     // Generates and queues the external stream values of the next `steps` timesteps.
     int queue_ext(int64_t steps)
     {
@@ -682,6 +708,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope");
     if (timing_model != SANAFE_TIMING_SIMPLE && timing_model != SANAFE_TIMING_DETAILED)
         return fail(SANAFE_HIP_ERR_INVALID, "unknown timing model");
+    if (int rc = chip->commit_attributes()) return rc;
     MappedChip &mc = chip->mc;
     sanafe_hip_totals run{};
     chip->have_records = false;
@@ -1033,9 +1060,101 @@ extern "C" int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int6
     return 0;
 }
 
+extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, const char *key, int type, double num, const char *str)
+{
+    if (!chip || !key) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (!chip->dev) return fail(SANAFE_HIP_ERR_INVALID, "the chip has no device (mapped only)");
+    if (neuron < 0 || neuron >= chip->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "neuron id out of range");
+    MappedChip &mc = chip->mc;
+    const uint32_t s = mc.slot_of_gid[neuron];
+    if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots) return 0; // another rank's neuron
+    const uint32_t ls = s - mc.slot_offset;
+    const uint32_t model = mc.slot_model[ls];
+    try
+    {
+        if (model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH)
+        {
+            sanafe_amd::SomaAttr a;
+            a.key = key;
+            a.type = type;
+            a.num = num;
+            if (type == SANAFE_ATTR_STRING) a.str = str ? str : "";
+            if (type == SANAFE_ATTR_LIST) return 0; // no list-valued attribute on these models: ignored like any unknown key
+            const uint32_t cls = mc.slot_cls[ls];
+            sanafe_hip_soma_class p = mc.soma_classes[cls >> 16];
+            sanafe_amd::SomaAttrEffect fx;
+            sanafe_amd::apply_soma_attribute(model, a, p, fx);
+            if (fx.random_mask_set)
+            {
+                uint32_t old_mask = 0;
+                if (!mc.slot_ext.empty() && mc.slot_ext[ls] != 0xffffffffu) old_mask = mc.ext[mc.slot_ext[ls]].mask;
+                if (fx.random_mask != old_mask)
+                    return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: random_mask cannot change after load() on the MI355X backend "
+                                                            "(it defines the chip's rand() schedule)");
+            }
+            if (fx.bias_set)
+            {
+                mc.slot_bias[ls] = fx.bias;
+                DEV(sanafe_hip_write_bias(chip->dev, ls, 1, &fx.bias));
+            }
+            if (fx.potential_set) DEV(sanafe_hip_write_potential(chip->dev, ls, 1, &fx.potential));
+            const sanafe_hip_soma_class canon = sanafe_amd::canonical_soma_class(p);
+            if (chip->class_ids.empty())
+                for (size_t k = 0; k < mc.soma_classes.size(); k++) chip->class_ids.emplace(sanafe_chip::class_key(mc.soma_classes[k]), static_cast<uint32_t>(k));
+            auto it = chip->class_ids.find(sanafe_chip::class_key(canon));
+            if (it == chip->class_ids.end())
+            {
+                if (mc.soma_classes.size() >= 65536) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: more than 65536 distinct soma parameter sets");
+                it = chip->class_ids.emplace(sanafe_chip::class_key(canon), static_cast<uint32_t>(mc.soma_classes.size())).first;
+                mc.soma_classes.push_back(canon);
+                chip->classes_dirty = true;
+            }
+            const uint32_t new_cls = (cls & 0xffffu) | (it->second << 16);
+            if (new_cls != cls)
+            {
+                mc.slot_cls[ls] = new_cls;
+                chip->dirty_slots.push_back(ls);
+            }
+            return 0;
+        }
+        if (model == SANAFE_SOMA_HOST)
+        {
+            for (const MappedChip::HostNeuron &hn : mc.host_neurons)
+                if (hn.slot == ls)
+                {
+                    sanafe::ModelAttribute ma;
+                    ma.name = key;
+                    if (type == SANAFE_ATTR_BOOL) ma.value = (num != 0.0);
+                    else if (type == SANAFE_ATTR_INT) ma.value = static_cast<int>(num);
+                    else if (type == SANAFE_ATTR_DOUBLE) ma.value = num;
+                    else if (type == SANAFE_ATTR_STRING) ma.value = std::string(str ? str : "");
+                    else return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: list attributes cannot be patched on a mapped neuron");
+                    chip->plugin_units[hn.unit]->set_attribute_neuron(hn.addr, std::string(key), ma);
+                    return 0;
+                }
+            return 0;
+        }
+        if (model == SANAFE_SOMA_INPUT)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: attributes of input neurons (spikes, rate, poisson) cannot change after "
+                                                    "load() on the MI355X backend");
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    return 0;
+}
+
+extern "C" int sanafe_chip_commit_attributes(sanafe_chip *chip)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    return chip->dev ? chip->commit_attributes() : 0;
+}
+
 extern "C" int sanafe_chip_step_neurons(sanafe_chip *chip)
 {
     if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (int rc = chip->commit_attributes()) return rc;
     if (int rc = chip->queue_ext(1)) return rc;
     DEV(sanafe_hip_step_neurons(chip->dev));
     return 0;

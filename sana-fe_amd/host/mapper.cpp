@@ -59,6 +59,90 @@ uint8_t parse_reset_mode(const std::string &s) // src/models.cpp:905-931
     throw std::invalid_argument("Reset mode not recognized");
 }
 
+} // namespace
+
+double SomaAttr::as_double() const
+{
+    if (type == SANAFE_ATTR_DOUBLE || type == SANAFE_ATTR_INT) return num;
+    throw std::runtime_error("Error: Attribute " + key + " cannot be cast to a double");
+}
+int SomaAttr::as_int() const
+{
+    if (type != SANAFE_ATTR_INT) throw std::runtime_error("Error: Attribute " + key + " is not an integer");
+    return static_cast<int>(num);
+}
+bool SomaAttr::as_bool() const
+{
+    if (type == SANAFE_ATTR_BOOL || type == SANAFE_ATTR_INT) return num != 0.0;
+    throw std::runtime_error("Error: Attribute " + key + " cannot be cast to a bool ()");
+}
+const std::string &SomaAttr::as_string() const
+{
+    if (type != SANAFE_ATTR_STRING) throw std::runtime_error("Error: Attribute " + key + " is not a string");
+    return str;
+}
+
+void apply_soma_attribute(uint32_t model, const SomaAttr &a, sanafe_hip_soma_class &p, SomaAttrEffect &fx)
+{
+    const std::string &k = a.key;
+    if (model == SANAFE_SOMA_LIF)
+    {
+        if (k == "threshold") p.threshold = a.as_double();
+        else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
+        else if (k == "reset") p.reset = a.as_double();
+        else if (k == "reverse_reset") p.reverse_reset = a.as_double();
+        else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
+        else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
+        else if (k == "leak_decay") p.leak_decay = a.as_double();
+        else if (k == "log_u") (void) a.as_bool();
+        else if (k == "input_decay") p.input_decay = a.as_double();
+        else if (k == "bias") fx.bias = a.as_double(), fx.bias_set = true;
+        else if (k == "force_update" || k == "force_update_every_timestep") p.force_update = a.as_bool();
+        else if (k == "refractory_delay") p.refractory_delay = a.as_int();
+        else if (k == "potential") fx.potential = a.as_double(), fx.potential_set = true;
+    }
+    else if (model == SANAFE_SOMA_TRUENORTH)
+    {
+        if (k == "threshold") p.threshold = a.as_double();
+        else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
+        else if (k == "reset") p.reset = a.as_double();
+        else if (k == "reverse_reset") p.reverse_reset = a.as_double();
+        else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
+        else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
+        else if (k == "leak") p.leak_decay = a.as_double();
+        else if (k == "bias") fx.bias = a.as_double(), fx.bias_set = true;
+        else if (k == "force_update_every_timestep" || k == "force_update") p.force_update = a.as_bool();
+        else if (k == "leak_towards_zero") p.leak_towards_zero = a.as_bool();
+        else if (k == "random_mask")
+        {
+            const int m = a.as_int();
+            if (m < 0) throw std::invalid_argument("random_mask < 0; must be unsigned.");
+            fx.random_mask = static_cast<uint32_t>(m);
+            fx.random_mask_set = true;
+        }
+    }
+}
+
+sanafe_hip_soma_class canonical_soma_class(const sanafe_hip_soma_class &p)
+{
+    sanafe_hip_soma_class canon;
+    std::memset(&canon, 0, sizeof(canon));
+    canon.threshold = p.threshold;
+    canon.reverse_threshold = p.reverse_threshold;
+    canon.reset = p.reset;
+    canon.reverse_reset = p.reverse_reset;
+    canon.leak_decay = p.leak_decay;
+    canon.input_decay = p.input_decay;
+    canon.refractory_delay = p.refractory_delay;
+    canon.reset_mode = p.reset_mode;
+    canon.reverse_reset_mode = p.reverse_reset_mode;
+    canon.force_update = p.force_update;
+    canon.leak_towards_zero = p.leak_towards_zero;
+    return canon;
+}
+
+namespace
+{
 enum Model { M_CURRENT_BASED, M_ACCUMULATOR, M_ACC_DELAY, M_TAPS, M_INPUT, M_LIF, M_TRUENORTH, M_PLUGIN };
 
 struct UnitInfo // one pipeline unit of a core template
@@ -610,40 +694,18 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     k == "log_potential" || k == "log_v")
                 throw std::invalid_argument("Reserved neuron attribute '" + k + "' cannot be used as a model attribute. Pass it as a direct argument instead (if supported).");
             if (!(a.fwd() & SANAFE_FWD_SOMA)) continue;
-            if (model == SANAFE_SOMA_LIF)
+            if (model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH)
             {
-                if (k == "threshold") p.threshold = a.as_double();
-                else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
-                else if (k == "reset") p.reset = a.as_double();
-                else if (k == "reverse_reset") p.reverse_reset = a.as_double();
-                else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
-                else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
-                else if (k == "leak_decay") p.leak_decay = a.as_double();
-                else if (k == "log_u") (void) a.as_bool();
-                else if (k == "input_decay") p.input_decay = a.as_double();
-                else if (k == "bias") mc.slot_bias[ls] = a.as_double();
-                else if (k == "force_update" || k == "force_update_every_timestep") p.force_update = a.as_bool();
-                else if (k == "refractory_delay") p.refractory_delay = a.as_int();
-                else if (k == "potential") mc.slot_v0[ls] = a.as_double();
-            }
-            else if (model == SANAFE_SOMA_TRUENORTH)
-            {
-                if (k == "threshold") p.threshold = a.as_double();
-                else if (k == "reverse_threshold") p.reverse_threshold = a.as_double();
-                else if (k == "reset") p.reset = a.as_double();
-                else if (k == "reverse_reset") p.reverse_reset = a.as_double();
-                else if (k == "reset_mode") p.reset_mode = parse_reset_mode(a.as_string());
-                else if (k == "reverse_reset_mode") p.reverse_reset_mode = parse_reset_mode(a.as_string());
-                else if (k == "leak") p.leak_decay = a.as_double();
-                else if (k == "bias") mc.slot_bias[ls] = a.as_double();
-                else if (k == "force_update_every_timestep" || k == "force_update") p.force_update = a.as_bool();
-                else if (k == "leak_towards_zero") p.leak_towards_zero = a.as_bool();
-                else if (k == "random_mask")
-                {
-                    const int m = a.as_int();
-                    if (m < 0) throw std::invalid_argument("random_mask < 0; must be unsigned.");
-                    tn_mask = static_cast<uint32_t>(m);
-                }
+                SomaAttr sa;
+                sa.key = k;
+                sa.type = a.type();
+                sa.num = (a.type() == SANAFE_ATTR_STRING || a.type() == SANAFE_ATTR_LIST) ? 0.0 : d.neuron_attrs.num[i];
+                if (a.type() == SANAFE_ATTR_STRING) sa.str = a.as_string();
+                SomaAttrEffect fx;
+                apply_soma_attribute(model, sa, p, fx);
+                if (fx.bias_set) mc.slot_bias[ls] = fx.bias;
+                if (fx.potential_set) mc.slot_v0[ls] = fx.potential;
+                if (fx.random_mask_set) tn_mask = fx.random_mask;
             }
             else
             {
@@ -743,18 +805,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
             ClassKey key;
             std::memset(&key, 0, sizeof(key));
-            sanafe_hip_soma_class canon{};
-            canon.threshold = p.threshold;
-            canon.reverse_threshold = p.reverse_threshold;
-            canon.reset = p.reset;
-            canon.reverse_reset = p.reverse_reset;
-            canon.leak_decay = p.leak_decay;
-            canon.input_decay = p.input_decay;
-            canon.refractory_delay = p.refractory_delay;
-            canon.reset_mode = p.reset_mode;
-            canon.reverse_reset_mode = p.reverse_reset_mode;
-            canon.force_update = p.force_update;
-            canon.leak_towards_zero = p.leak_towards_zero;
+            const sanafe_hip_soma_class canon = canonical_soma_class(p);
             std::memcpy(key.b, &canon, sizeof(canon));
             auto it = class_ids.find(key);
             if (it == class_ids.end())

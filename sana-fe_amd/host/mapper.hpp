@@ -30,6 +30,31 @@ public:
     explicit UnsupportedError(const std::string &m) : std::runtime_error(m) {}
 };
 
+// One attribute value as the soma models see it (ModelAttribute conversions, src/attribute.hpp:43-93).
+struct SomaAttr
+{
+    std::string key;
+    int type{SANAFE_ATTR_DOUBLE};
+    double num{0.0};
+    std::string str;
+    double as_double() const;
+    int as_int() const;
+    bool as_bool() const;
+    const std::string &as_string() const;
+};
+// What <Model>::set_attribute_neuron does with one attribute (src/models.cpp:375-439 LIF, 664-722 TrueNorth),
+// applied to the parameter class / per-slot values of a neuron.  Used by the mapper at load() and by
+// MappedNeuron::set_attributes between sim() calls.  Unknown keys are ignored, as in the reference.
+struct SomaAttrEffect
+{
+    bool bias_set{false}, potential_set{false}, random_mask_set{false};
+    double bias{0.0}, potential{0.0};
+    uint32_t random_mask{0};
+};
+void apply_soma_attribute(uint32_t soma_model, const SomaAttr &a, sanafe_hip_soma_class &p, SomaAttrEffect &fx);
+// Bytes of a class that define it (padding zeroed), for deduplication.
+sanafe_hip_soma_class canonical_soma_class(const sanafe_hip_soma_class &p);
+
 struct MappedChip
 {
     // ---- geometry ----

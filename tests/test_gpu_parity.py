@@ -250,6 +250,37 @@ def test_set_bias_between_sims(S):
             assert np.array_equal(chip.potentials(), orc.potentials())
 
 
+def test_set_attributes_between_sims(S):
+    """MappedNeuron.set_attributes with any soma attribute (src/mapped.cpp:113-166): the neuron moves to the
+    parameter class holding the new value; bias and potential are patched in place."""
+    D = S.description
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="loihi", p_fire=0.15, seed=6)
+    chip, orc = make(S, arch, net)
+    rng = np.random.default_rng(1)
+    n = net.neuron_count
+    groups = chip.mapped_neuron_groups
+    changes = [("threshold", lambda: int(rng.integers(20, 90))), ("reset", lambda: int(rng.integers(-5, 5))),
+               ("leak_decay", lambda: float(rng.choice([0.5, 0.75, 0.9375]))), ("reset_mode", lambda: str(rng.choice(["soft", "hard"]))),
+               ("refractory_delay", lambda: int(rng.integers(0, 3))), ("potential", lambda: float(rng.integers(-20, 60))),
+               ("bias", lambda: int(rng.integers(0, 30))), ("reverse_threshold", lambda: float(-rng.integers(10, 40))),
+               ("reverse_reset_mode", lambda: "saturate"), ("force_update", lambda: bool(rng.integers(0, 2)))]
+    for round_ in range(4):
+        for _ in range(40):
+            g = int(rng.integers(0, n))
+            key, gen = changes[int(rng.integers(0, len(changes)))]
+            value = gen()
+            groups["n"][g].set_attributes(model_attributes={key: value})
+            orc.set_neuron_attr(g, key, D.py_to_attr(value))
+        for t in range(6):
+            a, b = chip.run(1, "simple"), orc.step("simple")
+            for ka, kb in INT_KEYS:
+                assert a[ka] == b[kb], (round_, t, ka)
+            assert np.array_equal(chip.status(), orc.status()), (round_, t)
+            assert np.array_equal(chip.potentials(), orc.potentials()), (round_, t)
+    with pytest.raises(RuntimeError):
+        groups["n"][0].set_attributes(model_attributes={"reset_mode": "sideways"})
+
+
 def test_reset(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, arch_kind="loihi")
     chip, orc = make(S, arch, net)
