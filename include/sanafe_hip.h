@@ -233,6 +233,11 @@ int sanafe_hip_read_core_delays(sanafe_hip_chip *chip, double *gen_sum, double *
 int sanafe_hip_write_bias(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const double *bias);
 int sanafe_hip_write_potential(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const double *v);
 int sanafe_hip_write_slot_class(sanafe_hip_chip *chip, uint32_t first_slot, uint32_t count, const uint32_t *cls);
+/* Replaces the input-model tables (same meaning as in_train_beg/len/in_rate_period/in_train_bits of the image;
+ * n_input must equal the image's) and rewinds the spike-train cursor of every input with rewind[i] != 0:
+ * InputModel::set_attribute_neuron "spikes" / "rate" after load() (src/models.cpp:832-853). */
+int sanafe_hip_write_inputs(sanafe_hip_chip *chip, uint32_t n_input, const uint32_t *train_beg, const uint32_t *train_len,
+        const int64_t *rate_period, const uint32_t *train_bits, uint64_t n_train_words, const uint8_t *rewind);
 int sanafe_hip_write_soma_classes(sanafe_hip_chip *chip, uint32_t n, const sanafe_hip_soma_class *classes);
 /* Host-evaluated soma units (plugins, `extern "C" PipelineUnit *create_<model>()`,
  * src/plugins.cpp:45-98), between step_neurons and step_deliver:

@@ -69,6 +69,9 @@ int sanafe_chip_set_scheduler_threads(sanafe_chip *chip, int n_threads);
  * type is a SANAFE_ATTR_* (include/sanafe_desc.h); `str` is read for SANAFE_ATTR_STRING.  Changes reach the
  * device at the next sim()/step (or sanafe_chip_commit_attributes).  Neurons of other ranks are ignored. */
 int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, const char *key, int type, double num, const char *str);
+/* The list-valued form (type SANAFE_ATTR_LIST): input neurons' `spikes` train, which also rewinds the train
+ * (src/models.cpp:832-841).  Input neurons also take `rate`, and `poisson` when they had poisson > 0 at load(). */
+int sanafe_chip_set_attribute_list(sanafe_chip *chip, int64_t neuron, const char *key, const double *values, int64_t count);
 int sanafe_chip_commit_attributes(sanafe_chip *chip);
 /* Generates the next `steps` rows of the external value streams (include/sanafe_hip.h: slot_ext,
  * sanafe_hip_write_ext) into out[steps][image.n_ext], advancing the host-side sources (Poisson

@@ -154,6 +154,10 @@ class MappedNeuronRef:
     def __init__(self, chip, gid):
         self._chip, self._gid = chip, gid
 
+    def set_model_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None):
+        """Older spelling some scripts use (scripts/computer2026/combined.py:297)."""
+        return self.set_attributes(model_attributes, soma_attributes, dendrite_attributes)
+
     def set_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None, log_spikes=None):
         """MappedNeuron::set_attributes (src/mapped.cpp:113-166): every attribute goes to the neuron's soma unit as at
         load().  The built-in dendrites (accumulators) have no per-neuron attributes, so ``dendrite_attributes`` and the
@@ -162,7 +166,10 @@ class MappedNeuronRef:
         attrs.update(soma_attributes or {})
         for key, value in attrs.items():
             t, num, sval, lst = D.py_to_attr(value)
-            self._chip._set_attribute(self._gid, key, t, num, sval)
+            if t == D.ATTR_LIST:
+                self._chip._set_attribute_list(self._gid, key, lst)
+            else:
+                self._chip._set_attribute(self._gid, key, t, num, sval)
         if log_spikes is not None:
             self._chip._log_spikes[self._gid] = bool(log_spikes)
 
@@ -440,6 +447,13 @@ class SpikingChip:
         L.sanafe_chip_set_attribute.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_double, C.c_char_p]
         self._check(L.sanafe_chip_set_attribute(self._h, int(gid), str(key).encode(), int(attr_type), float(num),
                                                 None if sval is None else str(sval).encode()))
+
+    def _set_attribute_list(self, gid, key, values):
+        L = self._L
+        arr = np.ascontiguousarray(np.asarray(values, dtype=np.float64))
+        L.sanafe_chip_set_attribute_list.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_void_p, C.c_int64]
+        self._check(L.sanafe_chip_set_attribute_list(self._h, int(gid), str(key).encode(), arr.ctypes.data if len(arr) else None,
+                                                     len(arr)))
 
     def device_layout(self):
         """(synapse format, compact axon slices) the device image was packed with (sanafe_hip_get_layout)."""

@@ -1007,6 +1007,9 @@ struct sanafe_hip_chip
     uint8_t *d_host_status{nullptr};
     double *d_host_a{nullptr}, *d_host_b{nullptr};
     uint32_t host_cap{0};
+    uint32_t *d_in_beg{nullptr}, *d_in_len{nullptr}, *d_in_bits{nullptr}; // input tables rewritten after create
+    long long *d_in_period{nullptr};
+    uint64_t in_bits_cap{0};
     sanafe_hip_soma_class *d_soma_classes{nullptr}; // table rewritten after create (sanafe_hip_write_soma_classes)
     uint32_t soma_class_cap{0};
     // external stream rows queued by sanafe_hip_write_ext
@@ -1494,7 +1497,8 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
-                 (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes})
+                 (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes,
+                 (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
         if (p) (void) hipFree(p);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -1775,6 +1779,50 @@ extern "C" int sanafe_hip_write_slot_class(sanafe_hip_chip *c, uint32_t first, u
     if (!c || !cls || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
     return h2d(c, const_cast<uint32_t *>(c->im.slot_cls) + first, cls, count);
 }
+extern "C" int sanafe_hip_write_inputs(sanafe_hip_chip *c, uint32_t n_input, const uint32_t *train_beg, const uint32_t *train_len,
+        const int64_t *rate_period, const uint32_t *train_bits, uint64_t n_train_words, const uint8_t *rewind)
+{
+    if (!c || n_input != c->im.n_input) return fail(SANAFE_HIP_ERR_INVALID, "input count differs from the image's");
+    if (n_input == 0) return 0;
+    if (!train_beg || !train_len || !rate_period || (n_train_words > 0 && !train_bits) || !rewind)
+        return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n_input; i++)
+        if ((uint64_t) train_beg[i] + train_len[i] > n_train_words * 32ull)
+            return fail(SANAFE_HIP_ERR_INVALID, "input %u: spike train outside train_bits", i);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream)); // steps in flight still read the old tables
+    if (!c->d_in_beg)
+    {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_in_beg), (size_t) n_input * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_in_len), (size_t) n_input * sizeof(uint32_t)));
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_in_period), (size_t) n_input * sizeof(long long)));
+    }
+    if (n_train_words > c->in_bits_cap)
+    {
+        if (c->d_in_bits) HIPCHK(hipFree(c->d_in_bits));
+        c->d_in_bits = nullptr;
+        c->in_bits_cap = 0;
+        const uint64_t cap = n_train_words + n_train_words / 2 + 64;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_in_bits), cap * sizeof(uint32_t)));
+        c->in_bits_cap = cap;
+    }
+    HIPCHK(hipMemcpy(c->d_in_beg, train_beg, (size_t) n_input * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_in_len, train_len, (size_t) n_input * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(c->d_in_period, rate_period, (size_t) n_input * sizeof(long long), hipMemcpyHostToDevice));
+    if (n_train_words > 0) HIPCHK(hipMemcpy(c->d_in_bits, train_bits, n_train_words * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // rewind the cursors: read, patch, write (n_input words)
+    std::vector<uint32_t> pos(n_input);
+    HIPCHK(hipMemcpy(pos.data(), c->st.in_pos, (size_t) n_input * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_input; i++)
+        if (rewind[i]) pos[i] = 0;
+    HIPCHK(hipMemcpy(c->st.in_pos, pos.data(), (size_t) n_input * sizeof(uint32_t), hipMemcpyHostToDevice));
+    c->im.in_train_beg = c->d_in_beg;
+    c->im.in_train_len = c->d_in_len;
+    c->im.in_rate_period = c->d_in_period;
+    if (c->d_in_bits) c->im.in_train_bits = c->d_in_bits;
+    return 0;
+}
+
 extern "C" int sanafe_hip_write_soma_classes(sanafe_hip_chip *c, uint32_t n, const sanafe_hip_soma_class *classes)
 {
     if (!c || !classes || n == 0 || n > 65536) return fail(SANAFE_HIP_ERR_INVALID, "bad class table");

@@ -186,6 +186,8 @@ struct sanafe_chip
     std::map<std::string, uint32_t> class_ids; // bytes of a canonical soma class -> index in mc.soma_classes
     std::vector<uint32_t> dirty_slots;
     bool classes_dirty{false};
+    bool inputs_dirty{false};
+    std::vector<uint8_t> input_rewind; // per input: its train was replaced since the last commit
     static std::string class_key(const sanafe_hip_soma_class &c) { return std::string(reinterpret_cast<const char *>(&c), sizeof(c)); }
     int commit_attributes()
     {
@@ -206,6 +208,69 @@ struct sanafe_chip
             i = j;
         }
         dirty_slots.clear();
+        if (inputs_dirty)
+        {
+            // compact the train storage (replaced trains leave holes), then replace the device tables
+            std::vector<uint32_t> bits, beg(mc.in_train_beg.size());
+            for (size_t a = 0; a < mc.in_train_beg.size(); a++)
+            {
+                const uint32_t nb = static_cast<uint32_t>(bits.size()) * 32u;
+                beg[a] = nb;
+                bits.resize(bits.size() + (mc.in_train_len[a] + 31u) / 32u, 0u);
+                for (uint32_t b = 0; b < mc.in_train_len[a]; b++)
+                {
+                    const uint32_t src = mc.in_train_beg[a] + b;
+                    if ((mc.in_train_bits[src >> 5] >> (src & 31u)) & 1u) bits[(nb + b) >> 5] |= 1u << ((nb + b) & 31u);
+                }
+            }
+            mc.in_train_beg.swap(beg);
+            mc.in_train_bits.swap(bits);
+            if (sanafe_hip_write_inputs(dev, static_cast<uint32_t>(mc.in_train_beg.size()), mc.in_train_beg.data(), mc.in_train_len.data(),
+                        mc.in_rate_period.data(), mc.in_train_bits.data(), mc.in_train_bits.size(), input_rewind.data()) != 0)
+                return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+            inputs_dirty = false;
+            std::fill(input_rewind.begin(), input_rewind.end(), 0);
+        }
+        return 0;
+    }
+    // InputModel::set_attribute_neuron after load(), src/models.cpp:832-853
+    int set_input_attribute(uint32_t ls, const std::string &key, int type, double num, const double *list, int64_t n_list)
+    {
+        const uint32_t a = mc.slot_aux[ls];
+        if (input_rewind.size() != mc.in_train_beg.size()) input_rewind.assign(mc.in_train_beg.size(), 0);
+        if (key == "spikes")
+        {
+            if (type != SANAFE_ATTR_LIST) return fail(SANAFE_HIP_ERR_INVALID, "Error: Attribute spikes is not a list");
+            const uint32_t nb = static_cast<uint32_t>(mc.in_train_bits.size()) * 32u;
+            mc.in_train_beg[a] = nb;
+            mc.in_train_len[a] = static_cast<uint32_t>(n_list);
+            mc.in_train_bits.resize(mc.in_train_bits.size() + (static_cast<size_t>(n_list) + 31) / 32, 0u);
+            for (int64_t b = 0; b < n_list; b++)
+                if (list[b] != 0.0) mc.in_train_bits[(nb + b) >> 5] |= 1u << ((nb + b) & 31u);
+            input_rewind[a] = 1;
+            inputs_dirty = true;
+        }
+        else if (key == "rate")
+        {
+            if (type != SANAFE_ATTR_DOUBLE && type != SANAFE_ATTR_INT) return fail(SANAFE_HIP_ERR_INVALID, "Error: Attribute rate cannot be cast to a double");
+            int64_t period = 0;
+            if (num > 0.0)
+            {
+                period = static_cast<long>(1.0 / num);
+                if (period == 0) return fail(SANAFE_HIP_ERR_INVALID, "input rate > 1 makes the reference divide by zero (SURVEY quirk 14)");
+            }
+            mc.in_rate_period[a] = period;
+            inputs_dirty = true;
+        }
+        else if (key == "poisson")
+        {
+            if (type != SANAFE_ATTR_DOUBLE && type != SANAFE_ATTR_INT) return fail(SANAFE_HIP_ERR_INVALID, "Error: Attribute poisson cannot be cast to a double");
+            const bool has_column = !mc.slot_ext.empty() && mc.slot_ext[ls] != 0xffffffffu;
+            if (has_column) mc.ext[mc.slot_ext[ls]].poisson = num;
+            else if (num > 0.0)
+                return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: an input neuron that had poisson == 0 at load() cannot get a "
+                                                        "Poisson rate later on the MI355X backend (no value-stream column)");
+        }
         return 0;
     }
     // Generates and queues the external stream values of the next `steps` timesteps.
@@ -1134,15 +1199,28 @@ extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, cons
                 }
             return 0;
         }
-        if (model == SANAFE_SOMA_INPUT)
-            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: attributes of input neurons (spikes, rate, poisson) cannot change after "
-                                                    "load() on the MI355X backend");
+        if (model == SANAFE_SOMA_INPUT) return chip->set_input_attribute(ls, key, type, num, nullptr, 0);
     }
     catch (const std::exception &e)
     {
         return fail(SANAFE_HIP_ERR_INVALID, e.what());
     }
     return 0;
+}
+
+extern "C" int sanafe_chip_set_attribute_list(sanafe_chip *chip, int64_t neuron, const char *key, const double *values, int64_t count)
+{
+    if (!chip || !key || count < 0 || (count > 0 && !values)) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (!chip->dev) return fail(SANAFE_HIP_ERR_INVALID, "the chip has no device (mapped only)");
+    if (neuron < 0 || neuron >= chip->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "neuron id out of range");
+    MappedChip &mc = chip->mc;
+    const uint32_t s = mc.slot_of_gid[neuron];
+    if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots) return 0; // another rank's neuron
+    const uint32_t ls = s - mc.slot_offset;
+    if (mc.slot_model[ls] == SANAFE_SOMA_INPUT) return chip->set_input_attribute(ls, key, SANAFE_ATTR_LIST, 0.0, values, count);
+    if (mc.slot_model[ls] == SANAFE_SOMA_HOST)
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: list attributes cannot be patched on a plugin neuron after load()");
+    return 0; // LIF / TrueNorth have no list-valued attribute: ignored like any unknown key
 }
 
 extern "C" int sanafe_chip_commit_attributes(sanafe_chip *chip)

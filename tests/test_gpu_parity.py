@@ -281,6 +281,32 @@ def test_set_attributes_between_sims(S):
         groups["n"][0].set_attributes(model_attributes={"reset_mode": "sideways"})
 
 
+def test_input_attributes_between_sims(S, tmp_path):
+    """Scripts replace the `spikes` train of mapped input neurons before every sim() (scripts/computer2026/
+    crossbar.py:301-309); `rate` and an existing Poisson probability can change too.  The train rewinds."""
+    D = S.description
+    arch, net = nets.stochastic(S, tmp_path)
+    chip, orc = make(S, arch, net)
+    rng = np.random.default_rng(5)
+    gin = chip.mapped_neuron_groups["in"]
+    base = dict(chip._built.groups)["in"][0]
+    for frame in range(4):
+        for i in range(len(gin)):
+            train = [int(x) for x in rng.integers(0, 2, size=int(rng.integers(0, 12)))]
+            gin[i].set_model_attributes(model_attributes={"spikes": train})
+            orc.set_neuron_attr(base + i, "spikes", D.py_to_attr(train))
+        i = int(rng.integers(0, len(gin)))
+        for key, value in (("rate", float(rng.choice([0.0, 0.25, 0.5]))), ("poisson", float(rng.choice([0.0, 0.125, 0.5])))):
+            gin[i].set_attributes(model_attributes={key: value})
+            orc.set_neuron_attr(base + i, key, D.py_to_attr(value))
+        for t in range(9):
+            a, b = chip.run(1, "simple"), orc.step("simple")
+            for ka, kb in INT_KEYS:
+                assert a[ka] == b[kb], (frame, t, ka)
+            assert np.array_equal(chip.status(), orc.status()), (frame, t)
+            assert np.array_equal(chip.potentials(), orc.potentials()), (frame, t)
+
+
 def test_reset(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, arch_kind="loihi")
     chip, orc = make(S, arch, net)
