@@ -1000,6 +1000,7 @@ struct sanafe_hip_chip
     long long rec_host{0};
     bool timing{false};
     double t_neuron{0}, t_deliver{0}, t_reduce{0};
+    std::vector<hipEvent_t> split_events;
     long long t_launches{0};
     std::vector<double> v0;
     // staging for host-evaluated units
@@ -1640,11 +1641,24 @@ extern "C" int sanafe_hip_synchronize(sanafe_hip_chip *c)
     return 0;
 }
 
+// Timed mode of the split step (multi-GPU loop): events queue up here and are resolved by sanafe_hip_read_timing.
+static int timed_event(sanafe_hip_chip *c)
+{
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    HIPCHK(hipEventRecord(e, c->stream));
+    c->split_events.push_back(e);
+    return 0;
+}
+
 extern "C" int sanafe_hip_step_neurons(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
-    return launch_neurons(c, 0);
+    if (!c->timing) return launch_neurons(c, 0);
+    TRY(timed_event(c));
+    TRY(launch_neurons(c, 0));
+    return timed_event(c);
 }
 
 extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, int record)
@@ -1652,8 +1666,16 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
     if (record) TRY(ensure_log(c, 1));
+    if (!c->timing)
+    {
+        TRY(launch_deliver(c));
+        return launch_reduce(c, simple_timing, 0);
+    }
+    TRY(timed_event(c));
     TRY(launch_deliver(c));
-    return launch_reduce(c, simple_timing, 0);
+    TRY(timed_event(c));
+    TRY(launch_reduce(c, simple_timing, 0));
+    return timed_event(c);
 }
 
 template <typename T> static int d2h(sanafe_hip_chip *c, T *dst, const T *src, size_t n);
@@ -1920,12 +1942,36 @@ extern "C" int sanafe_hip_set_timing(sanafe_hip_chip *c, int enabled)
     c->timing = enabled != 0;
     c->t_neuron = c->t_deliver = c->t_reduce = 0.0;
     c->t_launches = 0;
+    for (hipEvent_t e : c->split_events) (void) hipEventDestroy(e);
+    c->split_events.clear();
     return 0;
 }
 extern "C" int sanafe_hip_read_timing(sanafe_hip_chip *c, double *neuron_ms, double *deliver_ms, double *reduce_ms,
         int64_t *launches)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (!c->split_events.empty())
+    {
+        // events of timed split steps: [n0, n1] per step_neurons, [d0, d1, r1] per step_deliver, in call order
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        size_t i = 0;
+        const size_t n_ev = c->split_events.size();
+        while (i + 5 <= n_ev)
+        {
+            float a = 0, b = 0, d = 0;
+            HIPCHK(hipEventElapsedTime(&a, c->split_events[i], c->split_events[i + 1]));
+            HIPCHK(hipEventElapsedTime(&b, c->split_events[i + 2], c->split_events[i + 3]));
+            HIPCHK(hipEventElapsedTime(&d, c->split_events[i + 3], c->split_events[i + 4]));
+            c->t_neuron += a;
+            c->t_deliver += b;
+            c->t_reduce += d;
+            c->t_launches += 1;
+            i += 5;
+        }
+        for (hipEvent_t e : c->split_events) (void) hipEventDestroy(e);
+        c->split_events.clear();
+    }
     const double n = c->t_launches > 0 ? (double) c->t_launches : 1.0;
     if (neuron_ms) *neuron_ms = c->t_neuron / n;
     if (deliver_ms) *deliver_ms = c->t_deliver / n;
