@@ -3,18 +3,21 @@
 // Implements the C ABI of include/sanafe_hip.h.  Three kernels per timestep, all on one
 // HIP stream, no host round trip between steps (the timestep counter lives on the device):
 //
-//   K1 neuron_kernel   one 64-lane wavefront per simulated core; SoA neuron state, coalesced
-//                      8-byte loads; soma update (LIF / TrueNorth / input); wave ballot ->
-//                      spike bitmap; per-core cost/counter sums by wave reduction.
+//   K1 neuron_kernel   one 256-thread workgroup per simulated core, its 64-slot chunks dealt to the 4
+//                      wavefronts; SoA neuron state, coalesced 8-byte loads; soma update (LIF / TrueNorth /
+//                      input, incl. the host-generated stochastic value streams); wave ballot -> spike
+//                      bitmap; per-core cost/counter sums by wave reduction.
 //                      Reference: process_neurons / process_neuron / execute_pipeline,
 //                      src/chip.cpp:624-654, 710-736, 766-789; models src/models.cpp:441-903;
 //                      default costing src/pipeline.hpp:631-731.
-//   K2 deliver_kernel  one 256-thread workgroup per delivery slice of a destination core:
-//                      scans the core's static inbound-axon list against the spike bitmap
-//                      (pull, so the order is the reference's delivery order), compacts the
-//                      active axons with ballot + prefix sums, expands them to synaptic
-//                      events load-balanced over the workgroup, and accumulates weights in
-//                      LDS (per-core accumulators + delay ring) before one write-back.
+//   K2 deliver_kernel  one 256-thread workgroup (4 independent wavefronts) per delivery slice of a
+//                      destination core: walks the core's static inbound-axon list in 256-axon chunks
+//                      against the spike bitmap ("pull": messages are never materialised) and adds the
+//                      weights of the spiking axons' synapses into LDS accumulators (one row per delay
+//                      value) before one write-back.  Two paths per chunk: STREAM (many spikes: every
+//                      synapse word of the chunk is read once, in order, and says itself whether its axon
+//                      spiked) and GATHER (few spikes: compaction by ballot + prefix sums, load-balanced
+//                      expansion to synaptic events).  The chunk loop is software-pipelined.
 //                      Reference: process_messages / process_message, src/chip.cpp:656-764;
 //                      AccumulatorModel / AccumulatorWithDelayModel src/models.cpp:71-131.
 //   K3 reduce_kernel   fixed-order reduction of the per-core partials into the timestep
@@ -23,7 +26,7 @@
 //                      schedule_messages_timestep_simple, src/chip.cpp:1028-1051, 1171-1261;
 //                      src/schedule.cpp:61-102.
 //
-// No MFMA: the path is HBM-bound pointwise work plus an irregular gather.
+// No MFMA: the path is HBM-bound pointwise work plus an irregular gather / stream.
 // Compile with -ffp-contract=off: the membrane arithmetic must round exactly like the
 // reference's scalar C++ (no fused multiply-add).
 #include <hip/hip_runtime.h>
@@ -66,9 +69,9 @@ int fail(int code, const char *fmt, ...)
     } while (0)
 
 constexpr int WAVE = 64;
-constexpr int NEURON_BLOCK = 256;   // 4 wavefronts = 4 simulated cores per workgroup
+constexpr int NEURON_BLOCK = 256;   // one workgroup per simulated core: 4 wavefronts share its 64-slot chunks
 constexpr int DELIVER_BLOCK = 256;
-constexpr int AX_PER_THREAD = 4;    // one 16-byte load of ax_pre per lane
+constexpr int AX_PER_THREAD = 4;    // axon records per lane: one 8-byte (compact) or two 16-byte (wide) loads
 constexpr int REDUCE_BLOCK = 256;
 
 // Per-core partial sums written by K1 (one record per core, one writer).
@@ -834,34 +837,19 @@ deliver_kernel(DevImage im, DevState st)
 // ---------------------------------------------------------------------------------------
 // K3: per-step reduction.  one workgroup of 1024 threads, fixed summation order
 // ---------------------------------------------------------------------------------------
-template <typename T> __device__ T block_sum(T x, T *scratch)
-{
-    x = wave_sum(x);
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) scratch[wave] = x;
-    __syncthreads();
-    T r = 0;
-    for (int w = 0; w < REDUCE_BLOCK / WAVE; w++) r += scratch[w];
-    return r;
-}
-__device__ double block_max(double x, double *scratch)
+__device__ __forceinline__ double wave_max(double x)
 {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, WAVE));
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    __syncthreads();
-    if (lane == 0) scratch[wave] = x;
-    __syncthreads();
-    double r = scratch[0];
-    for (int w = 1; w < REDUCE_BLOCK / WAVE; w++) r = fmax(r, scratch[w]);
-    return r;
+    return x;
 }
 
 __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, int simple_timing, int record)
 {
-    __shared__ double sd[REDUCE_BLOCK / WAVE];
-    __shared__ long long sl[REDUCE_BLOCK / WAVE];
+    // every quantity: per-thread partial over its cores -> wave reduction (shuffles) -> one LDS slot per wave ->
+    // thread 0 combines the waves in order.  One barrier in all; the association is fixed, so results are reproducible.
+    __shared__ double sd[REDUCE_BLOCK / WAVE][6];
+    __shared__ long long sl[REDUCE_BLOCK / WAVE][5];
     double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
     long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
     for (uint32_t c = threadIdx.x; c < im.n_cores; c += REDUCE_BLOCK)
@@ -879,17 +867,54 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
         gmax = fmax(gmax, cp.gen_sum);
         pmax = fmax(pmax, st.core_proc[c]);
     }
-    e_soma = block_sum(e_soma, sd);
-    e_dend = block_sum(e_dend, sd);
-    e_syn = block_sum(e_syn, sd);
-    e_net = block_sum(e_net, sd);
-    upd = block_sum(upd, sl);
-    fired = block_sum(fired, sl);
-    packets = block_sum(packets, sl);
-    hops = block_sum(hops, sl);
-    events = block_sum(events, sl);
-    gmax = block_max(gmax, sd);
-    pmax = block_max(pmax, sd);
+    e_soma = wave_sum(e_soma);
+    e_dend = wave_sum(e_dend);
+    e_syn = wave_sum(e_syn);
+    e_net = wave_sum(e_net);
+    gmax = wave_max(gmax);
+    pmax = wave_max(pmax);
+    upd = wave_sum(upd);
+    fired = wave_sum(fired);
+    packets = wave_sum(packets);
+    hops = wave_sum(hops);
+    events = wave_sum(events);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    if (lane == 0)
+    {
+        sd[wave][0] = e_soma;
+        sd[wave][1] = e_dend;
+        sd[wave][2] = e_syn;
+        sd[wave][3] = e_net;
+        sd[wave][4] = gmax;
+        sd[wave][5] = pmax;
+        sl[wave][0] = upd;
+        sl[wave][1] = fired;
+        sl[wave][2] = packets;
+        sl[wave][3] = hops;
+        sl[wave][4] = events;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        e_soma = e_dend = e_syn = e_net = 0.0;
+        upd = fired = packets = hops = events = 0;
+        gmax = sd[0][4];
+        pmax = sd[0][5];
+        for (int w = 0; w < REDUCE_BLOCK / WAVE; w++)
+        {
+            e_soma += sd[w][0];
+            e_dend += sd[w][1];
+            e_syn += sd[w][2];
+            e_net += sd[w][3];
+            gmax = fmax(gmax, sd[w][4]);
+            pmax = fmax(pmax, sd[w][5]);
+            upd += sl[w][0];
+            fired += sl[w][1];
+            packets += sl[w][2];
+            hops += sl[w][3];
+            events += sl[w][4];
+        }
+    }
     if (threadIdx.x == 0)
     {
         sanafe_hip_totals ts;

@@ -1337,6 +1337,16 @@ extern "C" int sanafe_generate_random_edges_sharded(int64_t n_neurons, int64_t o
         std::vector<uint64_t> seen((n_neurons + 63) / 64, 0);
         std::vector<int64_t> targets(out_degree);
         const int64_t b = n_neurons * tid / n_threads, e = n_neurons * (tid + 1) / n_threads; // contiguous: output stays sorted by source
+        {
+            // expected number of kept edges (+2 %): no doubling slack in vectors that reach tens of GB
+            const int64_t local_src = std::max<int64_t>(0, std::min(e, hi) - std::max(b, lo));
+            const double frac_in = static_cast<double>(hi - lo) / static_cast<double>(n_neurons);
+            const double expect = static_cast<double>(out_degree) * (local_src + (e - b - local_src) * frac_in);
+            const size_t cap = static_cast<size_t>(expect * 1.02) + 4096;
+            set->src[tid].reserve(cap);
+            set->dst[tid].reserve(cap);
+            set->w[tid].reserve(cap);
+        }
         for (int64_t i = b; i < e; i++)
         {
             std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(i) + 1);
@@ -1379,10 +1389,15 @@ extern "C" int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t 
     int64_t o = 0;
     for (size_t t = 0; t < set->src.size(); t++)
     {
+        const int64_t n = static_cast<int64_t>(set->src[t].size());
         std::copy(set->src[t].begin(), set->src[t].end(), src + o);
         std::copy(set->dst[t].begin(), set->dst[t].end(), dst + o);
         std::copy(set->w[t].begin(), set->w[t].end(), weight + o);
-        o += static_cast<int64_t>(set->src[t].size());
+        // the set is consumed by the copy: give each part back as soon as it has been copied
+        std::vector<int64_t>().swap(set->src[t]);
+        std::vector<int64_t>().swap(set->dst[t]);
+        std::vector<double>().swap(set->w[t]);
+        o += n;
     }
     return 0;
 }
