@@ -161,6 +161,23 @@ def test_value_streams_batched_in_chunks(S, tmp_path, monkeypatch):
     assert tot["neurons_fired"] > 0
 
 
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
+def test_random_configurations(S, seed):
+    """Randomly drawn shapes around the thresholds of the delivery kernel's paths: chunk boundaries (256 axons),
+    the stream/gather switch (16 spiking axons per chunk), single- and multi-slice cores, delays or not."""
+    rng = np.random.default_rng(seed)
+    kind = ["large", "loihi"][int(rng.integers(0, 2))]
+    delays = bool(kind == "large" and rng.integers(0, 2))
+    npc = int(rng.choice([37, 64, 200, 257, 511, 700]))
+    cores = int(rng.integers(2, 7))
+    n = npc * cores
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=npc, cores_used=cores,
+                                  out_degree=int(min(n, rng.choice([5, 40, 150, 400]))), arch_kind=kind, delays=delays,
+                                  p_fire=float(rng.choice([0.01, 0.05, 0.3])), seed=seed,
+                                  weights=str(rng.choice(["int", "int", "int12"])), refractory=bool(rng.integers(0, 2)))
+    check_batched(S, arch, net, steps=14)
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:
