@@ -675,10 +675,10 @@ deliver_kernel(DevImage im, DevState st)
 #pragma unroll
                     for (int u = 0; u < STREAM_DEPTH; u++)
                     {
-                        const uint4 cur_g = sq[u];
+                        // add, then refill the same registers (the other groups of the window are still in flight)
+                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u]);
                         const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
                         if (nxt < st_groups) sq[u] = st_src[nxt];
-                        if (g + (uint32_t) u * WAVE < st_groups) add4(cur_g);
                     }
                 }
                 // processing delay of the chunk's messages: axon-in latency per message + per-event latency
