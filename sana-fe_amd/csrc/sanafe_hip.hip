@@ -1,7 +1,7 @@
 // sanafe_hip.hip -- SANA-FE's per-timestep simulation loop for MI355X (gfx950, CDNA4).
 //
-// Implements the C ABI of include/sanafe_hip.h.  Three kernels per timestep, all on one
-// HIP stream, no host round trip between steps (the timestep counter lives on the device):
+// Implements the C ABI of include/sanafe_hip.h.  Two launches per timestep, all on one
+// HIP stream, no host round trip between steps:
 //
 //   K1 neuron_kernel   one 256-thread workgroup per simulated core, its 64-slot chunks dealt to the 4
 //                      wavefronts; SoA neuron state, coalesced 8-byte loads; soma update (LIF / TrueNorth /
@@ -20,8 +20,9 @@
 //                      expansion to synaptic events).  The chunk loop is software-pipelined.
 //                      Reference: process_messages / process_message, src/chip.cpp:656-764;
 //                      AccumulatorModel / AccumulatorWithDelayModel src/models.cpp:71-131.
-//   K3 reduce_kernel   fixed-order reduction of the per-core partials into the timestep
-//                      totals, simple timing model, run totals, t += 1.
+//   K3 reduce_step     fixed-order reduction of the per-core partials into the timestep totals, simple
+//                      timing model, run totals, t += 1.  Runs in workgroup 0 of the NEXT step's neuron
+//                      launch (a timestep is two launches); reduce_kernel flushes the last step.
 //                      Reference: sim_calculate_ts_energy, sim_update_ts_counters,
 //                      schedule_messages_timestep_simple, src/chip.cpp:1028-1051, 1171-1261;
 //                      src/schedule.cpp:61-102.
@@ -125,6 +126,17 @@ struct DevImage
     const double *syn_weight;
 };
 
+// The reduction of step s runs at the START of step s+1's neuron launch (its workgroup 0), so a timestep costs
+// two launches instead of three; the per-core partials of consecutive steps therefore live in two alternating
+// halves ("parity" = steps simulated before the step, & 1).  A trailing reduce_kernel flushes the last step
+// before anything reads results.
+struct PrevStep
+{
+    int valid;          // 0: nothing to reduce
+    int simple_timing, record, parity;
+    long long rec_index; // record slot of that step
+};
+
 struct DevState
 {
     double *v, *icur;
@@ -135,9 +147,9 @@ struct DevState
     uint8_t *ring_valid;   // [ring_slots][n_slots]
     uint32_t *bits_local;  // [n_slots/32]
     uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
-    CorePart *core_part;   // [n_cores]
+    CorePart *core_part;   // [2][n_cores], by step parity
     double *slice_proc;    // [n_slices]
-    double *core_proc;     // [n_cores]
+    double *core_proc;     // [2][n_cores], by step parity
     long long *t;          // timesteps simulated so far
     long long *rec;        // records written so far in this sim
     sanafe_hip_totals *run;       // run totals
@@ -172,20 +184,30 @@ __device__ __forceinline__ int cvt_int_x86(double x)
 // workgroup's 4 wavefronts (a 256-neuron TrueNorth core is one chunk per wave, a 1024-neuron
 // Loihi core four), every wave owns whole 64-slot chunks so the spike ballot maps 1:1 to bitmap words.
 // ---------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record, const int *ext_row)
+__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5]);
+
+__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record, const int *ext_row,
+        long long done /* steps simulated before this one */, long long rec, PrevStep prev)
 {
+    static_assert(NEURON_BLOCK == REDUCE_BLOCK, "workgroup 0 reduces the previous step");
+    if (blockIdx.x == 0 && prev.valid)
+    {
+        __shared__ double r_sd[REDUCE_BLOCK / WAVE][6];
+        __shared__ long long r_sl[REDUCE_BLOCK / WAVE][5];
+        reduce_step(im, st, prev, r_sd, r_sl);
+        __syncthreads();
+    }
+    const uint32_t parity_off = (uint32_t) (done & 1) * im.n_cores;
     __shared__ double s_d[NEURON_BLOCK / WAVE][5];
     __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const uint32_t core = blockIdx.x;
-    const long long done = *st.t;      // steps simulated before this one
     const long long t = done + 1;      // Timestep::timestep of this step
     const uint32_t nbase = im.core_nbase[core];
     const uint32_t ncount = im.core_ncount[core];
     const uint32_t rslot = (uint32_t) (t % im.ring_slots);
     double *ring = st.ring + (size_t) rslot * im.n_slots;
     uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
-    const long long rec = record ? *st.rec : 0;
     uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
 
     double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
@@ -406,8 +428,8 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         cp.packets = l[2];
         cp.hops = l[3];
         cp.events = l[4];
-        st.core_part[core] = cp;
-        st.core_proc[core] = 0.0; // the delivery slices of this step add their processing delays
+        st.core_part[parity_off + core] = cp;
+        st.core_proc[parity_off + core] = 0.0; // the delivery slices of this step add their processing delays
     }
 }
 
@@ -460,7 +482,7 @@ extern __shared__ __align__(16) unsigned char deliver_lds[];
 
 template <int SYN_FMT, bool HAS_DELAY>
 __global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, SANAFE_DELIVER_WAVES_PER_EU)))
-deliver_kernel(DevImage im, DevState st)
+deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
     __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
@@ -477,7 +499,7 @@ deliver_kernel(DevImage im, DevState st)
     // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
     // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
     const uint32_t RS = (SYN_FMT == 0) ? npad + 1u : npad;
-    const long long t = *st.t + 1;
+    const long long t = done + 1;
     const unsigned long long a_beg = im.slice_axon_beg[slice];
     const uint32_t n_ax = (uint32_t) (im.slice_axon_end[slice] - a_beg); // slices hold < 2^32 axons
     const unsigned long long syn_base = im.core_syn_base[core];
@@ -830,12 +852,12 @@ deliver_kernel(DevImage im, DevState st)
         for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
         // one add per slice; the order over a core's slices is not fixed, which moves the simple
         // timing model's per-core sum by at most an ulp or two (tolerance on sim_time is 1e-6)
-        atomicAdd(&st.core_proc[core], p);
+        atomicAdd(&st.core_proc[(uint32_t) (done & 1) * im.n_cores + core], p);
     }
 }
 
 // ---------------------------------------------------------------------------------------
-// K3: per-step reduction.  one workgroup of 1024 threads, fixed summation order
+// K3: per-step reduction (one workgroup, fixed summation order): inside the next neuron launch, or reduce_kernel
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_max(double x)
 {
@@ -844,17 +866,20 @@ __device__ __forceinline__ double wave_max(double x)
     return x;
 }
 
-__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, int simple_timing, int record)
+// One 256-thread workgroup reduces a finished step: per-thread partial over its cores -> wave reduction (shuffles)
+// -> one LDS slot per wave -> thread 0 combines the waves in order.  One barrier; the association is fixed, so
+// results are reproducible.  sim_calculate_ts_energy, sim_update_ts_counters, schedule_messages_timestep_simple
+// (src/chip.cpp:1028-1051, 1171-1261; src/schedule.cpp:61-102), update_run_data (src/chip.cpp:462-475).
+__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5])
 {
-    // every quantity: per-thread partial over its cores -> wave reduction (shuffles) -> one LDS slot per wave ->
-    // thread 0 combines the waves in order.  One barrier in all; the association is fixed, so results are reproducible.
-    __shared__ double sd[REDUCE_BLOCK / WAVE][6];
-    __shared__ long long sl[REDUCE_BLOCK / WAVE][5];
+    const int simple_timing = prev.simple_timing, record = prev.record;
+    const CorePart *core_part = st.core_part + (size_t) prev.parity * im.n_cores;
+    const double *core_proc = st.core_proc + (size_t) prev.parity * im.n_cores;
     double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
     long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
     for (uint32_t c = threadIdx.x; c < im.n_cores; c += REDUCE_BLOCK)
     {
-        const CorePart cp = st.core_part[c];
+        const CorePart cp = core_part[c];
         e_soma += cp.e_soma;
         e_dend += cp.e_dend;
         e_syn += cp.e_syn;
@@ -865,7 +890,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
         hops += cp.hops;
         events += cp.events;
         gmax = fmax(gmax, cp.gen_sum);
-        pmax = fmax(pmax, st.core_proc[c]);
+        pmax = fmax(pmax, core_proc[c]);
     }
     e_soma = wave_sum(e_soma);
     e_dend = wave_sum(e_dend);
@@ -946,21 +971,29 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
         *st.run = r;
         if (record)
         {
-            const long long rec = *st.rec;
             ts.timesteps = *st.t + 1; // the record carries the timestep number
-            st.step_log[rec % st.log_cap] = ts;
-            *st.rec = rec + 1;
+            st.step_log[prev.rec_index % st.log_cap] = ts;
+            *st.rec = prev.rec_index + 1;
         }
         *st.t = *st.t + 1;
     }
 }
 
-__global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has)
+// Flushes the reduction of the last launched step when no further neuron launch follows it.
+__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PrevStep prev)
+{
+    __shared__ double sd[REDUCE_BLOCK / WAVE][6];
+    __shared__ long long sl[REDUCE_BLOCK / WAVE][5];
+    reduce_step(im, st, prev, sd, sl);
+}
+
+__global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has,
+        long long done)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t g = slots[i];
-    const long long t = *st.t + 1;
+    const long long t = done + 1;
     const size_t gi = (size_t) (t % im.ring_slots) * im.n_slots + g;
     const uint32_t inkind = (im.slot_cls[g] >> 3) & 7u;
     if (inkind == SANAFE_IN_ZERO)
@@ -980,14 +1013,14 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
 }
 
 __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status,
-        const uint32_t *core, const double *energy, const double *latency)
+        const uint32_t *core, const double *energy, const double *latency, int parity)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t g = slots[i];
     const uint8_t s = status[i];
     st.status[g] = s;
-    CorePart *cp = st.core_part + core[i];
+    CorePart *cp = st.core_part + (size_t) parity * im.n_cores + core[i];
     atomicAdd(&cp->e_soma, energy[i]);
     atomicAdd(&cp->gen_sum, latency[i]);
     if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
@@ -1015,6 +1048,8 @@ struct sanafe_hip_chip
     hipStream_t stream{nullptr};
     bool own_stream{true};
     bool has_delay{false};
+    long long t_host{0};      // timesteps launched so far (the device's *st.t trails it by the pending reduction)
+    PrevStep pend{};          // the launched step whose reduction has not been launched yet
     int syn_format{2};        // 0: 2+1 B, 1: 4 B, 2: 4+8 B per synapse (DevImage)
     uint32_t n_compact_slices{0};
     DevImage im{};
@@ -1468,9 +1503,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
     if (h.n_global_slots == h.n_slots) st.bits_global = st.bits_local;
     else TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
-    TRYC(dalloc(c, h.n_cores, &st.core_part));
+    TRYC(dalloc(c, 2 * (size_t) h.n_cores, &st.core_part));
     TRYC(dalloc(c, h.n_slices, &st.slice_proc));
-    TRYC(dalloc(c, h.n_cores, &st.core_proc));
+    TRYC(dalloc(c, 2 * (size_t) h.n_cores, &st.core_proc));
     TRYC(dalloc(c, 1, &st.t));
     TRYC(dalloc(c, 1, &st.rec));
     TRYC(dalloc(c, 1, &st.run));
@@ -1544,7 +1579,8 @@ static int ensure_log(sanafe_hip_chip *c, long long steps)
     return 0;
 }
 
-static int launch_neurons(sanafe_hip_chip *c, int record)
+// ---- one timestep = neuron launch (which first reduces the previous step) + delivery launch ----
+static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 {
     const int *ext_row = nullptr;
     if (c->im.n_ext > 0)
@@ -1554,8 +1590,10 @@ static int launch_neurons(sanafe_hip_chip *c, int record)
         ext_row = c->d_ext + (size_t) c->ext_next * c->im.n_ext;
         c->ext_next++;
     }
-    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record, ext_row);
+    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record, ext_row,
+            c->t_host, rec_index, c->pend);
     HIPCHK(hipGetLastError());
+    c->pend.valid = 0; // reduced by workgroup 0 of that launch
     return 0;
 }
 static int launch_deliver(sanafe_hip_chip *c)
@@ -1563,7 +1601,8 @@ static int launch_deliver(sanafe_hip_chip *c)
     if (c->im.n_slices > 0)
     {
         const dim3 grid(c->im.n_slices), block(DELIVER_BLOCK);
-#define SANAFE_LAUNCH_DELIVER(F, DLY) hipLaunchKernelGGL((deliver_kernel<F, DLY>), grid, block, c->deliver_lds, c->stream, c->im, c->st)
+#define SANAFE_LAUNCH_DELIVER(F, DLY) \
+    hipLaunchKernelGGL((deliver_kernel<F, DLY>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
         if (c->syn_format == 0 && c->has_delay) SANAFE_LAUNCH_DELIVER(0, true);
         else if (c->syn_format == 0) SANAFE_LAUNCH_DELIVER(0, false);
         else if (c->syn_format == 1 && c->has_delay) SANAFE_LAUNCH_DELIVER(1, true);
@@ -1575,10 +1614,22 @@ static int launch_deliver(sanafe_hip_chip *c)
     }
     return 0;
 }
-static int launch_reduce(sanafe_hip_chip *c, int simple_timing, int record)
+// The reduction of the step just launched is left pending: the next neuron launch performs it, or flush_pending.
+static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long long rec_index)
 {
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(REDUCE_BLOCK), 0, c->stream, c->im, c->st, simple_timing, record);
+    c->pend.valid = 1;
+    c->pend.simple_timing = simple_timing;
+    c->pend.record = record;
+    c->pend.parity = (int) (c->t_host & 1);
+    c->pend.rec_index = rec_index;
+    c->t_host += 1;
+}
+static int flush_pending(sanafe_hip_chip *c)
+{
+    if (!c->pend.valid) return 0;
+    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(REDUCE_BLOCK), 0, c->stream, c->im, c->st, c->pend);
     HIPCHK(hipGetLastError());
+    c->pend.valid = 0;
     return 0;
 }
 
@@ -1588,6 +1639,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     HIPCHK(hipSetDevice(c->device));
     if (record)
     {
+        TRY(flush_pending(c)); // an earlier step's record must not land in the resized log
         TRY(ensure_log(c, n_steps));
         HIPCHK(hipMemsetAsync(c->st.rec, 0, sizeof(long long), c->stream));
     }
@@ -1595,9 +1647,9 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     {
         for (int64_t s = 0; s < n_steps; s++)
         {
-            TRY(launch_neurons(c, record));
+            TRY(launch_neurons(c, record, s));
             TRY(launch_deliver(c));
-            TRY(launch_reduce(c, simple_timing, record));
+            finish_step(c, simple_timing, record, s);
         }
         return 0;
     }
@@ -1606,12 +1658,14 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int64_t s = 0; s < n_steps; s++)
     {
+        TRY(flush_pending(c)); // timed steps keep the three phases apart
         HIPCHK(hipEventRecord(ev[s * 4 + 0], c->stream));
-        TRY(launch_neurons(c, record));
+        TRY(launch_neurons(c, record, s));
         HIPCHK(hipEventRecord(ev[s * 4 + 1], c->stream));
         TRY(launch_deliver(c));
         HIPCHK(hipEventRecord(ev[s * 4 + 2], c->stream));
-        TRY(launch_reduce(c, simple_timing, record));
+        finish_step(c, simple_timing, record, s);
+        TRY(flush_pending(c));
         HIPCHK(hipEventRecord(ev[s * 4 + 3], c->stream));
     }
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -1662,6 +1716,7 @@ extern "C" int sanafe_hip_synchronize(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -1680,9 +1735,10 @@ extern "C" int sanafe_hip_step_neurons(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
-    if (!c->timing) return launch_neurons(c, 0);
+    if (!c->timing) return launch_neurons(c, 0, 0);
+    TRY(flush_pending(c));
     TRY(timed_event(c));
-    TRY(launch_neurons(c, 0));
+    TRY(launch_neurons(c, 0, 0));
     return timed_event(c);
 }
 
@@ -1690,16 +1746,22 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
-    if (record) TRY(ensure_log(c, 1));
+    if (record)
+    {
+        TRY(flush_pending(c));
+        TRY(ensure_log(c, 1));
+    }
     if (!c->timing)
     {
         TRY(launch_deliver(c));
-        return launch_reduce(c, simple_timing, 0);
+        finish_step(c, simple_timing, 0, 0);
+        return 0;
     }
     TRY(timed_event(c));
     TRY(launch_deliver(c));
     TRY(timed_event(c));
-    TRY(launch_reduce(c, simple_timing, 0));
+    finish_step(c, simple_timing, 0, 0);
+    TRY(flush_pending(c));
     return timed_event(c);
 }
 
@@ -1736,6 +1798,7 @@ extern "C" int sanafe_hip_set_stream(sanafe_hip_chip *c, void *stream)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->own_stream) HIPCHK(hipStreamDestroy(c->stream));
     c->stream = static_cast<hipStream_t>(stream);
@@ -1761,12 +1824,15 @@ template <typename T> static int h2d(sanafe_hip_chip *c, T *dst, const T *src, s
 extern "C" int sanafe_hip_read_totals(sanafe_hip_chip *c, sanafe_hip_totals *out)
 {
     if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
     return d2h(c, out, c->st.run, 1);
 }
 extern "C" int sanafe_hip_reset_totals(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
     HIPCHK(hipMemsetAsync(c->st.run, 0, sizeof(sanafe_hip_totals), c->stream));
     return 0;
 }
@@ -1774,6 +1840,8 @@ extern "C" int sanafe_hip_read_step_totals(sanafe_hip_chip *c, int64_t first, in
 {
     if (!c || !out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.step_log)
         return fail(SANAFE_HIP_ERR_INVALID, "step records [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
     return d2h(c, out, c->st.step_log + first, (size_t) count);
 }
 extern "C" int sanafe_hip_read_step_spikes(sanafe_hip_chip *c, int64_t index, uint32_t *bits_out)
@@ -1801,13 +1869,16 @@ extern "C" int sanafe_hip_read_input_current(sanafe_hip_chip *c, double *out)
 extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, double *proc_sum)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
+    const size_t last_parity = (size_t) ((c->t_host > 0 ? c->t_host - 1 : 0) & 1); // the step launched last
     if (gen_sum)
     {
         std::vector<CorePart> cp(c->im.n_cores);
-        TRY(d2h(c, cp.data(), c->st.core_part, cp.size()));
+        TRY(d2h(c, cp.data(), c->st.core_part + last_parity * c->im.n_cores, cp.size()));
         for (uint32_t k = 0; k < c->im.n_cores; k++) gen_sum[k] = cp[k].gen_sum;
     }
-    if (proc_sum) TRY(d2h(c, proc_sum, c->st.core_proc, c->im.n_cores));
+    if (proc_sum) TRY(d2h(c, proc_sum, c->st.core_proc + last_parity * c->im.n_cores, c->im.n_cores));
     return 0;
 }
 
@@ -1918,7 +1989,7 @@ extern "C" int sanafe_hip_read_host_inputs(sanafe_hip_chip *c, uint32_t count, c
     TRY(ensure_host_staging(c, count));
     HIPCHK(hipMemcpyAsync(c->d_host_slots, slots, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(host_input_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
-            c->d_host_slots, c->d_host_a, c->d_host_status);
+            c->d_host_slots, c->d_host_a, c->d_host_status, c->t_host);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(current_out, c->d_host_a, (size_t) count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipMemcpyAsync(has_out, c->d_host_status, (size_t) count, hipMemcpyDeviceToHost, c->stream));
@@ -1942,7 +2013,7 @@ extern "C" int sanafe_hip_write_host_status(sanafe_hip_chip *c, uint32_t count, 
     HIPCHK(hipMemcpyAsync(c->d_host_a, energy, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_host_b, latency, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
-            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b);
+            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b, (int) (c->t_host & 1));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
