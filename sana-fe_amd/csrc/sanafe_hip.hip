@@ -217,7 +217,14 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
     {
         const uint32_t g = nbase + off + lane;
         const bool live = (off + lane) < ncount;
-        uint32_t cls = live ? im.slot_cls[g] : 0u;
+        // every load that does not depend on the neuron's class is issued up front (padding slots exist in all
+        // per-slot arrays), so the class-table lookups overlap with them instead of preceding them
+        const uint32_t cls_raw = im.slot_cls[g];
+        const uint8_t in_valid = rvalid[g];
+        const double in_value = ring[g];
+        const double bias = im.slot_bias[g];
+        const double v_in = st.v[g];
+        uint32_t cls = live ? cls_raw : 0u;
         const uint32_t model = cls & 7u;
         int status = 0;
         if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
@@ -234,16 +241,15 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             }
             else
             {
-                has_in = rvalid[g] != 0;
+                has_in = in_valid != 0;
                 cur = 0.0;
                 if (has_in)
                 {
-                    cur = ring[g];
+                    cur = in_value;
                     ring[g] = 0.0;
                     rvalid[g] = 0;
                 }
             }
-            const double bias = im.slot_bias[g];
             // host-generated value of a sequential source this neuron consumes at every update
             // (Poisson draw, std::rand() & mask, noise file): include/sanafe_hip.h, slot_ext
             bool has_ext = false;
@@ -258,7 +264,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             {
                 // LoihiLifModel::update, src/models.cpp:497-567
                 const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
-                double v = st.v[g];
+                double v = v_in;
                 double ic = st.icur[g];
                 int rc = st.refrac[g];
                 status = 1;
@@ -300,7 +306,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             {
                 // TrueNorthModel::update, src/models.cpp:724-830
                 const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
-                double v = st.v[g];
+                double v = v_in;
                 status = 1;
                 if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
                 if (p.leak_towards_zero)
