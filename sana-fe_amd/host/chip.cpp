@@ -501,7 +501,6 @@ struct sanafe_chip
     // ---- detailed timing model: src/schedule.cpp:208-620 ----
     struct Noc
     {
-        std::vector<std::list<Msg>> received;
         size_t w, h, max_cpt;
         std::vector<double> density, core_finished;
         double mean_delay{0.0};
@@ -558,42 +557,74 @@ struct sanafe_chip
     {
         bool operator()(const Msg &a, const Msg &b) const noexcept { return a.sent_timestamp > b.sent_timestamp; }
     };
+    // schedule_messages_timestep_detailed, src/schedule.cpp:208-292, with the same arithmetic in the same order but
+    // without its O(cores) scan per scheduled message: the reference walks every core's list of in-flight messages
+    // at each pop (noc_update_all_tracked_messages, :380-400) and retires those received by `now`, in (core, list)
+    // order.  Here the in-flight messages sit in a min-heap on their received time; the ones due are popped,
+    // put back into (destination core, arrival) order and retired -- the identical sequence of density and
+    // rolling-average updates, so every timestamp is bit-identical (checked against the oracle, which keeps the scan).
     double schedule_detailed(std::vector<std::vector<Msg>> &per_core) const
     {
         Noc noc;
         noc.w = mc.noc_width;
         noc.h = mc.noc_height;
         noc.max_cpt = mc.max_cores_per_tile;
-        noc.received.resize(mc.n_cores);
         noc.core_finished.assign(mc.n_cores, 0.0);
         noc.density.assign(static_cast<size_t>(mc.noc_height) * mc.noc_width * (4 + mc.max_cores_per_tile), 0.0);
         std::vector<size_t> head(mc.n_cores, 0);
         std::vector<std::vector<Msg>> scheduled(mc.n_cores);
-        std::priority_queue<Msg, std::vector<Msg>, BySent> pq;
+        // The send queue holds handles; its order depends only on the comparisons, which are the reference's
+        // (CompareMessagesBySentTime, src/message.cpp:61-65), so ties break exactly as there.
+        struct Pending
+        {
+            double sent;
+            Msg *m;
+        };
+        struct BySentHandle
+        {
+            bool operator()(const Pending &a, const Pending &b) const noexcept { return a.sent > b.sent; }
+        };
+        std::priority_queue<Pending, std::vector<Pending>, BySentHandle> pq;
+        std::deque<Msg> live; // messages taken off their source core's FIFO (stable addresses)
+        struct InFlight
+        {
+            double received;
+            uint64_t seq; // arrival order at its destination core's list
+            Msg m;
+        };
+        struct ByReceived
+        {
+            bool operator()(const InFlight &a, const InFlight &b) const noexcept { return a.received > b.received; }
+        };
+        std::priority_queue<InFlight, std::vector<InFlight>, ByReceived> in_flight;
+        std::vector<InFlight> due;
+        uint64_t seq = 0;
         for (uint32_t c = 0; c < mc.n_cores; c++)
             if (!per_core[c].empty())
             {
-                Msg m = per_core[c][head[c]++];
+                live.push_back(per_core[c][head[c]++]);
+                Msg &m = live.back();
                 m.sent_timestamp = m.generation_delay;
-                pq.push(m);
+                pq.push(Pending{m.sent_timestamp, &m});
             }
         double last = 0.0;
         while (!pq.empty())
         {
-            Msg m = pq.top();
+            Msg m = *pq.top().m;
             pq.pop();
             last = std::max(last, m.sent_timestamp);
             const double tnow = m.sent_timestamp;
-            for (auto &q : noc.received) // noc_update_all_tracked_messages
-                q.remove_if([&](Msg &r) {
-                    if (r.in_noc && tnow >= r.received_timestamp)
-                    {
-                        r.in_noc = false;
-                        track(noc, r, false);
-                        return true;
-                    }
-                    return false;
+            due.clear();
+            while (!in_flight.empty() && tnow >= in_flight.top().received)
+            {
+                due.push_back(in_flight.top());
+                in_flight.pop();
+            }
+            if (due.size() > 1)
+                std::sort(due.begin(), due.end(), [](const InFlight &a, const InFlight &b) {
+                    return a.m.dest_core_id != b.m.dest_core_id ? a.m.dest_core_id < b.m.dest_core_id : a.seq < b.seq;
                 });
+            for (const InFlight &r : due) track(noc, r.m, false);
             if (!m.placeholder) // schedule_handle_message
             {
                 const size_t dc = m.dest_core_id;
@@ -617,16 +648,17 @@ struct sanafe_chip
                 noc.core_finished[dc] = std::max(noc.core_finished[dc] + m.processing_delay, earliest + m.processing_delay);
                 m.processed_timestamp = noc.core_finished[dc];
                 m.in_noc = true;
-                noc.received[dc].push_back(m);
+                in_flight.push(InFlight{m.received_timestamp, seq++, m});
                 track(noc, m, true);
                 last = std::max(last, m.processed_timestamp);
             }
             const size_t sc = m.src_core_id;
             if (head[sc] < per_core[sc].size()) // schedule_push_next_message
             {
-                Msg nx = per_core[sc][head[sc]++];
+                live.push_back(per_core[sc][head[sc]++]);
+                Msg &nx = live.back();
                 nx.sent_timestamp = m.sent_timestamp + nx.generation_delay;
-                pq.push(nx);
+                pq.push(Pending{nx.sent_timestamp, &nx});
                 last = std::max(last, nx.sent_timestamp);
             }
             scheduled[sc].push_back(m);

@@ -119,6 +119,21 @@ def test_random_loihi_detailed_messages(S):
         assert a["sim_time"] == b["sim_time"]
 
 
+def test_detailed_scheduler_many_messages_in_flight(S):
+    """Thousands of messages per step over 64 cores: the heap-based retirement of in-flight messages performs the
+    reference's density / rolling-average updates in the reference's order (the oracle keeps its per-core scan)."""
+    arch, net = nets.random_loihi(S, n_tiles=16, neurons_per_core=40, out_degree=120, arch_kind="loihi", p_fire=0.3, seed=21)
+    chip, orc = make(S, arch, net)
+    for t in range(5):
+        a = chip.run(1, "detailed", record=True)
+        b = orc.step("detailed")
+        ma, mb = chip.step_messages(0), orc.messages()
+        assert len(ma) == len(mb) > 1000
+        for name in ma.dtype.names:
+            assert np.array_equal(ma[name], mb[name]), (t, name)
+        assert a["sim_time"] == b["sim_time"]
+
+
 def test_detailed_scheduler_threads_match_inline(S):
     """`scheduler_threads=n` (src/chip.cpp:291-349, src/schedule.cpp:182-206) overlaps the NoC schedule of finished
     steps with the GPU; every timestep's schedule is independent, so results equal the inline run bit for bit."""
