@@ -572,7 +572,7 @@ struct sanafe_chip
         noc.core_finished.assign(mc.n_cores, 0.0);
         noc.density.assign(static_cast<size_t>(mc.noc_height) * mc.noc_width * (4 + mc.max_cores_per_tile), 0.0);
         std::vector<size_t> head(mc.n_cores, 0);
-        std::vector<std::vector<Msg>> scheduled(mc.n_cores);
+        std::vector<std::vector<const Msg *>> sched_order(mc.n_cores); // pop order per source core
         // The send queue holds handles; its order depends only on the comparisons, which are the reference's
         // (CompareMessagesBySentTime, src/message.cpp:61-65), so ties break exactly as there.
         struct Pending
@@ -590,7 +590,7 @@ struct sanafe_chip
         {
             double received;
             uint64_t seq; // arrival order at its destination core's list
-            Msg m;
+            const Msg *m;
         };
         struct ByReceived
         {
@@ -610,7 +610,7 @@ struct sanafe_chip
         double last = 0.0;
         while (!pq.empty())
         {
-            Msg m = *pq.top().m;
+            Msg &m = *pq.top().m; // scheduled in place: `live` keeps addresses stable
             pq.pop();
             last = std::max(last, m.sent_timestamp);
             const double tnow = m.sent_timestamp;
@@ -622,9 +622,9 @@ struct sanafe_chip
             }
             if (due.size() > 1)
                 std::sort(due.begin(), due.end(), [](const InFlight &a, const InFlight &b) {
-                    return a.m.dest_core_id != b.m.dest_core_id ? a.m.dest_core_id < b.m.dest_core_id : a.seq < b.seq;
+                    return a.m->dest_core_id != b.m->dest_core_id ? a.m->dest_core_id < b.m->dest_core_id : a.seq < b.seq;
                 });
-            for (const InFlight &r : due) track(noc, r.m, false);
+            for (const InFlight &r : due) track(noc, *r.m, false);
             if (!m.placeholder) // schedule_handle_message
             {
                 const size_t dc = m.dest_core_id;
@@ -648,7 +648,7 @@ struct sanafe_chip
                 noc.core_finished[dc] = std::max(noc.core_finished[dc] + m.processing_delay, earliest + m.processing_delay);
                 m.processed_timestamp = noc.core_finished[dc];
                 m.in_noc = true;
-                in_flight.push(InFlight{m.received_timestamp, seq++, m});
+                in_flight.push(InFlight{m.received_timestamp, seq++, &m});
                 track(noc, m, true);
                 last = std::max(last, m.processed_timestamp);
             }
@@ -661,7 +661,13 @@ struct sanafe_chip
                 pq.push(Pending{nx.sent_timestamp, &nx});
                 last = std::max(last, nx.sent_timestamp);
             }
-            scheduled[sc].push_back(m);
+            sched_order[sc].push_back(&m);
+        }
+        std::vector<std::vector<Msg>> scheduled(mc.n_cores);
+        for (uint32_t c = 0; c < mc.n_cores; c++)
+        {
+            scheduled[c].reserve(sched_order[c].size());
+            for (const Msg *pm : sched_order[c]) scheduled[c].push_back(*pm);
         }
         per_core.swap(scheduled);
         return last + mc.sync_delay;
