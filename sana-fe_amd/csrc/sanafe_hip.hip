@@ -210,8 +210,11 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
     uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
     uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
 
-    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
-    long long n_upd = 0, n_fire = 0, n_pack = 0, n_hops = 0, n_ev = 0;
+    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0, e_dspk = 0.0; // per lane
+    long long n_pack = 0, n_hops = 0, n_ev = 0;                                         // per lane
+    double w_e_soma = 0.0, w_e_dend = 0.0, w_lat = 0.0;                                 // per wavefront (uniform)
+    long long w_upd = 0, w_fire = 0;
+    bool mixed = false, any_fire = false;                                               // wave-uniform
 
     for (uint32_t off = wave * WAVE; off < ncount; off += NEURON_BLOCK)
     {
@@ -230,7 +233,6 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
         {
             const uint32_t inkind = (cls >> 3) & 7u;
-            const sanafe_hip_cost_class &cc = im.cost_classes[(cls >> 6) & 1023u];
             // ---- synaptic input from the time-step buffer / delay ring (read, then clear) ----
             bool has_in;
             double cur;
@@ -353,28 +355,60 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 if (period > 0 && (t % period) == 0) send = true;
                 status = send ? 3 : 1;
             }
-            // ---- default costing, src/pipeline.hpp:574-731; sums as in execute_pipeline ----
-            e_dend += cc.dendrite_energy;
-            e_soma += cc.soma_energy[status - 1];
-            lat += (0.0 + cc.dendrite_latency) + cc.soma_latency[status - 1];
-            n_upd += status >= 2;
-            if (status == 3)
-            {
-                // everything this spike causes downstream is static per neuron
-                // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
-                n_fire += 1;
-                n_pack += im.slot_packets[g];
-                n_hops += im.slot_hops[g];
-                n_ev += im.slot_events[g];
-                e_net += im.slot_e_net[g];
-                e_syn += im.slot_e_syn[g];
-                e_dend += im.slot_e_dend[g];
-            }
         }
         // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
         // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
         if (live && model != SANAFE_SOMA_HOST) st.status[g] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
+        // ---- default costing, src/pipeline.hpp:574-731.  Counters and class costs are taken per wavefront from
+        //      ballots (no cross-lane reduction at the end); only what depends on the individual neuron -- the
+        //      static totals of a spike, or costs when the 64 neurons do not share one cost class -- is summed
+        //      per lane and reduced once, and only by wavefronts that saw such a case. ----
+        const bool counted = (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST);
+        const unsigned long long m_cnt = __ballot(counted);
+        if (m_cnt != 0ull) // wave-uniform
+        {
+            const unsigned long long m_upd = __ballot(status >= 2);
+            w_upd += __popcll(m_upd);
+            w_fire += __popcll(fired_mask);
+            const uint32_t ccid = (cls >> 6) & 1023u;
+            const uint32_t cc0 = (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
+            if (__ballot(counted && ccid != cc0) == 0ull)
+            {
+                const sanafe_hip_cost_class &c0 = im.cost_classes[cc0];
+                const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_mask),
+                             n_u = (double) __popcll(m_upd & ~fired_mask), n_i = (double) __popcll(m_cnt & ~m_upd);
+                w_e_soma += (n_i * c0.soma_energy[0] + n_u * c0.soma_energy[1]) + n_f * c0.soma_energy[2];
+                w_e_dend += n_all * c0.dendrite_energy;
+                w_lat += n_all * (0.0 + c0.dendrite_latency) + ((n_i * c0.soma_latency[0] + n_u * c0.soma_latency[1]) + n_f * c0.soma_latency[2]);
+            }
+            else
+            {
+                mixed = true;
+                if (counted)
+                {
+                    const sanafe_hip_cost_class &cc = im.cost_classes[ccid];
+                    e_dend += cc.dendrite_energy;
+                    e_soma += cc.soma_energy[status - 1];
+                    lat += (0.0 + cc.dendrite_latency) + cc.soma_latency[status - 1];
+                }
+            }
+            if (fired_mask != 0ull)
+            {
+                any_fire = true;
+                if (status == 3 && counted)
+                {
+                    // everything this spike causes downstream is static per neuron
+                    // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
+                    n_pack += im.slot_packets[g];
+                    n_hops += im.slot_hops[g];
+                    n_ev += im.slot_events[g];
+                    e_net += im.slot_e_net[g];
+                    e_syn += im.slot_e_syn[g];
+                    e_dspk += im.slot_e_dend[g];
+                }
+            }
+        }
         if (lane == 0)
         {
             const uint32_t w = (nbase + off) >> 5;
@@ -387,16 +421,25 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             }
         }
     }
-    e_soma = wave_sum(e_soma);
-    e_dend = wave_sum(e_dend);
-    e_syn = wave_sum(e_syn);
-    e_net = wave_sum(e_net);
-    lat = wave_sum(lat);
-    n_upd = wave_sum(n_upd);
-    n_fire = wave_sum(n_fire);
-    n_pack = wave_sum(n_pack);
-    n_hops = wave_sum(n_hops);
-    n_ev = wave_sum(n_ev);
+    if (mixed)
+    {
+        w_e_soma += wave_sum(e_soma);
+        w_e_dend += wave_sum(e_dend);
+        w_lat += wave_sum(lat);
+    }
+    if (any_fire)
+    {
+        e_syn = wave_sum(e_syn);
+        e_net = wave_sum(e_net);
+        w_e_dend += wave_sum(e_dspk);
+        n_pack = wave_sum(n_pack);
+        n_hops = wave_sum(n_hops);
+        n_ev = wave_sum(n_ev);
+    }
+    e_soma = w_e_soma;
+    e_dend = w_e_dend;
+    lat = w_lat;
+    const long long n_upd = w_upd, n_fire = w_fire;
     if (lane == 0)
     {
         s_d[wave][0] = e_soma;
