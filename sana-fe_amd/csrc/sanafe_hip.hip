@@ -158,17 +158,41 @@ struct DevState
     long long log_cap;
 };
 
+// Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles (the neuron kernel's
+// waves spent a third of their cycles waiting to issue those): Hillis-Steele inside each 16-lane row, row_bcast:15
+// and row_bcast:31 across rows, total in lane 63.  Lanes without a source read 0 bits = +0.0 / 0.  Fixed order.
+#define SANAFE_DPP_STEPS(STEP)                  \
+    STEP(0x111, 0xf) /* row_shr:1 */            \
+    STEP(0x112, 0xf) /* row_shr:2 */            \
+    STEP(0x114, 0xf) /* row_shr:4 */            \
+    STEP(0x118, 0xf) /* row_shr:8 */            \
+    STEP(0x142, 0xa) /* row_bcast:15 */         \
+    STEP(0x143, 0xc) /* row_bcast:31 */
 __device__ __forceinline__ double wave_sum(double x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
-    return x;
+#define SANAFE_STEP(CTRL, ROWS)                                                                   \
+    {                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, false); \
+        x += __hiloint2double(hi, lo);                                                            \
+    }
+    SANAFE_DPP_STEPS(SANAFE_STEP)
+#undef SANAFE_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
 }
 __device__ __forceinline__ long long wave_sum(long long x)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, WAVE);
-    return x;
+#define SANAFE_STEP(CTRL, ROWS)                                                                            \
+    {                                                                                                      \
+        const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) x, CTRL, ROWS, 0xf, false);          \
+        const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) ((unsigned long long) x >> 32), CTRL, ROWS, 0xf, false); \
+        x += (long long) (((unsigned long long) hi << 32) | lo);                                           \
+    }
+    SANAFE_DPP_STEPS(SANAFE_STEP)
+#undef SANAFE_STEP
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) x, 63);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) x >> 32), 63);
+    return (long long) (((unsigned long long) hi << 32) | lo);
 }
 
 // static_cast<int>(double) as x86-64 performs it (cvttsd2si): out-of-range and NaN give INT_MIN.
