@@ -61,7 +61,10 @@ enum { SANAFE_SOMA_NONE = 0, SANAFE_SOMA_LIF = 1, SANAFE_SOMA_TRUENORTH = 2,
 /* how a neuron's synaptic input reaches its soma */
 enum {
     SANAFE_IN_BUFFERED = 0,   /* accumulator + kernel time-step buffer, or delay line: read slot t % ring_slots */
-    SANAFE_IN_ZERO = 1        /* `accumulator` with the buffer inside the unit: always 0.0 */
+    SANAFE_IN_ZERO = 1,       /* `accumulator` with the buffer inside the unit: always 0.0 */
+    SANAFE_IN_LAST = 2        /* buffer before the dendrite unit (`buffer_position: dendrite`, outside): the kernel's
+                                 time-step buffer keeps only the LAST synaptic event's current (src/chip.cpp:759), which the
+                                 accumulator then integrates alone; always "has input" (the lazy clear leaves 0.0) */
 };
 /* NeuronResetModes (src/arch.hpp:61-68) */
 enum { SANAFE_RESET_NONE = 0, SANAFE_RESET_SOFT = 1, SANAFE_RESET_HARD = 2, SANAFE_RESET_SATURATE = 3 };

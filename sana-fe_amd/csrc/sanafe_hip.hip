@@ -124,6 +124,8 @@ struct DevImage
     //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64
     const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
     const double *syn_weight;
+    int syn_format;               // 0 / 1 / 2 as above
+    int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
 };
 
 // The reduction of step s runs at the START of step s+1's neuron launch (its workgroup 0), so a timestep costs
@@ -145,6 +147,7 @@ struct DevState
     uint32_t *in_pos;
     double *ring;          // [ring_slots][n_slots]
     uint8_t *ring_valid;   // [ring_slots][n_slots]
+    uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
     uint32_t *bits_local;  // [n_slots/32]
     uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
     CorePart *core_part;   // [2][n_cores], by step parity
@@ -264,6 +267,22 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             {
                 has_in = true;
                 cur = 0.0;
+            }
+            else if (inkind == SANAFE_IN_LAST)
+            {
+                // the accumulator integrates the one current the time-step buffer kept, after its lazy clear
+                // (src/models.cpp:71-94): 0.0 + w_last, or plain 0.0 -- a value either way
+                has_in = true;
+                cur = 0.0;
+                const uint32_t last = st.ring_last[g];
+                if (last != 0u)
+                {
+                    const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
+                    const double w = (im.syn_format == 2) ? im.syn_weight[pos]
+                                                          : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
+                    cur = 0.0 + w;
+                    st.ring_last[g] = 0u;
+                }
             }
             else
             {
@@ -553,7 +572,11 @@ __device__ __forceinline__ void wave_lds_fence()
 
 extern __shared__ __align__(16) unsigned char deliver_lds[];
 
-template <int SYN_FMT, bool HAS_DELAY>
+// LAST: the chip has cores whose time-step buffer sits before the dendrite unit (SANAFE_IN_LAST): for those cores the
+// workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
+// instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
+// (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
+template <int SYN_FMT, bool HAS_DELAY, bool LAST>
 __global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, SANAFE_DELIVER_WAVES_PER_EU)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
@@ -589,10 +612,16 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
+    const bool last_mode = LAST && (((im.slot_cls[nbase] >> 3) & 7u) == SANAFE_IN_LAST); // workgroup-uniform
+    uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
 
     for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
     {
-        if (TOUCH_BYTES)
+        if (LAST && last_mode)
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = 0ull; // two `lastv` entries
+        }
+        else if (TOUCH_BYTES)
         {
             acc[i] = 0.0;
             touched[i] = 0;
@@ -639,12 +668,13 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     bool hot = false;
     uint4 sq[STREAM_DEPTH];
     const uint4 *st_src = nullptr;
-    uint32_t st_groups = 0;
+    uint32_t st_groups = 0, st_pos0 = 0;
     constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
     uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // axon offset of the chunk inside the slice
     auto stream_preload = [&]() {
         const uint32_t ci = c0 / WAVE_CHUNK;
         const uint32_t s0 = chunk_syn0[ci];
+        st_pos0 = s0;
         st_groups = (chunk_syn0[ci + 1] - s0) >> 2; // chunks are 16-byte aligned and padded (format 0)
         st_src = reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
 #pragma unroll
@@ -747,7 +777,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 wave_lds_fence();
                 if (!hot) stream_preload();
                 hot = true;
-                auto add4 = [&](const uint4 &g) {
+                auto add4 = [&](const uint4 &g, uint32_t pos0 /* position of g.x among the core's synapses */) {
                     const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
                     uint32_t fired[4];
 #pragma unroll
@@ -760,8 +790,15 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     for (int u = 0; u < 4; u++)
                         if (fired[u])
                         {
-                            const uint32_t idx = (HAS_DELAY ? __umul24((w4[u] >> 12) & 7u, RS) : 0u) + (w4[u] & 0xfffu);
-                            atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
+                            if (LAST && last_mode)
+                            {
+                                atomicMax(&lastv[w4[u] & 0xfffu], pos0 + (uint32_t) u + 1u);
+                            }
+                            else
+                            {
+                                const uint32_t idx = (HAS_DELAY ? __umul24((w4[u] >> 12) & 7u, RS) : 0u) + (w4[u] & 0xfffu);
+                                atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
+                            }
                         }
                 };
                 // rolling window: STREAM_DEPTH 16-byte groups per lane in flight while one is added
@@ -771,7 +808,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     for (int u = 0; u < STREAM_DEPTH; u++)
                     {
                         // add, then refill the same registers (the other groups of the window are still in flight)
-                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u]);
+                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
                         const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
                         if (nxt < st_groups) sq[u] = st_src[nxt];
                     }
@@ -851,6 +888,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             for (uint32_t e0 = 0; e0 < w_end; e0 += WAVE * EXPAND_UNROLL)
             {
                 uint32_t meta[EXPAND_UNROLL]; // post (16b) | delay << 16 | drop << 19, whatever the stored format
+                uint32_t spos[EXPAND_UNROLL]; // position among the core's synapses (used in last_mode)
                 double wgt[EXPAND_UNROLL];
 #pragma unroll
                 for (int u = 0; u < EXPAND_UNROLL; u++)
@@ -858,6 +896,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     const uint32_t tile = e0 + u * WAVE;
                     meta[u] = 1u << 19; // "drop": nothing to add
                     wgt[u] = 0.0;
+                    spos[u] = 0u;
                     if (tile < w_end) // wave-uniform
                     {
                         const unsigned long long h = (unsigned long long) w_pref[tile >> 5] | ((unsigned long long) w_pref[(tile >> 5) + 1] << 32);
@@ -867,7 +906,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         const uint32_t e = w0 + tile + lane;
                         if (e < n_ev)
                         {
-                            const unsigned long long s = syn_base + (uint32_t) (w_beg[owner] + e);
+                            spos[u] = (uint32_t) (w_beg[owner] + e);
+                            const unsigned long long s = syn_base + spos[u];
                             if (SYN_FMT == 0)
                             {
                                 const uint32_t m = im.syn_meta[s];
@@ -892,6 +932,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 for (int u = 0; u < EXPAND_UNROLL; u++)
                     if (!((meta[u] >> 19) & 1u))
                     {
+                        if (LAST && last_mode)
+                        {
+                            atomicMax(&lastv[meta[u] & 0xffffu], spos[u] + 1u);
+                            continue;
+                        }
                         const uint32_t idx = (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
                         atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
                         if (TOUCH_BYTES) touched[idx] = 1;
@@ -904,6 +949,13 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     __syncthreads();
     // ---- write the accumulated charge back (one RMW per touched neuron and delay value) ----
     const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
+    if (LAST && last_mode)
+    {
+        // the latest event over all slices of the core wins: positions grow in delivery order
+        for (uint32_t n = threadIdx.x; n < npad; n += DELIVER_BLOCK)
+            if (lastv[n] != 0u) atomicMax(&st.ring_last[nbase + n], lastv[n]);
+    }
+    else
     for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
     {
         if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
@@ -1075,6 +1127,22 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
         cur[i] = 0.0;
         return;
     }
+    if (inkind == SANAFE_IN_LAST)
+    {
+        has[i] = 1;
+        double c = 0.0;
+        const uint32_t last = st.ring_last[g];
+        if (last != 0u)
+        {
+            uint32_t core = 0; // the slot's core: cores are few, slots of a core contiguous
+            while (core + 1 < im.n_cores && im.core_nbase[core + 1] <= g) core++;
+            const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
+            c = 0.0 + ((im.syn_format == 2) ? im.syn_weight[pos] : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20)));
+            st.ring_last[g] = 0u;
+        }
+        cur[i] = c;
+        return;
+    }
     const uint8_t h = st.ring_valid[gi];
     has[i] = h;
     cur[i] = h ? st.ring[gi] : 0.0;
@@ -1220,6 +1288,15 @@ int validate(const sanafe_hip_image *im)
         next = (uint64_t) im->core_nbase[c] + ((im->core_ncount[c] + 63u) & ~63u);
         if (next > im->n_slots) return fail(SANAFE_HIP_ERR_INVALID, "core %u overruns n_slots", c);
         if (im->core_ncount[c] > 65536) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "core %u has more than 65536 neurons", c);
+        // the buffer position is a property of the core: SANAFE_IN_LAST for all of its neurons or for none
+        bool any_last = false, any_other = false;
+        for (uint32_t k = 0; k < im->core_ncount[c]; k++)
+        {
+            const uint32_t cl = im->slot_cls[im->core_nbase[c] + k];
+            if ((cl & 7u) == SANAFE_SOMA_NONE) continue;
+            ((((cl >> 3) & 7u) == SANAFE_IN_LAST) ? any_last : any_other) = true;
+        }
+        if (any_last && any_other) return fail(SANAFE_HIP_ERR_INVALID, "core %u mixes SANAFE_IN_LAST with other input kinds", c);
     }
     for (uint32_t s = 0; s < im->n_slices; s++)
     {
@@ -1284,6 +1361,7 @@ int validate(const sanafe_hip_image *im)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
+        if (((cls >> 3) & 7u) > SANAFE_IN_LAST) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
     }
     if (im->n_ext > 0)
     {
@@ -1573,6 +1651,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(dalloc(c, h.n_input, &st.in_pos));
     TRYC(dalloc(c, (size_t) h.ring_slots * h.n_slots, &st.ring));
     TRYC(dalloc(c, (size_t) h.ring_slots * h.n_slots, &st.ring_valid));
+    im.has_last = 0;
+    for (uint32_t g = 0; g < h.n_slots && !im.has_last; g++)
+        im.has_last = ((h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST) ? 1 : 0;
+    st.ring_last = nullptr;
+    if (im.has_last) TRYC(dalloc(c, h.n_slots, &st.ring_last));
     TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
     if (h.n_global_slots == h.n_slots) st.bits_global = st.bits_local;
     else TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
@@ -1606,10 +1689,18 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     }
     c->deliver_lds = (size_t) im.delay_slots * (max_pad + 1) * (sizeof(double) + 1);
     c->has_delay = im.delay_slots > 1;
+    im.syn_format = c->syn_format;
+    if (im.has_last && c->has_delay)
+        return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "cores with the buffer before the dendrite unit cannot be mixed with synaptic delays"));
     if (c->deliver_lds + 9 * 1024 > 160 * 1024)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu B of LDS (> 160 KiB)",
                 max_pad, im.delay_slots, c->deliver_lds));
-#define SANAFE_SET_LDS(F, DLY) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, DLY>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
+#define SANAFE_SET_LDS(F, DLY) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, DLY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
+#define SANAFE_SET_LDS_LAST(F) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
+    SANAFE_SET_LDS_LAST(0);
+    SANAFE_SET_LDS_LAST(1);
+    SANAFE_SET_LDS_LAST(2);
+#undef SANAFE_SET_LDS_LAST
     SANAFE_SET_LDS(0, true);
     SANAFE_SET_LDS(0, false);
     SANAFE_SET_LDS(1, true);
@@ -1675,14 +1766,20 @@ static int launch_deliver(sanafe_hip_chip *c)
     {
         const dim3 grid(c->im.n_slices), block(DELIVER_BLOCK);
 #define SANAFE_LAUNCH_DELIVER(F, DLY) \
-    hipLaunchKernelGGL((deliver_kernel<F, DLY>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
-        if (c->syn_format == 0 && c->has_delay) SANAFE_LAUNCH_DELIVER(0, true);
+    hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
+#define SANAFE_LAUNCH_DELIVER_LAST(F) \
+    hipLaunchKernelGGL((deliver_kernel<F, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
+        if (c->im.has_last && c->syn_format == 0) SANAFE_LAUNCH_DELIVER_LAST(0);
+        else if (c->im.has_last && c->syn_format == 1) SANAFE_LAUNCH_DELIVER_LAST(1);
+        else if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(2);
+        else if (c->syn_format == 0 && c->has_delay) SANAFE_LAUNCH_DELIVER(0, true);
         else if (c->syn_format == 0) SANAFE_LAUNCH_DELIVER(0, false);
         else if (c->syn_format == 1 && c->has_delay) SANAFE_LAUNCH_DELIVER(1, true);
         else if (c->syn_format == 1) SANAFE_LAUNCH_DELIVER(1, false);
         else if (c->has_delay) SANAFE_LAUNCH_DELIVER(2, true);
         else SANAFE_LAUNCH_DELIVER(2, false);
 #undef SANAFE_LAUNCH_DELIVER
+#undef SANAFE_LAUNCH_DELIVER_LAST
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -2102,6 +2199,7 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
     HIPCHK(hipMemsetAsync(c->st.status, 0, n, c->stream));
     HIPCHK(hipMemsetAsync(c->st.ring, 0, (size_t) c->im.ring_slots * n * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
+    if (c->st.ring_last) HIPCHK(hipMemsetAsync(c->st.ring_last, 0, n * sizeof(uint32_t), c->stream));
     return 0;
 }
 

@@ -647,14 +647,15 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         const UnitInfo &du = t.units[dend_unit[gid]];
         const UnitInfo &su = t.units[soma_unit[gid]];
         const int bp = d.core_buffer_pos[c];
-        if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE)
+        if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE && bp != SANAFE_BUF_BEFORE_DENDRITE)
             throw UnsupportedError("buffer position " + std::to_string(bp) +
-                    " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside)");
+                    " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside, dendrite/outside)");
         if (du.model == M_TAPS || du.model == M_PLUGIN)
             throw UnsupportedError("dendrite model of unit '" + du.name + "' is not implemented on the MI355X backend");
         if (du.log || su.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
         uint8_t kind = SANAFE_IN_BUFFERED;
         if (bp == SANAFE_BUF_INSIDE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_ZERO, neuron_dend_kind[gid] = 1;
+        if (bp == SANAFE_BUF_BEFORE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_LAST;
         if (du.model == M_ACC_DELAY)
         {
             if (bp != SANAFE_BUF_INSIDE_DENDRITE)

@@ -72,14 +72,15 @@ def loihi(n_inputs=1024, api=None, noise_file=None, noise_bits=None):
     return arch
 
 
-def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128, api=None):
-    """arch/loihi_large.yaml: 256x128 mesh, 1024 tiles x 4 cores, buffer inside the dendrite unit."""
+def loihi_large(n_tiles=1024, n_inputs=1024, width=256, height=128, api=None, buffer_inside_unit=True):
+    """arch/loihi_large.yaml: 256x128 mesh, 1024 tiles x 4 cores, buffer inside the dendrite unit
+    (``buffer_inside_unit=False``: the same chip with the time-step buffer BEFORE the dendrite unit)."""
     arch = _api(api).Architecture("loihi_chip", width, height, 16, _LOIHI_SYNC)
     shared = {}
     for t in range(n_tiles):
         tile = arch.create_tile("loihi_tile[%d]" % t, **_LOIHI_TILE)
         for c in range(4):
-            _loihi_core(arch, tile.id, c, "dendrite", True, shared, n_inputs)
+            _loihi_core(arch, tile.id, c, "dendrite", buffer_inside_unit, shared, n_inputs)
     return arch
 
 

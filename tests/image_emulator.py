@@ -20,6 +20,8 @@ class ImageEmulator:
         self.in_pos = np.zeros(max(1, im["n_input"]), dtype=np.int64)
         self.t = 0
         self.ext_next = 0
+        self.last_w = np.zeros(n)           # SANAFE_IN_LAST cores: current of the last event of the previous step
+        self.last_set = np.zeros(n, dtype=bool)
         cls = im["slot_cls"]
         self.model = cls & 7
         self.inkind = (cls >> 3) & 7
@@ -47,8 +49,10 @@ class ImageEmulator:
         rs = t % self.R
         n = im["n_slots"]
         status = np.zeros(n, dtype=np.uint8)
-        has_in = np.where(self.inkind == 1, True, self.valid[rs])
+        has_in = np.where(self.inkind >= 1, True, self.valid[rs])
         cur = np.where(self.inkind == 1, 0.0, np.where(self.valid[rs], self.ring[rs], 0.0))
+        cur = np.where(self.inkind == 2, np.where(self.last_set, 0.0 + self.last_w, 0.0), cur)
+        self.last_set[:] = False
         buf = (self.inkind == 0) & self.valid[rs] & (self.model != 0)
         self.ring[rs][buf] = 0.0
         self.valid[rs][buf] = False
@@ -183,6 +187,10 @@ class ImageEmulator:
                     if (meta >> 19) & 1:
                         continue
                     post, d = meta & 0xffff, (meta >> 16) & 7
+                    if self.inkind[nb + post] == 2:  # the buffer keeps the last event only (delivery order = array order)
+                        self.last_w[nb + post] = im["syn_weight"][s0 + k]
+                        self.last_set[nb + post] = True
+                        continue
                     ws = (t + 1 + d) % self.R
                     self.ring[ws][nb + post] += im["syn_weight"][s0 + k]
                     self.valid[ws][nb + post] = True

@@ -96,7 +96,13 @@ def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=
     fixed out-degree with targets drawn without replacement, integer weights in {-8..8}\\{0}."""
     D = S.description
     rng = np.random.default_rng(seed)
-    if arch_kind == "large":
+    if arch_kind == "before_dendrite":
+        # buffer_position: dendrite, buffer_inside_unit: false -- only the last event of a step reaches the accumulator
+        w = max(1, int(np.ceil(np.sqrt(n_tiles))))
+        arch = S.presets.loihi_large(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), n_inputs=4, api=S.description,
+                                     buffer_inside_unit=False)
+        dend = "loihi_dendrites"
+    elif arch_kind == "large":
         w = max(1, int(np.ceil(np.sqrt(n_tiles))))
         arch = S.presets.loihi_large(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), n_inputs=4, api=S.description)
         dend = "loihi_dendrites_delay"  # quirk 1: plain accumulator loses all input inside the dendrite

@@ -193,6 +193,18 @@ def test_random_configurations(S, seed):
     check_batched(S, arch, net, steps=14)
 
 
+@pytest.mark.parametrize("weights", ["int", "int12", "float"])
+def test_buffer_before_dendrite_keeps_last_event(S, weights, monkeypatch):
+    """`buffer_position: dendrite` outside the unit (SANAFE_IN_LAST): last event in delivery order wins, across
+    the stream and gather paths, several slices per core and all three synapse formats."""
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
+    monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=300, out_degree=200, arch_kind="before_dendrite", p_fire=0.2,
+                                  seed=4, weights=weights)
+    chip, _ = check_batched(S, arch, net, steps=12)[:2]
+    assert chip.info()["n_slices"] > 8
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

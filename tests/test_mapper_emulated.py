@@ -55,6 +55,15 @@ def test_random_loihi_inside_dendrite_plain_accumulator_loses_input(S):
     compare(S, arch, net, steps=15)
 
 
+def test_buffer_before_dendrite_keeps_last_event(S):
+    """`buffer_position: dendrite` with the buffer outside the unit: the message pipeline stops after the synapse,
+    the time-step buffer keeps the LAST event's current per neuron (src/chip.cpp:759) and the accumulator integrates
+    just that one at the next step; every neuron counts as having input (lazy clear leaves 0.0)."""
+    arch, net = nets.random_loihi(S, n_tiles=3, neurons_per_core=60, out_degree=30, arch_kind="before_dendrite", p_fire=0.2,
+                                  seed=4)
+    compare(S, arch, net, steps=25)
+
+
 def test_truenorth(S):
     compare(S, *nets.truenorth_net(S, n_tiles=6, neurons_per_core=32), steps=25)
 
@@ -67,7 +76,7 @@ def test_float_weights_within_tolerance(S):
 def test_unsupported_configs_fail_loudly(S):
     arch = S.presets.example_chip(api=S.description)
     for c in arch.cores():
-        c.buffer_position = S.description.BUF_BEFORE_DENDRITE
+        c.buffer_position = S.description.BUF_INSIDE_SOMA  # the soma would run once per synaptic event
     net = S.presets.example_snn(arch)
     with pytest.raises(NotImplementedError, match="buffer position"):
         S.map_only(arch, net)
