@@ -62,6 +62,10 @@ enum { SANAFE_SOMA_NONE = 0, SANAFE_SOMA_LIF = 1, SANAFE_SOMA_TRUENORTH = 2,
 enum {
     SANAFE_IN_BUFFERED = 0,   /* accumulator + kernel time-step buffer, or delay line: read slot t % ring_slots */
     SANAFE_IN_ZERO = 1,       /* `accumulator` with the buffer inside the unit: always 0.0 */
+    SANAFE_IN_GATED = 3,      /* `accumulator_with_delay` reached through the kernel's buffer (`buffer_position: soma`,
+                                 outside): the charge maturing at step t is handed to the soma at t+1 only if some event
+                                 reached the neuron at step t (the unit is only called on events and its output is what the
+                                 buffer keeps, src/models.cpp:96-131, src/chip.cpp:759); otherwise it is lost */
     SANAFE_IN_LAST = 2        /* buffer before the dendrite unit (`buffer_position: dendrite`, outside): the kernel's
                                  time-step buffer keeps only the LAST synaptic event's current (src/chip.cpp:759), which the
                                  accumulator then integrates alone; always "has input" (the lazy clear leaves 0.0) */

@@ -147,6 +147,7 @@ struct DevState
     uint32_t *in_pos;
     double *ring;          // [ring_slots][n_slots]
     uint8_t *ring_valid;   // [ring_slots][n_slots]
+    uint8_t *arrived;      // [n_slots], SANAFE_IN_GATED cores: an event reached the neuron in the previous step
     uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
     uint32_t *bits_local;  // [n_slots/32]
     uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
@@ -267,6 +268,24 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
             {
                 has_in = true;
                 cur = 0.0;
+            }
+            else if (inkind == SANAFE_IN_GATED)
+            {
+                // the delay line's matured charge reaches the soma only through the buffer an event of the
+                // previous step wrote; unobserved charge is consumed all the same (the line keeps shifting)
+                has_in = false;
+                cur = 0.0;
+                if (in_valid != 0)
+                {
+                    ring[g] = 0.0;
+                    rvalid[g] = 0;
+                }
+                if (st.arrived[g] != 0)
+                {
+                    st.arrived[g] = 0;
+                    has_in = in_valid != 0;
+                    cur = has_in ? in_value : 0.0;
+                }
             }
             else if (inkind == SANAFE_IN_LAST)
             {
@@ -612,7 +631,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
-    const bool last_mode = LAST && (((im.slot_cls[nbase] >> 3) & 7u) == SANAFE_IN_LAST); // workgroup-uniform
+    const uint32_t core_inkind = (im.slot_cls[nbase] >> 3) & 7u;  // the buffer position belongs to the core
+    const bool last_mode = LAST && core_inkind == SANAFE_IN_LAST; // workgroup-uniform
+
     uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
 
     for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
@@ -961,11 +982,14 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
         const uint32_t d = i / RS, n = i - d * RS;
         if (n >= npad) continue; // trash entry
-        const uint32_t wslot = (uint32_t) ((t + 1 + d) % R);
+        // a neuron behind a gated delay line (SANAFE_IN_GATED; per neuron: a core may mix dendrite units)
+        const bool gated = HAS_DELAY && ((im.slot_cls[nbase + n] >> 3) & 7u) == SANAFE_IN_GATED;
+        const uint32_t wslot = (uint32_t) ((t + 1 + d + (gated ? 1 : 0)) % R);
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
         if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
         else st.ring[gi] += acc[i];
         st.ring_valid[gi] = 1;
+        if (gated) st.arrived[nbase + n] = 1;
     }
     // ---- processing-delay sum of this slice (simple timing model) ----
     proc = wave_sum(proc);
@@ -1127,6 +1151,21 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
         cur[i] = 0.0;
         return;
     }
+    if (inkind == SANAFE_IN_GATED)
+    {
+        const uint8_t valid = st.ring_valid[gi];
+        const double value = st.ring[gi];
+        if (valid)
+        {
+            st.ring[gi] = 0.0;
+            st.ring_valid[gi] = 0;
+        }
+        const bool arr = st.arrived[g] != 0;
+        st.arrived[g] = 0;
+        has[i] = (arr && valid) ? 1 : 0;
+        cur[i] = (arr && valid) ? value : 0.0;
+        return;
+    }
     if (inkind == SANAFE_IN_LAST)
     {
         has[i] = 1;
@@ -1188,7 +1227,7 @@ struct sanafe_hip_chip
     int device{0};
     hipStream_t stream{nullptr};
     bool own_stream{true};
-    bool has_delay{false};
+    bool has_delay{false}, force_delay_variant{false};
     long long t_host{0};      // timesteps launched so far (the device's *st.t trails it by the pending reduction)
     PrevStep pend{};          // the launched step whose reduction has not been launched yet
     int syn_format{2};        // 0: 2+1 B, 1: 4 B, 2: 4+8 B per synapse (DevImage)
@@ -1361,7 +1400,7 @@ int validate(const sanafe_hip_image *im)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
-        if (((cls >> 3) & 7u) > SANAFE_IN_LAST) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) > SANAFE_IN_GATED) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
     }
     if (im->n_ext > 0)
     {
@@ -1656,6 +1695,18 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         im.has_last = ((h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST) ? 1 : 0;
     st.ring_last = nullptr;
     if (im.has_last) TRYC(dalloc(c, h.n_slots, &st.ring_last));
+    st.arrived = nullptr;
+    {
+        bool any_gated = false;
+        for (uint32_t g = 0; g < h.n_slots && !any_gated; g++)
+            any_gated = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_GATED;
+        if (any_gated)
+        {
+            if (h.ring_slots < 7) return bail(fail(SANAFE_HIP_ERR_INVALID, "SANAFE_IN_GATED neurons need ring_slots >= 7"));
+            TRYC(dalloc(c, h.n_slots, &st.arrived));
+            c->force_delay_variant = true; // the +1 slot shift lives in the HAS_DELAY kernels
+        }
+    }
     TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
     if (h.n_global_slots == h.n_slots) st.bits_global = st.bits_local;
     else TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
@@ -1688,7 +1739,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         im.delay_slots = max_delay + 1;
     }
     c->deliver_lds = (size_t) im.delay_slots * (max_pad + 1) * (sizeof(double) + 1);
-    c->has_delay = im.delay_slots > 1;
+    c->has_delay = im.delay_slots > 1 || c->force_delay_variant;
     im.syn_format = c->syn_format;
     if (im.has_last && c->has_delay)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "cores with the buffer before the dendrite unit cannot be mixed with synaptic delays"));
@@ -2200,6 +2251,7 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
     HIPCHK(hipMemsetAsync(c->st.ring, 0, (size_t) c->im.ring_slots * n * sizeof(double), c->stream));
     HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
     if (c->st.ring_last) HIPCHK(hipMemsetAsync(c->st.ring_last, 0, n * sizeof(uint32_t), c->stream));
+    if (c->st.arrived) HIPCHK(hipMemsetAsync(c->st.arrived, 0, n, c->stream));
     return 0;
 }
 

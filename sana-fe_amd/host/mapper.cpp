@@ -623,7 +623,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     mc.slot_model.assign(LS, SANAFE_SOMA_NONE);
     std::map<ClassKey, uint32_t> class_ids;
     std::map<CostKey, uint32_t> cost_ids;
-    bool any_delay_dendrite = false;
+    bool any_delay_dendrite = false, any_gated_delay = false;
     std::vector<uint8_t> neuron_dend_kind(N, 0); // 0 buffered accumulator, 1 zero, 2 delay line
     // InputModel seeds: every unit of every core is constructed up front, cores in id order, units in
     // template order (src/chip.cpp:83-87), and each `input` instance takes ++counter (src/models.hpp:347).
@@ -658,8 +658,9 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         if (bp == SANAFE_BUF_BEFORE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_LAST;
         if (du.model == M_ACC_DELAY)
         {
-            if (bp != SANAFE_BUF_INSIDE_DENDRITE)
-                throw UnsupportedError("accumulator_with_delay with the buffer outside the dendrite unit is not implemented");
+            if (bp == SANAFE_BUF_BEFORE_DENDRITE)
+                throw UnsupportedError("accumulator_with_delay with the buffer before the dendrite unit is not implemented");
+            if (bp == SANAFE_BUF_BEFORE_SOMA) kind = SANAFE_IN_GATED, any_gated_delay = true;
             any_delay_dendrite = true;
             neuron_dend_kind[gid] = 2;
         }
@@ -883,7 +884,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     }
     if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});
-    mc.ring_slots = any_delay_dendrite ? 6 : 1;
+    mc.ring_slots = any_gated_delay ? 7 : any_delay_dendrite ? 6 : 1; // gated delay lines mature one step later
 
     lap("neurons + slots");
     // ------------------------------------------------------------------ map_connections, src/chip.cpp:334-380

@@ -22,6 +22,7 @@ class ImageEmulator:
         self.ext_next = 0
         self.last_w = np.zeros(n)           # SANAFE_IN_LAST cores: current of the last event of the previous step
         self.last_set = np.zeros(n, dtype=bool)
+        self.arrived = np.zeros(n, dtype=bool)  # SANAFE_IN_GATED: an event reached the neuron in the previous step
         cls = im["slot_cls"]
         self.model = cls & 7
         self.inkind = (cls >> 3) & 7
@@ -53,7 +54,11 @@ class ImageEmulator:
         cur = np.where(self.inkind == 1, 0.0, np.where(self.valid[rs], self.ring[rs], 0.0))
         cur = np.where(self.inkind == 2, np.where(self.last_set, 0.0 + self.last_w, 0.0), cur)
         self.last_set[:] = False
-        buf = (self.inkind == 0) & self.valid[rs] & (self.model != 0)
+        gated = self.inkind == 3
+        has_in = np.where(gated, self.arrived & self.valid[rs], has_in)
+        cur = np.where(gated, np.where(self.arrived & self.valid[rs], self.ring[rs], 0.0), cur)
+        self.arrived[:] = False
+        buf = ((self.inkind == 0) | gated) & self.valid[rs] & (self.model != 0)
         self.ring[rs][buf] = 0.0
         self.valid[rs][buf] = False
         bias = im["slot_bias"]
@@ -191,6 +196,9 @@ class ImageEmulator:
                         self.last_w[nb + post] = im["syn_weight"][s0 + k]
                         self.last_set[nb + post] = True
                         continue
+                    if self.inkind[nb + post] == 3:
+                        d += 1
+                        self.arrived[nb + post] = True
                     ws = (t + 1 + d) % self.R
                     self.ring[ws][nb + post] += im["syn_weight"][s0 + k]
                     self.valid[ws][nb + post] = True

@@ -90,7 +90,7 @@ def dvs_yaml(S):
 
 
 def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=32, p_fire=0.1, seed=1,
-                 arch_kind="large", delays=False, weights="int", refractory=False):
+                 arch_kind="large", delays=False, weights="int", refractory=False, dendrite=None):
     """Config C3-style synthetic SNN (recipe after scripts/tcad2025/random_network.py:63-105):
     LIF neurons, threshold 64, reset 0, force_update, a fraction p_fire with bias 128 (fire every step),
     fixed out-degree with targets drawn without replacement, integer weights in {-8..8}\\{0}."""
@@ -111,6 +111,7 @@ def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=
         arch.tiles = arch.tiles[:n_tiles]
         arch._cores = arch._cores[:4 * n_tiles]
         dend = "loihi_dendrites"
+    dend = dendrite or dend
     cores = arch.cores()
     cores_used = cores_used or len(cores)
     n = cores_used * neurons_per_core

@@ -205,6 +205,19 @@ def test_buffer_before_dendrite_keeps_last_event(S, weights, monkeypatch):
     assert chip.info()["n_slices"] > 8
 
 
+def test_delay_line_behind_the_time_step_buffer(S, monkeypatch):
+    """arch/loihi.yaml + `loihi_dendrites_delay` (SANAFE_IN_GATED), some neurons of the same cores on the plain
+    accumulator, cores split over several delivery slices."""
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
+    monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=200, out_degree=120, arch_kind="loihi", delays=True, p_fire=0.15,
+                                  seed=13, dendrite="loihi_dendrites_delay")
+    g = net._order[0]
+    g.dendrite_hw[::3] = net.strings("loihi_dendrites")  # every third neuron integrates without the delay line
+    chip, _ = check_batched(S, arch, net, steps=30)[:2]
+    assert chip.info()["n_slices"] > 8
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

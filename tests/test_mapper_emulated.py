@@ -64,6 +64,15 @@ def test_buffer_before_dendrite_keeps_last_event(S):
     compare(S, arch, net, steps=25)
 
 
+def test_delay_line_behind_the_time_step_buffer(S):
+    """`accumulator_with_delay` on arch/loihi.yaml (buffer before the soma, outside the units): the unit only runs on
+    events and the buffer keeps its output, so matured charge reaches the soma one step later and only when some
+    event hit the neuron in the step it matured (SANAFE_IN_GATED)."""
+    arch, net = nets.random_loihi(S, n_tiles=3, neurons_per_core=50, out_degree=20, arch_kind="loihi", delays=True, p_fire=0.15,
+                                  seed=13, dendrite="loihi_dendrites_delay")
+    compare(S, arch, net, steps=40)
+
+
 def test_truenorth(S):
     compare(S, *nets.truenorth_net(S, n_tiles=6, neurons_per_core=32), steps=25)
 
