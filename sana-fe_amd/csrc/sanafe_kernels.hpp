@@ -1,0 +1,1153 @@
+// sanafe_kernels.hpp -- device side of libsanafe_hip: constants, device views of the image and state, and the
+// kernels (neuron_kernel, deliver_kernel, reduce_step / reduce_kernel, host-unit kernels).  Included by
+// sanafe_hip.hip inside its anonymous namespace; see the header comment there for the map of the kernels.
+#pragma once
+
+constexpr int WAVE = 64;
+constexpr int NEURON_BLOCK = 256;   // one workgroup per simulated core: 4 wavefronts share its 64-slot chunks
+constexpr int DELIVER_BLOCK = 256;
+constexpr int AX_PER_THREAD = 4;    // axon records per lane: one 8-byte (compact) or two 16-byte (wide) loads
+constexpr int REDUCE_BLOCK = 256;
+
+// Per-core partial sums written by K1 (one record per core, one writer).
+struct CorePart
+{
+    double e_soma, e_dend, e_syn, e_net, gen_sum;
+    long long updated, fired, packets, hops, events;
+};
+
+struct DevImage
+{
+    uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots, delay_slots;
+    double sync_delay;
+    const uint32_t *core_nbase, *core_ncount;
+    const double *core_axon_out_latency, *core_axon_in_latency;
+    const sanafe_hip_soma_class *soma_classes;
+    const sanafe_hip_cost_class *cost_classes;
+    const uint32_t *slot_cls, *slot_aux, *slot_packets, *slot_hops, *slot_events;
+    const double *slot_bias, *slot_e_net, *slot_e_syn, *slot_e_dend;
+    const uint32_t *in_train_beg, *in_train_len, *in_train_bits;
+    const long long *in_rate_period;
+    const uint32_t *slot_ext; // column of the slot in a row of external stream values (0xffffffff: none)
+    uint32_t n_ext;
+    const uint32_t *slice_core;
+    const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
+    const uint32_t *core_slice_beg; // [n_cores+1]
+    // Device layout of the inbound axons, chosen per delivery slice (slice_mode):
+    //   wide    8 bytes/axon: bits 0-31 pre-synaptic GLOBAL slot | 32-47 synapse count | 48-55 latency class
+    //           (255: read ax_proc_delay)
+    //   compact 2 bytes/axon: bits 0-7 pre slot minus the previous axon's pre slot (0 for the first axon of a
+    //           256-axon chunk, whose pre slot is chunk_pre0) | 8-15 synapse count; one latency class per slice.
+    //           Used when the slice's axons are dense in pre-slot order (gaps < 256), have < 256 synapses each
+    //           and share a latency class -- the normal case of a large recurrent network.
+    const unsigned char *ax_bytes;            // all slices' records, each slice 16-byte aligned
+    const unsigned long long *slice_rec_off;  // [n_slices] byte offset of the slice's records
+    const uint8_t *slice_mode;                // [n_slices] 0 wide, 1 compact
+    const uint8_t *slice_lat_class;           // [n_slices] latency class of a compact slice
+    const uint32_t *slice_chunk0;             // [n_slices] first entry of the slice in the chunk tables
+    const uint32_t *chunk_syn0;               // per 256-axon chunk: first synapse (relative to the core)
+    const uint32_t *chunk_pre0;               // per 256-axon chunk: pre slot of its first axon
+    const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
+    const double *lat_class;      // [256] per-event latency of each class
+    // Synapses, one of three formats (chip-wide):
+    //   0: 4 bytes      post (12b) | delay (3b) << 12 | drop << 15 | axon code (8b) << 16 | int8 weight << 24
+    //                   axon code = ((a & 3) << 6) | (a >> 2), a = index of the synapse's axon inside its 256-axon
+    //                   chunk: lets a chunk with many spikes be STREAMED (every synapse word read once, in order,
+    //                   fired or not decided from the word itself) instead of gathered
+    //   1: 4 bytes      post (16b) | delay (3b) << 16 | drop << 19 | 12-bit signed weight << 20
+    //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64
+    const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
+    const double *syn_weight;
+    int syn_format;               // 0 / 1 / 2 as above
+    int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
+};
+
+// The reduction of step s runs at the START of step s+1's neuron launch (its workgroup 0), so a timestep costs
+// two launches instead of three; the per-core partials of consecutive steps therefore live in two alternating
+// halves ("parity" = steps simulated before the step, & 1).  A trailing reduce_kernel flushes the last step
+// before anything reads results.
+struct PrevStep
+{
+    int valid;          // 0: nothing to reduce
+    int simple_timing, record, parity;
+    long long rec_index; // record slot of that step
+};
+
+struct DevState
+{
+    double *v, *icur;
+    int *refrac;
+    uint8_t *status;
+    uint32_t *in_pos;
+    double *ring;          // [ring_slots][n_slots]
+    uint8_t *ring_valid;   // [ring_slots][n_slots]
+    uint8_t *arrived;      // [n_slots], SANAFE_IN_GATED cores: an event reached the neuron in the previous step
+    uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
+    uint32_t *bits_local;  // [n_slots/32]
+    uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
+    CorePart *core_part;   // [2][n_cores], by step parity
+    double *slice_proc;    // [n_slices]
+    double *core_proc;     // [2][n_cores], by step parity
+    long long *t;          // timesteps simulated so far
+    long long *rec;        // records written so far in this sim
+    sanafe_hip_totals *run;       // run totals
+    sanafe_hip_totals *step_log;  // [log_cap]
+    uint32_t *spike_log;          // [log_cap][n_slots/32]
+    long long log_cap;
+};
+
+// Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles (the neuron kernel's
+// waves spent a third of their cycles waiting to issue those): Hillis-Steele inside each 16-lane row, row_bcast:15
+// and row_bcast:31 across rows, total in lane 63.  Lanes without a source read 0 bits = +0.0 / 0.  Fixed order.
+#define SANAFE_DPP_STEPS(STEP)                  \
+    STEP(0x111, 0xf) /* row_shr:1 */            \
+    STEP(0x112, 0xf) /* row_shr:2 */            \
+    STEP(0x114, 0xf) /* row_shr:4 */            \
+    STEP(0x118, 0xf) /* row_shr:8 */            \
+    STEP(0x142, 0xa) /* row_bcast:15 */         \
+    STEP(0x143, 0xc) /* row_bcast:31 */
+__device__ __forceinline__ double wave_sum(double x)
+{
+#define SANAFE_STEP(CTRL, ROWS)                                                                   \
+    {                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROWS, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROWS, 0xf, false); \
+        x += __hiloint2double(hi, lo);                                                            \
+    }
+    SANAFE_DPP_STEPS(SANAFE_STEP)
+#undef SANAFE_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), 63), __builtin_amdgcn_readlane(__double2loint(x), 63));
+}
+__device__ __forceinline__ long long wave_sum(long long x)
+{
+#define SANAFE_STEP(CTRL, ROWS)                                                                            \
+    {                                                                                                      \
+        const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) x, CTRL, ROWS, 0xf, false);          \
+        const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) ((unsigned long long) x >> 32), CTRL, ROWS, 0xf, false); \
+        x += (long long) (((unsigned long long) hi << 32) | lo);                                           \
+    }
+    SANAFE_DPP_STEPS(SANAFE_STEP)
+#undef SANAFE_STEP
+    const unsigned lo = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) x, 63);
+    const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) x >> 32), 63);
+    return (long long) (((unsigned long long) hi << 32) | lo);
+}
+
+// static_cast<int>(double) as x86-64 performs it (cvttsd2si): out-of-range and NaN give INT_MIN.
+// The reference quantises with it (src/models.cpp:447-455).
+__device__ __forceinline__ int cvt_int_x86(double x)
+{
+    if (!(x > -2147483649.0 && x < 2147483648.0)) return (int) 0x80000000;
+    return (int) x;
+}
+
+// ---------------------------------------------------------------------------------------
+// K1: neuron update.  grid = n_cores, block = 256: the core's 64-slot chunks are dealt to the
+// workgroup's 4 wavefronts (a 256-neuron TrueNorth core is one chunk per wave, a 1024-neuron
+// Loihi core four), every wave owns whole 64-slot chunks so the spike ballot maps 1:1 to bitmap words.
+// ---------------------------------------------------------------------------------------
+__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5]);
+
+__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record, const int *ext_row,
+        long long done /* steps simulated before this one */, long long rec, PrevStep prev)
+{
+    static_assert(NEURON_BLOCK == REDUCE_BLOCK, "workgroup 0 reduces the previous step");
+    if (blockIdx.x == 0 && prev.valid)
+    {
+        __shared__ double r_sd[REDUCE_BLOCK / WAVE][6];
+        __shared__ long long r_sl[REDUCE_BLOCK / WAVE][5];
+        reduce_step(im, st, prev, r_sd, r_sl);
+        __syncthreads();
+    }
+    const uint32_t parity_off = (uint32_t) (done & 1) * im.n_cores;
+    __shared__ double s_d[NEURON_BLOCK / WAVE][5];
+    __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const uint32_t core = blockIdx.x;
+    const long long t = done + 1;      // Timestep::timestep of this step
+    const uint32_t nbase = im.core_nbase[core];
+    const uint32_t ncount = im.core_ncount[core];
+    const uint32_t rslot = (uint32_t) (t % im.ring_slots);
+    double *ring = st.ring + (size_t) rslot * im.n_slots;
+    uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
+    uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
+
+    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0, e_dspk = 0.0; // per lane
+    long long n_pack = 0, n_hops = 0, n_ev = 0;                                         // per lane
+    double w_e_soma = 0.0, w_e_dend = 0.0, w_lat = 0.0;                                 // per wavefront (uniform)
+    long long w_upd = 0, w_fire = 0;
+    bool mixed = false, any_fire = false;                                               // wave-uniform
+
+    for (uint32_t off = wave * WAVE; off < ncount; off += NEURON_BLOCK)
+    {
+        const uint32_t g = nbase + off + lane;
+        const bool live = (off + lane) < ncount;
+        // every load that does not depend on the neuron's class is issued up front (padding slots exist in all
+        // per-slot arrays), so the class-table lookups overlap with them instead of preceding them
+        const uint32_t cls_raw = im.slot_cls[g];
+        const uint8_t in_valid = rvalid[g];
+        const double in_value = ring[g];
+        const double bias = im.slot_bias[g];
+        const double v_in = st.v[g];
+        uint32_t cls = live ? cls_raw : 0u;
+        const uint32_t model = cls & 7u;
+        int status = 0;
+        if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
+        {
+            const uint32_t inkind = (cls >> 3) & 7u;
+            // ---- synaptic input from the time-step buffer / delay ring (read, then clear) ----
+            bool has_in;
+            double cur;
+            if (inkind == SANAFE_IN_ZERO)
+            {
+                has_in = true;
+                cur = 0.0;
+            }
+            else if (inkind == SANAFE_IN_GATED)
+            {
+                // the delay line's matured charge reaches the soma only through the buffer an event of the
+                // previous step wrote; unobserved charge is consumed all the same (the line keeps shifting)
+                has_in = false;
+                cur = 0.0;
+                if (in_valid != 0)
+                {
+                    ring[g] = 0.0;
+                    rvalid[g] = 0;
+                }
+                if (st.arrived[g] != 0)
+                {
+                    st.arrived[g] = 0;
+                    has_in = in_valid != 0;
+                    cur = has_in ? in_value : 0.0;
+                }
+            }
+            else if (inkind == SANAFE_IN_LAST)
+            {
+                // the accumulator integrates the one current the time-step buffer kept, after its lazy clear
+                // (src/models.cpp:71-94): 0.0 + w_last, or plain 0.0 -- a value either way
+                has_in = true;
+                cur = 0.0;
+                const uint32_t last = st.ring_last[g];
+                if (last != 0u)
+                {
+                    const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
+                    const double w = (im.syn_format == 2) ? im.syn_weight[pos]
+                                                          : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
+                    cur = 0.0 + w;
+                    st.ring_last[g] = 0u;
+                }
+            }
+            else
+            {
+                has_in = in_valid != 0;
+                cur = 0.0;
+                if (has_in)
+                {
+                    cur = in_value;
+                    ring[g] = 0.0;
+                    rvalid[g] = 0;
+                }
+            }
+            // host-generated value of a sequential source this neuron consumes at every update
+            // (Poisson draw, std::rand() & mask, noise file): include/sanafe_hip.h, slot_ext
+            bool has_ext = false;
+            int ext = 0;
+            if (ext_row != nullptr)
+            {
+                const uint32_t col = im.slot_ext[g];
+                has_ext = col != 0xffffffffu;
+                if (has_ext) ext = ext_row[col];
+            }
+            if (model == SANAFE_SOMA_LIF)
+            {
+                // LoihiLifModel::update, src/models.cpp:497-567
+                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
+                double v = v_in;
+                double ic = st.icur[g];
+                int rc = st.refrac[g];
+                status = 1;
+                if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
+                if (done > 0)
+                {
+                    ic *= p.input_decay;
+                    v *= p.leak_decay;
+                }
+                v = (double) cvt_int_x86(v * 64.0) / 64.0;
+                if (has_ext) v += (double) ext; // loihi_generate_noise, src/models.cpp:535-539
+                if (!(rc > 0))
+                {
+                    v += bias;
+                    ic += has_in ? cur : 0.0;
+                    v += ic;
+                    bool fired = false;
+                    if (v > p.threshold)
+                    {
+                        if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
+                        else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
+                        rc = p.refractory_delay;
+                        fired = true;
+                    }
+                    if (v < p.reverse_threshold)
+                    {
+                        if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v -= p.reverse_threshold;
+                        else if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
+                        else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
+                    }
+                    if (fired) status = 3;
+                }
+                rc = rc - 1 > 0 ? rc - 1 : 0;
+                st.v[g] = v;
+                st.icur[g] = ic;
+                st.refrac[g] = rc;
+            }
+            else if (model == SANAFE_SOMA_TRUENORTH)
+            {
+                // TrueNorthModel::update, src/models.cpp:724-830
+                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
+                double v = v_in;
+                status = 1;
+                if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
+                if (p.leak_towards_zero)
+                {
+                    if (v > 0.0) v -= p.leak_decay;
+                    else if (v < 0.0) v += p.leak_decay;
+                }
+                else
+                {
+                    v += p.leak_decay;
+                }
+                v += bias;
+                if (has_in) v += cur;
+                // the randomised threshold test sees V + (rand() & mask); the resets act on V (src/models.cpp:745-797)
+                const double vt = has_ext ? v + (double) ext : v;
+                if (vt >= p.threshold)
+                {
+                    if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
+                    else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
+                    else if (p.reset_mode == SANAFE_RESET_SATURATE) v = p.threshold;
+                    status = 3;
+                }
+                else if (vt <= p.reverse_threshold)
+                {
+                    if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
+                    else if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v += p.reverse_threshold;
+                    else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
+                }
+                st.v[g] = v;
+            }
+            else // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903
+            {
+                const uint32_t a = im.slot_aux[g];
+                const uint32_t pos = st.in_pos[a];
+                bool send = false;
+                if (pos < im.in_train_len[a])
+                {
+                    const uint32_t b = im.in_train_beg[a] + pos;
+                    send = (im.in_train_bits[b >> 5] >> (b & 31u)) & 1u;
+                    st.in_pos[a] = pos + 1;
+                }
+                if (ext != 0) send = true; // poisson_probability > uniform_distribution(gen)
+                const long long period = im.in_rate_period[a];
+                if (period > 0 && (t % period) == 0) send = true;
+                status = send ? 3 : 1;
+            }
+        }
+        // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
+        // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
+        if (live && model != SANAFE_SOMA_HOST) st.status[g] = (uint8_t) status;
+        const unsigned long long fired_mask = __ballot(status == 3);
+        // ---- default costing, src/pipeline.hpp:574-731.  Counters and class costs are taken per wavefront from
+        //      ballots (no cross-lane reduction at the end); only what depends on the individual neuron -- the
+        //      static totals of a spike, or costs when the 64 neurons do not share one cost class -- is summed
+        //      per lane and reduced once, and only by wavefronts that saw such a case. ----
+        const bool counted = (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST);
+        const unsigned long long m_cnt = __ballot(counted);
+        if (m_cnt != 0ull) // wave-uniform
+        {
+            const unsigned long long m_upd = __ballot(status >= 2);
+            w_upd += __popcll(m_upd);
+            w_fire += __popcll(fired_mask);
+            const uint32_t ccid = (cls >> 6) & 1023u;
+            const uint32_t cc0 = (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
+            if (__ballot(counted && ccid != cc0) == 0ull)
+            {
+                const sanafe_hip_cost_class &c0 = im.cost_classes[cc0];
+                const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_mask),
+                             n_u = (double) __popcll(m_upd & ~fired_mask), n_i = (double) __popcll(m_cnt & ~m_upd);
+                w_e_soma += (n_i * c0.soma_energy[0] + n_u * c0.soma_energy[1]) + n_f * c0.soma_energy[2];
+                w_e_dend += n_all * c0.dendrite_energy;
+                w_lat += n_all * (0.0 + c0.dendrite_latency) + ((n_i * c0.soma_latency[0] + n_u * c0.soma_latency[1]) + n_f * c0.soma_latency[2]);
+            }
+            else
+            {
+                mixed = true;
+                if (counted)
+                {
+                    const sanafe_hip_cost_class &cc = im.cost_classes[ccid];
+                    e_dend += cc.dendrite_energy;
+                    e_soma += cc.soma_energy[status - 1];
+                    lat += (0.0 + cc.dendrite_latency) + cc.soma_latency[status - 1];
+                }
+            }
+            if (fired_mask != 0ull)
+            {
+                any_fire = true;
+                if (status == 3 && counted)
+                {
+                    // everything this spike causes downstream is static per neuron
+                    // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
+                    n_pack += im.slot_packets[g];
+                    n_hops += im.slot_hops[g];
+                    n_ev += im.slot_events[g];
+                    e_net += im.slot_e_net[g];
+                    e_syn += im.slot_e_syn[g];
+                    e_dspk += im.slot_e_dend[g];
+                }
+            }
+        }
+        if (lane == 0)
+        {
+            const uint32_t w = (nbase + off) >> 5;
+            st.bits_local[w] = (uint32_t) fired_mask;
+            st.bits_local[w + 1] = (uint32_t) (fired_mask >> 32);
+            if (record)
+            {
+                slog[w] = (uint32_t) fired_mask;
+                slog[w + 1] = (uint32_t) (fired_mask >> 32);
+            }
+        }
+    }
+    if (mixed)
+    {
+        w_e_soma += wave_sum(e_soma);
+        w_e_dend += wave_sum(e_dend);
+        w_lat += wave_sum(lat);
+    }
+    if (any_fire)
+    {
+        e_syn = wave_sum(e_syn);
+        e_net = wave_sum(e_net);
+        w_e_dend += wave_sum(e_dspk);
+        n_pack = wave_sum(n_pack);
+        n_hops = wave_sum(n_hops);
+        n_ev = wave_sum(n_ev);
+    }
+    e_soma = w_e_soma;
+    e_dend = w_e_dend;
+    lat = w_lat;
+    const long long n_upd = w_upd, n_fire = w_fire;
+    if (lane == 0)
+    {
+        s_d[wave][0] = e_soma;
+        s_d[wave][1] = e_dend;
+        s_d[wave][2] = e_syn;
+        s_d[wave][3] = e_net;
+        s_d[wave][4] = lat;
+        s_l[wave][0] = n_upd;
+        s_l[wave][1] = n_fire;
+        s_l[wave][2] = n_pack;
+        s_l[wave][3] = n_hops;
+        s_l[wave][4] = n_ev;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double d[5] = {0, 0, 0, 0, 0};
+        long long l[5] = {0, 0, 0, 0, 0};
+        for (int w = 0; w < NEURON_BLOCK / WAVE; w++) // fixed order: deterministic
+            for (int k = 0; k < 5; k++)
+            {
+                d[k] += s_d[w][k];
+                l[k] += s_l[w][k];
+            }
+        CorePart cp;
+        cp.e_soma = d[0];
+        cp.e_dend = d[1];
+        cp.e_syn = d[2];
+        cp.e_net = d[3];
+        // sum of Message::generation_delay over the core's messages incl. the placeholder
+        // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81)
+        cp.gen_sum = d[4] + (double) l[2] * im.core_axon_out_latency[core];
+        cp.updated = l[0];
+        cp.fired = l[1];
+        cp.packets = l[2];
+        cp.hops = l[3];
+        cp.events = l[4];
+        st.core_part[parity_off + core] = cp;
+        st.core_proc[parity_off + core] = 0.0; // the delivery slices of this step add their processing delays
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2: spike delivery.  grid = n_slices, block = 256 (4 independent wavefronts), dynamic LDS
+//
+// The four waves of a workgroup share only the LDS accumulators of their destination core.
+// Each wave walks its own interleaved 256-axon chunks of the slice with NO workgroup
+// barrier inside the loop (scan -> ballot/prefix compaction -> expansion all stay inside the
+// wave, ordered by LDS issue order), so 16-32 waves per CU keep independent chains of
+// global loads in flight: the loop is a latency-bound gather, not a bandwidth-bound stream.
+// ---------------------------------------------------------------------------------------
+constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per iteration
+constexpr int EXPAND_UNROLL = 4;
+constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bitmap
+#ifndef SANAFE_STREAM_DEPTH
+#define SANAFE_STREAM_DEPTH 3
+#endif
+#ifndef SANAFE_DELIVER_WAVES_PER_EU
+#define SANAFE_DELIVER_WAVES_PER_EU 5
+#endif
+constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
+constexpr uint32_t STREAM_MIN_ACTIVE = 16; // spiking axons in a 256-axon chunk from which streaming beats gathering
+constexpr unsigned long long ACC_UNTOUCHED = 0x8000000000000000ull; // -0.0: no sum of additions yields it
+
+// Inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips): Hillis-Steele inside each
+// 16-lane row (row_shr 1/2/4/8), then row_bcast:15 carries a row's total into the next row (rows 1 and 3) and
+// row_bcast:31 the first half's total into rows 2 and 3.  Lanes without a source read `old` = 0.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t x)
+{
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x142, 0xa, 0xf, false); // row_bcast:15 -> rows 1, 3
+    x += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, 0x143, 0xc, 0xf, false); // row_bcast:31 -> rows 2, 3
+    return x;
+}
+
+// LDS traffic of ONE wave is executed in issue order, so a ds_read issued after a ds_write of
+// the same wave sees it even across lanes; this only has to stop the compiler from reordering.
+__device__ __forceinline__ void wave_lds_fence()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+extern __shared__ __align__(16) unsigned char deliver_lds[];
+
+// LAST: the chip has cores whose time-step buffer sits before the dendrite unit (SANAFE_IN_LAST): for those cores the
+// workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
+// instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
+// (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
+template <int SYN_FMT, bool HAS_DELAY, bool LAST>
+__global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, SANAFE_DELIVER_WAVES_PER_EU)))
+deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+{
+    __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
+    __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
+    __shared__ double s_red[DELIVER_BLOCK / WAVE];
+
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const uint32_t slice = blockIdx.x;
+    const uint32_t core = im.slice_core[slice];
+    const uint32_t ncount = im.core_ncount[core];
+    const uint32_t npad = (ncount + 63u) & ~63u;
+    const uint32_t nbase = im.core_nbase[core];
+    const uint32_t R = im.ring_slots;
+    const uint32_t D = HAS_DELAY ? im.delay_slots : 1u; // LDS holds one accumulator row per delay value in use
+    // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
+    // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
+    const uint32_t RS = (SYN_FMT == 0) ? npad + 1u : npad;
+    const long long t = done + 1;
+    const unsigned long long a_beg = im.slice_axon_beg[slice];
+    const uint32_t n_ax = (uint32_t) (im.slice_axon_end[slice] - a_beg); // slices hold < 2^32 axons
+    const unsigned long long syn_base = im.core_syn_base[core];
+    const double ain_lat = im.core_axon_in_latency[core];
+    const bool compact = im.slice_mode[slice] != 0; // workgroup-uniform
+    const unsigned char *rec = im.ax_bytes + im.slice_rec_off[slice];
+    const uint32_t *chunk_syn0 = im.chunk_syn0 + im.slice_chunk0[slice];
+    const uint32_t *chunk_pre0 = im.chunk_pre0 + im.slice_chunk0[slice];
+    const double slice_lat = im.lat_class[im.slice_lat_class[slice]];
+    double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
+    // Which accumulators received a synaptic event (the buffer holds a value, even a zero one: src/chip.cpp:759)?
+    // Integer-weight formats start every accumulator at -0.0, which no addition of weights can produce again;
+    // fp64 weights (format 2) could be -0.0 themselves and keep a byte per accumulator instead.
+    constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
+    uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
+    uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
+    const uint32_t core_inkind = (im.slot_cls[nbase] >> 3) & 7u;  // the buffer position belongs to the core
+    const bool last_mode = LAST && core_inkind == SANAFE_IN_LAST; // workgroup-uniform
+
+    uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
+
+    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
+    {
+        if (LAST && last_mode)
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = 0ull; // two `lastv` entries
+        }
+        else if (TOUCH_BYTES)
+        {
+            acc[i] = 0.0;
+            touched[i] = 0;
+        }
+        else
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = ACC_UNTOUCHED;
+        }
+    }
+    __syncthreads();
+
+    double proc = 0.0;
+    const uint32_t *bits = st.bits_global;
+    constexpr unsigned long long NONE = ~0ull; // wide record "past the end of the slice"
+    // The 4 consecutive axon records of this lane.  Wide: two 16-byte loads (r[0..3]).  Compact: one 8-byte
+    // load, kept in r[0] (4 x 16 bits; records past the end read as 0 = no synapses, no advance).
+    auto load4 = [&](uint32_t a0, unsigned long long (&r)[AX_PER_THREAD]) {
+        if (compact)
+        {
+            unsigned long long q = 0;
+            if (a0 + AX_PER_THREAD <= n_ax) q = *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0);
+            else
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                    if (a0 + k < n_ax) q |= (unsigned long long) *reinterpret_cast<const uint16_t *>(rec + 2ull * (a0 + k)) << (16 * k);
+            r[0] = q;
+            return;
+        }
+        const unsigned long long *wide = reinterpret_cast<const unsigned long long *>(rec);
+        if (a0 + AX_PER_THREAD <= n_ax)
+        {
+            const ulonglong2 lo = *reinterpret_cast<const ulonglong2 *>(wide + a0);
+            const ulonglong2 hi = *reinterpret_cast<const ulonglong2 *>(wide + a0 + 2);
+            r[0] = lo.x;
+            r[1] = lo.y;
+            r[2] = hi.x;
+            r[3] = hi.y;
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++) r[k] = (a0 + k < n_ax) ? wide[a0 + k] : NONE;
+    };
+    // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.  A wave whose
+    // previous chunk streamed ("hot") starts the loads of the next chunk before it knows which axons spiked.
+    bool hot = false;
+    uint4 sq[STREAM_DEPTH];
+    const uint4 *st_src = nullptr;
+    uint32_t st_groups = 0, st_pos0 = 0;
+    constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
+    uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // axon offset of the chunk inside the slice
+    auto stream_preload = [&]() {
+        const uint32_t ci = c0 / WAVE_CHUNK;
+        const uint32_t s0 = chunk_syn0[ci];
+        st_pos0 = s0;
+        st_groups = (chunk_syn0[ci + 1] - s0) >> 2; // chunks are 16-byte aligned and padded (format 0)
+        st_src = reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
+#pragma unroll
+        for (int u = 0; u < STREAM_DEPTH; u++)
+        {
+            const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
+            if (g < st_groups) sq[u] = st_src[g];
+        }
+    };
+    // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
+    // (pre slots) -> spike-bitmap words -> (which axons spiked) -> synapse words.  While chunk i is delivered,
+    // the bitmap words of chunk i+1 and the records of chunk i+2 are in flight.
+    unsigned long long cur[AX_PER_THREAD] = {NONE, NONE, NONE, NONE}; // records of the chunk AFTER the decoded one
+    uint32_t nx_pre[AX_PER_THREAD], nx_nsyn[AX_PER_THREAD], nx_lcls[AX_PER_THREAD], nx_word[AX_PER_THREAD], nx_valid = 0;
+    // decode the records in `cur` (chunk at axon offset cc) and issue the loads of their bitmap words
+    auto decode_and_probe = [&](uint32_t cc) {
+        const uint32_t a0 = cc + (uint32_t) lane * AX_PER_THREAD;
+        nx_valid = 0;
+        if (compact)
+        {
+            const unsigned long long q = cur[0];
+            uint32_t dl[AX_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                dl[k] = (uint32_t) (q >> (16 * k)) & 0xffu;
+                nx_nsyn[k] = (uint32_t) (q >> (16 * k + 8)) & 0xffu;
+                nx_lcls[k] = 0u;
+            }
+            const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+            uint32_t pre = chunk_pre0[cc / WAVE_CHUNK] + wave_inclusive_scan(lane_d) - lane_d;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                pre += dl[k];
+                nx_pre[k] = pre;
+                nx_valid |= (a0 + k < n_ax) ? (1u << k) : 0u;
+            }
+        }
+        else
+        {
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                const unsigned long long r = cur[k];
+                nx_pre[k] = (r == NONE) ? 0u : (uint32_t) r;
+                nx_nsyn[k] = (r == NONE) ? 0u : (uint32_t) ((r >> 32) & 0xffffu);
+                nx_lcls[k] = (uint32_t) ((r >> 48) & 0xffu);
+                nx_valid |= (r != NONE) ? (1u << k) : 0u;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++) nx_word[k] = bits[nx_pre[k] >> 5]; // pad axons read word 0: in bounds
+    };
+    if (c0 < n_ax)
+    {
+        load4(c0 + (uint32_t) lane * AX_PER_THREAD, cur);
+        decode_and_probe(c0);
+        if (c0 + stride < n_ax) load4(c0 + stride + (uint32_t) lane * AX_PER_THREAD, cur);
+    }
+    for (; c0 < n_ax; c0 += stride)
+    {
+        if (SYN_FMT == 0 && hot) stream_preload();
+        // ---- this chunk: take over what the previous iteration decoded and probed ----
+        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
+        uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++)
+        {
+            nsyn[k] = nx_nsyn[k];
+            lcls[k] = nx_lcls[k];
+            amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
+        }
+        // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
+        if (c0 + stride < n_ax)
+        {
+            decode_and_probe(c0 + stride);
+            if (c0 + 2 * stride < n_ax) load4(a0 + 2 * stride, cur);
+        }
+        if (__ballot(amask != 0) == 0ull)
+        {
+            hot = false;
+            continue; // wave-uniform
+        }
+        if (SYN_FMT == 0 && compact)
+        {
+            // ---- STREAM: with many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
+            //      so read them all once, in order (16 bytes per lane), and let each word say whether its axon
+            //      spiked: no compaction, no ownership search, no per-event address arithmetic. ----
+            const unsigned long long b0 = __ballot(amask & 1u), b1 = __ballot(amask & 2u), b2 = __ballot(amask & 4u),
+                                     b3 = __ballot(amask & 8u);
+            const uint32_t n_act = (uint32_t) (__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
+            if (n_act >= STREAM_MIN_ACTIVE)
+            {
+                if (lane < 8)
+                {
+                    const unsigned long long b = (lane < 2) ? b0 : (lane < 4) ? b1 : (lane < 6) ? b2 : b3;
+                    w_pref[lane] = (uint32_t) (b >> ((lane & 1) * 32)); // word k*2 + (L >> 5), bit L & 31: axon 4L + k
+                }
+                wave_lds_fence();
+                if (!hot) stream_preload();
+                hot = true;
+                auto add4 = [&](const uint4 &g, uint32_t pos0 /* position of g.x among the core's synapses */) {
+                    const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
+                    uint32_t fired[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                    {
+                        const uint32_t code = (w4[u] >> 16) & 0xffu;
+                        fired[u] = (w_pref[code >> 5] >> (code & 31u)) & 1u;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (fired[u])
+                        {
+                            if (LAST && last_mode)
+                            {
+                                atomicMax(&lastv[w4[u] & 0xfffu], pos0 + (uint32_t) u + 1u);
+                            }
+                            else
+                            {
+                                const uint32_t idx = (HAS_DELAY ? __umul24((w4[u] >> 12) & 7u, RS) : 0u) + (w4[u] & 0xfffu);
+                                atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
+                            }
+                        }
+                };
+                // rolling window: STREAM_DEPTH 16-byte groups per lane in flight while one is added
+                for (uint32_t g = (uint32_t) lane; g < st_groups; g += WAVE * STREAM_DEPTH)
+                {
+#pragma unroll
+                    for (int u = 0; u < STREAM_DEPTH; u++)
+                    {
+                        // add, then refill the same registers (the other groups of the window are still in flight)
+                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
+                        const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
+                        if (nxt < st_groups) sq[u] = st_src[nxt];
+                    }
+                }
+                // processing delay of the chunk's messages: axon-in latency per message + per-event latency
+                uint32_t my_events = 0;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++) my_events += (amask & (1u << k)) ? nsyn[k] : 0u;
+                proc += (double) my_events * slice_lat + (double) __popc(amask) * ain_lat;
+                wave_lds_fence(); // w_pref is rewritten by the next chunk
+                continue;
+            }
+        }
+        hot = false;
+        // ---- GATHER: few spiking axons; touch only their synapses ----
+        // the chunk's synapses are contiguous: one base + a prefix over ALL its axons' counts
+        const uint32_t lane_syn = nsyn[0] + nsyn[1] + nsyn[2] + nsyn[3];
+        uint32_t syn_off = chunk_syn0[c0 / WAVE_CHUNK] + wave_inclusive_scan(lane_syn) - lane_syn;
+        // ---- compact the active axons in axon (= reference delivery) order ----
+        const uint32_t my_act = (uint32_t) __popc(amask);
+        const uint32_t incl_act = wave_inclusive_scan(my_act);
+        uint32_t my_ev = 0;
+        uint32_t st4[AX_PER_THREAD], sb4[AX_PER_THREAD]; // MY active axons, packed to the front: event start, first synapse
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++) st4[k] = ~0u, sb4[k] = 0u;
+        {
+            uint32_t j = 0;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                if (amask & (1u << k))
+                {
+                    // (static indices only: a runtime-indexed register array would go to scratch)
+                    if (j == 0) st4[0] = my_ev, sb4[0] = syn_off;
+                    else if (j == 1) st4[1] = my_ev, sb4[1] = syn_off;
+                    else if (j == 2) st4[2] = my_ev, sb4[2] = syn_off;
+                    else st4[3] = my_ev, sb4[3] = syn_off;
+                    j++;
+                    my_ev += nsyn[k];
+                    if (compact) proc += ain_lat + (double) nsyn[k] * slice_lat;
+                    else proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a_beg + a0 + k];
+                }
+                syn_off += nsyn[k];
+            }
+        }
+        const uint32_t incl_ev = wave_inclusive_scan(my_ev);
+        const uint32_t n_ev = __shfl(incl_ev, WAVE - 1, WAVE);
+        const uint32_t lane_base = incl_ev - my_ev;
+        // event e of the chunk belongs to the active axon i with start[i] <= e < start[i+1]; its synapse
+        // is syn_base + (first_synapse[i] - start[i]) + e, so one word per active axon is enough
+        {
+            const uint32_t pos = incl_act - my_act;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+                if ((uint32_t) k < my_act)
+                {
+                    st4[k] += lane_base;
+                    w_beg[pos + k] = sb4[k] - st4[k];
+                }
+        }
+        // ---- expand to synaptic events.  Ownership comes from a bitmap of axon starts ("heads"):
+        //      owner(e) = (#heads at or before e) - 1, a popcount instead of a binary search. ----
+        uint32_t heads_before = 0; // heads in earlier windows (wave-uniform)
+        for (uint32_t w0 = 0; w0 < n_ev; w0 += HEAD_WINDOW)
+        {
+            w_pref[lane] = 0u; // 64 words = HEAD_WINDOW bits
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                const uint32_t rel = st4[k] - w0;
+                if (st4[k] != ~0u && st4[k] >= w0 && rel < HEAD_WINDOW) atomicOr(&w_pref[rel >> 5], 1u << (rel & 31u));
+            }
+            wave_lds_fence();
+            const uint32_t w_end = (n_ev - w0 < HEAD_WINDOW) ? n_ev - w0 : HEAD_WINDOW;
+            uint32_t seen = heads_before; // heads before the current tile
+            for (uint32_t e0 = 0; e0 < w_end; e0 += WAVE * EXPAND_UNROLL)
+            {
+                uint32_t meta[EXPAND_UNROLL]; // post (16b) | delay << 16 | drop << 19, whatever the stored format
+                uint32_t spos[EXPAND_UNROLL]; // position among the core's synapses (used in last_mode)
+                double wgt[EXPAND_UNROLL];
+#pragma unroll
+                for (int u = 0; u < EXPAND_UNROLL; u++)
+                {
+                    const uint32_t tile = e0 + u * WAVE;
+                    meta[u] = 1u << 19; // "drop": nothing to add
+                    wgt[u] = 0.0;
+                    spos[u] = 0u;
+                    if (tile < w_end) // wave-uniform
+                    {
+                        const unsigned long long h = (unsigned long long) w_pref[tile >> 5] | ((unsigned long long) w_pref[(tile >> 5) + 1] << 32);
+                        const unsigned long long le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+                        const uint32_t owner = seen + (uint32_t) __popcll(h & le) - 1u;
+                        seen += (uint32_t) __popcll(h);
+                        const uint32_t e = w0 + tile + lane;
+                        if (e < n_ev)
+                        {
+                            spos[u] = (uint32_t) (w_beg[owner] + e);
+                            const unsigned long long s = syn_base + spos[u];
+                            if (SYN_FMT == 0)
+                            {
+                                const uint32_t m = im.syn_meta[s];
+                                meta[u] = (m & 0xfffu) | (((m >> 12) & 0xfu) << 16);
+                                wgt[u] = (double) ((int) m >> 24);
+                            }
+                            else if (SYN_FMT == 1)
+                            {
+                                const uint32_t m = im.syn_meta[s];
+                                meta[u] = m & 0xfffffu;
+                                wgt[u] = (double) ((int) m >> 20);
+                            }
+                            else
+                            {
+                                meta[u] = im.syn_meta[s];
+                                wgt[u] = im.syn_weight[s];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < EXPAND_UNROLL; u++)
+                    if (!((meta[u] >> 19) & 1u))
+                    {
+                        if (LAST && last_mode)
+                        {
+                            atomicMax(&lastv[meta[u] & 0xffffu], spos[u] + 1u);
+                            continue;
+                        }
+                        const uint32_t idx = (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
+                        atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
+                        if (TOUCH_BYTES) touched[idx] = 1;
+                    }
+            }
+            heads_before = seen;
+        }
+        wave_lds_fence(); // the lists are rewritten by the next chunk
+    }
+    __syncthreads();
+    // ---- write the accumulated charge back (one RMW per touched neuron and delay value) ----
+    const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
+    if (LAST && last_mode)
+    {
+        // the latest event over all slices of the core wins: positions grow in delivery order
+        for (uint32_t n = threadIdx.x; n < npad; n += DELIVER_BLOCK)
+            if (lastv[n] != 0u) atomicMax(&st.ring_last[nbase + n], lastv[n]);
+    }
+    else
+    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
+    {
+        if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
+        const uint32_t d = i / RS, n = i - d * RS;
+        if (n >= npad) continue; // trash entry
+        // a neuron behind a gated delay line (SANAFE_IN_GATED; per neuron: a core may mix dendrite units)
+        const bool gated = HAS_DELAY && ((im.slot_cls[nbase + n] >> 3) & 7u) == SANAFE_IN_GATED;
+        const uint32_t wslot = (uint32_t) ((t + 1 + d + (gated ? 1 : 0)) % R);
+        const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
+        if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
+        else st.ring[gi] += acc[i];
+        st.ring_valid[gi] = 1;
+        if (gated) st.arrived[nbase + n] = 1;
+    }
+    // ---- processing-delay sum of this slice (simple timing model) ----
+    proc = wave_sum(proc);
+    if (lane == 0) s_red[wave] = proc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double p = 0.0;
+        for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
+        // one add per slice; the order over a core's slices is not fixed, which moves the simple
+        // timing model's per-core sum by at most an ulp or two (tolerance on sim_time is 1e-6)
+        atomicAdd(&st.core_proc[(uint32_t) (done & 1) * im.n_cores + core], p);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: per-step reduction (one workgroup, fixed summation order): inside the next neuron launch, or reduce_kernel
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_max(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, WAVE));
+    return x;
+}
+
+// One 256-thread workgroup reduces a finished step: per-thread partial over its cores -> wave reduction (shuffles)
+// -> one LDS slot per wave -> thread 0 combines the waves in order.  One barrier; the association is fixed, so
+// results are reproducible.  sim_calculate_ts_energy, sim_update_ts_counters, schedule_messages_timestep_simple
+// (src/chip.cpp:1028-1051, 1171-1261; src/schedule.cpp:61-102), update_run_data (src/chip.cpp:462-475).
+__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5])
+{
+    const int simple_timing = prev.simple_timing, record = prev.record;
+    const CorePart *core_part = st.core_part + (size_t) prev.parity * im.n_cores;
+    const double *core_proc = st.core_proc + (size_t) prev.parity * im.n_cores;
+    double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
+    long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
+    for (uint32_t c = threadIdx.x; c < im.n_cores; c += REDUCE_BLOCK)
+    {
+        const CorePart cp = core_part[c];
+        e_soma += cp.e_soma;
+        e_dend += cp.e_dend;
+        e_syn += cp.e_syn;
+        e_net += cp.e_net;
+        upd += cp.updated;
+        fired += cp.fired;
+        packets += cp.packets;
+        hops += cp.hops;
+        events += cp.events;
+        gmax = fmax(gmax, cp.gen_sum);
+        pmax = fmax(pmax, core_proc[c]);
+    }
+    e_soma = wave_sum(e_soma);
+    e_dend = wave_sum(e_dend);
+    e_syn = wave_sum(e_syn);
+    e_net = wave_sum(e_net);
+    gmax = wave_max(gmax);
+    pmax = wave_max(pmax);
+    upd = wave_sum(upd);
+    fired = wave_sum(fired);
+    packets = wave_sum(packets);
+    hops = wave_sum(hops);
+    events = wave_sum(events);
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    if (lane == 0)
+    {
+        sd[wave][0] = e_soma;
+        sd[wave][1] = e_dend;
+        sd[wave][2] = e_syn;
+        sd[wave][3] = e_net;
+        sd[wave][4] = gmax;
+        sd[wave][5] = pmax;
+        sl[wave][0] = upd;
+        sl[wave][1] = fired;
+        sl[wave][2] = packets;
+        sl[wave][3] = hops;
+        sl[wave][4] = events;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        e_soma = e_dend = e_syn = e_net = 0.0;
+        upd = fired = packets = hops = events = 0;
+        gmax = sd[0][4];
+        pmax = sd[0][5];
+        for (int w = 0; w < REDUCE_BLOCK / WAVE; w++)
+        {
+            e_soma += sd[w][0];
+            e_dend += sd[w][1];
+            e_syn += sd[w][2];
+            e_net += sd[w][3];
+            gmax = fmax(gmax, sd[w][4]);
+            pmax = fmax(pmax, sd[w][5]);
+            upd += sl[w][0];
+            fired += sl[w][1];
+            packets += sl[w][2];
+            hops += sl[w][3];
+            events += sl[w][4];
+        }
+    }
+    if (threadIdx.x == 0)
+    {
+        sanafe_hip_totals ts;
+        ts.timesteps = 1;
+        ts.spikes = events;
+        ts.packets_sent = packets;
+        ts.neurons_updated = upd;
+        ts.neurons_fired = fired;
+        ts.total_hops = hops;
+        ts.synapse_energy = e_syn;
+        ts.dendrite_energy = e_dend;
+        ts.soma_energy = e_soma;
+        ts.network_energy = e_net;
+        ts.total_energy = ((e_net + e_syn) + e_dend) + e_soma;
+        ts.sim_time = simple_timing ? fmax(pmax, gmax) + im.sync_delay : 0.0;
+        sanafe_hip_totals r = *st.run; // update_run_data, src/chip.cpp:462-475
+        r.timesteps += 1;
+        r.spikes += ts.spikes;
+        r.packets_sent += ts.packets_sent;
+        r.neurons_updated += ts.neurons_updated;
+        r.neurons_fired += ts.neurons_fired;
+        r.total_hops += ts.total_hops;
+        r.total_energy += ts.total_energy;
+        r.synapse_energy += ts.synapse_energy;
+        r.dendrite_energy += ts.dendrite_energy;
+        r.soma_energy += ts.soma_energy;
+        r.network_energy += ts.network_energy;
+        r.sim_time += ts.sim_time;
+        *st.run = r;
+        if (record)
+        {
+            ts.timesteps = *st.t + 1; // the record carries the timestep number
+            st.step_log[prev.rec_index % st.log_cap] = ts;
+            *st.rec = prev.rec_index + 1;
+        }
+        *st.t = *st.t + 1;
+    }
+}
+
+// Flushes the reduction of the last launched step when no further neuron launch follows it.
+__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PrevStep prev)
+{
+    __shared__ double sd[REDUCE_BLOCK / WAVE][6];
+    __shared__ long long sl[REDUCE_BLOCK / WAVE][5];
+    reduce_step(im, st, prev, sd, sl);
+}
+
+__global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has,
+        long long done)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t g = slots[i];
+    const long long t = done + 1;
+    const size_t gi = (size_t) (t % im.ring_slots) * im.n_slots + g;
+    const uint32_t inkind = (im.slot_cls[g] >> 3) & 7u;
+    if (inkind == SANAFE_IN_ZERO)
+    {
+        has[i] = 1;
+        cur[i] = 0.0;
+        return;
+    }
+    if (inkind == SANAFE_IN_GATED)
+    {
+        const uint8_t valid = st.ring_valid[gi];
+        const double value = st.ring[gi];
+        if (valid)
+        {
+            st.ring[gi] = 0.0;
+            st.ring_valid[gi] = 0;
+        }
+        const bool arr = st.arrived[g] != 0;
+        st.arrived[g] = 0;
+        has[i] = (arr && valid) ? 1 : 0;
+        cur[i] = (arr && valid) ? value : 0.0;
+        return;
+    }
+    if (inkind == SANAFE_IN_LAST)
+    {
+        has[i] = 1;
+        double c = 0.0;
+        const uint32_t last = st.ring_last[g];
+        if (last != 0u)
+        {
+            uint32_t core = 0; // the slot's core: cores are few, slots of a core contiguous
+            while (core + 1 < im.n_cores && im.core_nbase[core + 1] <= g) core++;
+            const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
+            c = 0.0 + ((im.syn_format == 2) ? im.syn_weight[pos] : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20)));
+            st.ring_last[g] = 0u;
+        }
+        cur[i] = c;
+        return;
+    }
+    const uint8_t h = st.ring_valid[gi];
+    has[i] = h;
+    cur[i] = h ? st.ring[gi] : 0.0;
+    if (h)
+    {
+        st.ring[gi] = 0.0;
+        st.ring_valid[gi] = 0;
+    }
+}
+
+__global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core, const double *energy, const double *latency, int parity)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t g = slots[i];
+    const uint8_t s = status[i];
+    st.status[g] = s;
+    CorePart *cp = st.core_part + (size_t) parity * im.n_cores + core[i];
+    atomicAdd(&cp->e_soma, energy[i]);
+    atomicAdd(&cp->gen_sum, latency[i]);
+    if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
+    if (s == 3)
+    {
+        atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
+        atomicAdd((unsigned long long *) &cp->fired, 1ull);
+        atomicAdd((unsigned long long *) &cp->packets, (unsigned long long) im.slot_packets[g]);
+        atomicAdd((unsigned long long *) &cp->hops, (unsigned long long) im.slot_hops[g]);
+        atomicAdd((unsigned long long *) &cp->events, (unsigned long long) im.slot_events[g]);
+        atomicAdd(&cp->e_net, im.slot_e_net[g]);
+        atomicAdd(&cp->e_syn, im.slot_e_syn[g]);
+        atomicAdd(&cp->e_dend, im.slot_e_dend[g]);
+        atomicAdd(&cp->gen_sum, (double) im.slot_packets[g] * im.core_axon_out_latency[core[i]]);
+    }
+}
