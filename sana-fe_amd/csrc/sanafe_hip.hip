@@ -283,9 +283,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
 {
     if (!image || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (sanafe_hip_device_count() <= device)
+    TRY(validate(image)); // a malformed image is reported as such, with or without a device
+    if (device < 0 || sanafe_hip_device_count() <= device)
         return fail(SANAFE_HIP_ERR_NO_DEVICE, "no HIP device %d (libsanafe_hip has no CPU fallback)", device);
-    TRY(validate(image));
     auto *c = new sanafe_hip_chip();
     c->device = device;
     auto bail = [&](int rc) {
