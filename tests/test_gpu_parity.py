@@ -176,46 +176,45 @@ def test_value_streams_batched_in_chunks(S, tmp_path, monkeypatch):
     assert tot["neurons_fired"] > 0
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16])
-def test_random_configurations(S, seed):
-    """Randomly drawn shapes around the thresholds of the delivery kernel's paths: chunk boundaries (256 axons),
-    the stream/gather switch (16 spiking axons per chunk), single- and multi-slice cores, delays or not."""
+def _random_configuration(S, seed):
+    """Randomly drawn shapes around the thresholds of the delivery kernel's paths: chunk boundaries (256 axons), the
+    stream/gather switch (16 spiking axons per chunk), single- and multi-slice cores, every supported buffer position
+    and dendrite, the three synapse formats."""
     rng = np.random.default_rng(seed)
-    kind = ["large", "loihi"][int(rng.integers(0, 2))]
-    delays = bool(kind == "large" and rng.integers(0, 2))
+    kind = ["large", "loihi", "before_dendrite", "loihi_delay"][int(rng.integers(0, 4))]
+    delays = kind == "loihi_delay" or bool(kind == "large" and rng.integers(0, 2))
     npc = int(rng.choice([37, 64, 200, 257, 511, 700]))
     cores = int(rng.integers(2, 7))
     n = npc * cores
-    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=npc, cores_used=cores,
-                                  out_degree=int(min(n, rng.choice([5, 40, 150, 400]))), arch_kind=kind, delays=delays,
-                                  p_fire=float(rng.choice([0.01, 0.05, 0.3])), seed=seed,
-                                  weights=str(rng.choice(["int", "int", "int12"])), refractory=bool(rng.integers(0, 2)))
-    check_batched(S, arch, net, steps=14)
+    return nets.random_loihi(S, n_tiles=2, neurons_per_core=npc, cores_used=cores,
+                             out_degree=int(min(n, rng.choice([5, 40, 150, 400]))), arch_kind="loihi" if kind == "loihi_delay" else kind,
+                             delays=delays, p_fire=float(rng.choice([0.01, 0.05, 0.3])), seed=seed,
+                             weights=str(rng.choice(["int", "int", "int12", "float"] if not delays else ["int", "int12"])),
+                             refractory=bool(rng.integers(0, 2)),
+                             dendrite="loihi_dendrites_delay" if kind == "loihi_delay" else None)
 
 
-@pytest.mark.parametrize("weights", ["int", "int12", "float"])
-def test_buffer_before_dendrite_keeps_last_event(S, weights, monkeypatch):
-    """`buffer_position: dendrite` outside the unit (SANAFE_IN_LAST): last event in delivery order wins, across
-    the stream and gather paths, several slices per core and all three synapse formats."""
-    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
-    monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
-    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=300, out_degree=200, arch_kind="before_dendrite", p_fire=0.2,
-                                  seed=4, weights=weights)
-    chip, _ = check_batched(S, arch, net, steps=12)[:2]
-    assert chip.info()["n_slices"] > 8
-
-
-def test_delay_line_behind_the_time_step_buffer(S, monkeypatch):
-    """arch/loihi.yaml + `loihi_dendrites_delay` (SANAFE_IN_GATED), some neurons of the same cores on the plain
-    accumulator, cores split over several delivery slices."""
-    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
-    monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
-    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=200, out_degree=120, arch_kind="loihi", delays=True, p_fire=0.15,
-                                  seed=13, dendrite="loihi_dendrites_delay")
-    g = net._order[0]
-    g.dendrite_hw[::3] = net.strings("loihi_dendrites")  # every third neuron integrates without the delay line
-    chip, _ = check_batched(S, arch, net, steps=30)[:2]
-    assert chip.info()["n_slices"] > 8
+@pytest.mark.parametrize("seed", list(range(11, 27)))
+def test_random_configurations(S, seed, monkeypatch):
+    if seed % 2:
+        monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
+        monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
+    arch, net = _random_configuration(S, seed)
+    chip, orc = make(S, arch, net)
+    exact = chip.device_layout()["syn_format"] != 2
+    tot = chip.run(14, "simple", record=True)
+    recs = chip.step_totals(0, 14)
+    for t in range(14):
+        b = orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert recs[ka][t] == b[kb], (t, ka)
+        for k in DBL_KEYS:
+            assert recs[k][t] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        assert np.array_equal(chip.step_fired(t), (orc.status() == 3).astype(np.uint8)), t
+    if exact:
+        assert np.array_equal(chip.potentials(), orc.potentials())
+    else:
+        assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-9, atol=1e-12)
 
 
 def test_plain_accumulator_inside_dendrite_quirk(S):
