@@ -128,7 +128,8 @@ typedef struct sanafe_desc
     const int64_t *edge_dst;         /* [e] global neuron id */
     const int32_t *edge_synapse_hw;  /* [e] Connection::synapse_hw_name or -1 */
     const double *edge_weight;       /* [e] "w"/"weight" (0.0 if absent) */
-    const int8_t *edge_delay;        /* [e] "d"/"delay" or -1 if absent; may be NULL */
+    const int8_t *edge_delay;        /* [e] the edge's dendrite attribute: "d"/"delay" (0..5), or 64 + "tap" (tap index
+                                        of a `taps` dendrite, src/models.cpp:330-342), or -1 if absent; may be NULL */
     const int64_t *edge_attr_ptr;    /* [e+1] extra attributes, may be NULL */
     sanafe_attr_table edge_attrs;
 } sanafe_desc;

@@ -66,6 +66,10 @@ enum {
                                  outside): the charge maturing at step t is handed to the soma at t+1 only if some event
                                  reached the neuron at step t (the unit is only called on events and its output is what the
                                  buffer keeps, src/models.cpp:96-131, src/chip.cpp:759); otherwise it is lost */
+    SANAFE_IN_TAPS = 4,       /* `taps` dendrite (MultiTapModel1D, src/models.cpp:167-348) behind the kernel's buffer: the
+                                 synapse's delay field carries the tap index; tap state advances once per step, the
+                                 step's charge is added per tap, and tap 0 is handed to the soma at t+1 if an event
+                                 reached the neuron at t (slot_aux = entry of the tap tables) */
     SANAFE_IN_LAST = 2        /* buffer before the dendrite unit (`buffer_position: dendrite`, outside): the kernel's
                                  time-step buffer keeps only the LAST synaptic event's current (src/chip.cpp:759), which the
                                  accumulator then integrates alone; always "has input" (the lazy clear leaves 0.0) */
@@ -137,6 +141,13 @@ typedef struct sanafe_hip_image
     const uint32_t *in_train_len; /* bits */
     const int64_t *in_rate_period;/* (long)(1.0/rate), 0 = no rate input */
     const uint32_t *in_train_bits;/* [n_train_words] packed LSB first */
+
+    /* ---- `taps` dendrites [n_taps] (optional) ---- */
+    uint32_t n_taps;
+    const uint32_t *tap_slot;     /* slot of the neuron */
+    const uint32_t *tap_count;    /* taps, 1..8 */
+    const double *tap_tc;         /* [n_taps][8] time constants */
+    const double *tap_sc;         /* [n_taps][8] space constants between tap k and k+1 */
 
     /* ---- external per-step value streams (optional; host-generated, sanafe_hip_write_ext) ----
      * Three models consume a sequential host-side source on every update, which makes the

@@ -1039,9 +1039,9 @@ struct oracle_chip
             if (d.edge_delay && d.edge_delay[e] >= 0)
             {
                 Attr dl;
-                dl.key = "delay";
+                dl.key = d.edge_delay[e] >= 64 ? "tap" : "delay"; // include/sanafe_desc.h: 64 + tap index
                 dl.type = SANAFE_ATTR_INT;
-                dl.num = d.edge_delay[e];
+                dl.num = d.edge_delay[e] >= 64 ? d.edge_delay[e] - 64 : d.edge_delay[e];
                 attrs.push_back(dl);
             }
             if (d.edge_attr_ptr)

@@ -524,6 +524,8 @@ class HipImage(C.Structure):
         ("slot_e_dend", _p(C.c_double)),
         ("in_train_beg", _p(C.c_uint32)), ("in_train_len", _p(C.c_uint32)), ("in_rate_period", _p(C.c_int64)),
         ("in_train_bits", _p(C.c_uint32)),
+        ("n_taps", C.c_uint32), ("tap_slot", _p(C.c_uint32)), ("tap_count", _p(C.c_uint32)), ("tap_tc", _p(C.c_double)),
+        ("tap_sc", _p(C.c_double)),
         ("n_ext", C.c_uint32), ("slot_ext", _p(C.c_uint32)),
         ("slice_core", _p(C.c_uint32)), ("slice_axon_beg", _p(C.c_uint64)), ("slice_axon_end", _p(C.c_uint64)),
         ("core_syn_base", _p(C.c_uint64)), ("core_axon_in_latency", _p(C.c_double)),
@@ -564,6 +566,7 @@ def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
                   "slot_e_net", "slot_e_syn", "slot_e_dend"):
             counts[n] = im.n_slots
         counts["slot_ext"] = im.n_slots if im.n_ext else 0
+        counts.update(tap_slot=im.n_taps, tap_count=im.n_taps, tap_tc=im.n_taps * 8, tap_sc=im.n_taps * 8)
         out = {}
         for n, _t in HipImage._fields_:
             v = getattr(im, n)

@@ -254,8 +254,12 @@ int validate(const sanafe_hip_image *im)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
-        if (((cls >> 3) & 7u) > SANAFE_IN_GATED) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) > SANAFE_IN_TAPS) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) == SANAFE_IN_TAPS && (im->slot_aux[g] >= im->n_taps || im->tap_count[im->slot_aux[g]] < 1 || im->tap_count[im->slot_aux[g]] > 8))
+            return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad tap table entry", g);
     }
+    for (uint32_t i = 0; i < im->n_taps; i++)
+        if (im->tap_slot[i] >= im->n_slots) return fail(SANAFE_HIP_ERR_INVALID, "tap table entry %u: bad slot", i);
     if (im->n_ext > 0)
     {
         if (!im->slot_ext) return fail(SANAFE_HIP_ERR_INVALID, "n_ext > 0 but slot_ext is NULL");
@@ -339,6 +343,16 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(upload(c, h.in_train_len, h.n_input, &im.in_train_len));
     TRYC(upload(c, reinterpret_cast<const long long *>(h.in_rate_period), h.n_input, &im.in_rate_period));
     TRYC(upload(c, h.in_train_bits, h.n_train_words, &im.in_train_bits));
+    im.n_taps = h.n_taps;
+    im.tap_slot = im.tap_count = nullptr;
+    im.tap_tc = im.tap_sc = nullptr;
+    if (h.n_taps > 0)
+    {
+        TRYC(upload(c, h.tap_slot, h.n_taps, &im.tap_slot));
+        TRYC(upload(c, h.tap_count, h.n_taps, &im.tap_count));
+        TRYC(upload(c, h.tap_tc, (size_t) h.n_taps * 8, &im.tap_tc));
+        TRYC(upload(c, h.tap_sc, (size_t) h.n_taps * 8, &im.tap_sc));
+    }
     im.n_ext = h.n_ext;
     im.slot_ext = nullptr;
     if (h.n_ext > 0) TRYC(upload(c, h.slot_ext, h.n_slots, &im.slot_ext));
@@ -554,11 +568,17 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         bool any_gated = false;
         for (uint32_t g = 0; g < h.n_slots && !any_gated; g++)
             any_gated = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_GATED;
-        if (any_gated)
+        if (any_gated && h.ring_slots < 7) return bail(fail(SANAFE_HIP_ERR_INVALID, "SANAFE_IN_GATED neurons need ring_slots >= 7"));
+        if (any_gated || h.n_taps > 0)
         {
-            if (h.ring_slots < 7) return bail(fail(SANAFE_HIP_ERR_INVALID, "SANAFE_IN_GATED neurons need ring_slots >= 7"));
             TRYC(dalloc(c, h.n_slots, &st.arrived));
-            c->force_delay_variant = true; // the +1 slot shift lives in the HAS_DELAY kernels
+            c->force_delay_variant = true; // per-neuron write-back rules live in the HAS_DELAY kernels
+        }
+        st.tap_v = st.tap_in = nullptr;
+        if (h.n_taps > 0)
+        {
+            TRYC(dalloc(c, (size_t) h.n_taps * 8, &st.tap_v));
+            TRYC(dalloc(c, (size_t) h.n_taps * 8, &st.tap_in));
         }
     }
     TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
@@ -689,6 +709,13 @@ static int launch_deliver(sanafe_hip_chip *c)
     }
     return 0;
 }
+static int launch_taps(sanafe_hip_chip *c)
+{
+    if (c->im.n_taps == 0) return 0;
+    hipLaunchKernelGGL(taps_kernel, dim3((c->im.n_taps + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, c->t_host);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
 // The reduction of the step just launched is left pending: the next neuron launch performs it, or flush_pending.
 static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long long rec_index)
 {
@@ -724,6 +751,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         {
             TRY(launch_neurons(c, record, s));
             TRY(launch_deliver(c));
+            TRY(launch_taps(c));
             finish_step(c, simple_timing, record, s);
         }
         return 0;
@@ -738,6 +766,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         TRY(launch_neurons(c, record, s));
         HIPCHK(hipEventRecord(ev[s * 4 + 1], c->stream));
         TRY(launch_deliver(c));
+        TRY(launch_taps(c));
         HIPCHK(hipEventRecord(ev[s * 4 + 2], c->stream));
         finish_step(c, simple_timing, record, s);
         TRY(flush_pending(c));
@@ -829,11 +858,13 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     if (!c->timing)
     {
         TRY(launch_deliver(c));
+        TRY(launch_taps(c));
         finish_step(c, simple_timing, 0, 0);
         return 0;
     }
     TRY(timed_event(c));
     TRY(launch_deliver(c));
+    TRY(launch_taps(c));
     TRY(timed_event(c));
     finish_step(c, simple_timing, 0, 0);
     TRY(flush_pending(c));
@@ -1106,6 +1137,11 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
     HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
     if (c->st.ring_last) HIPCHK(hipMemsetAsync(c->st.ring_last, 0, n * sizeof(uint32_t), c->stream));
     if (c->st.arrived) HIPCHK(hipMemsetAsync(c->st.arrived, 0, n, c->stream));
+    if (c->st.tap_v)
+    {
+        HIPCHK(hipMemsetAsync(c->st.tap_v, 0, (size_t) c->im.n_taps * 8 * sizeof(double), c->stream));
+        HIPCHK(hipMemsetAsync(c->st.tap_in, 0, (size_t) c->im.n_taps * 8 * sizeof(double), c->stream));
+    }
     return 0;
 }
 

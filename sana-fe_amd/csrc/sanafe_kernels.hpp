@@ -30,6 +30,9 @@ struct DevImage
     const long long *in_rate_period;
     const uint32_t *slot_ext; // column of the slot in a row of external stream values (0xffffffff: none)
     uint32_t n_ext;
+    uint32_t n_taps;          // neurons behind a `taps` dendrite (SANAFE_IN_TAPS); tables indexed by slot_aux
+    const uint32_t *tap_slot, *tap_count;
+    const double *tap_tc, *tap_sc; // [n_taps][8]
     const uint32_t *slice_core;
     const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
     const uint32_t *core_slice_beg; // [n_cores+1]
@@ -81,7 +84,9 @@ struct DevState
     uint32_t *in_pos;
     double *ring;          // [ring_slots][n_slots]
     uint8_t *ring_valid;   // [ring_slots][n_slots]
-    uint8_t *arrived;      // [n_slots], SANAFE_IN_GATED cores: an event reached the neuron in the previous step
+    uint8_t *arrived;      // [n_slots], SANAFE_IN_GATED / _TAPS neurons: an event reached the neuron in this step
+    double *tap_v;         // [n_taps][8] tap voltages
+    double *tap_in;        // [n_taps][8] charge delivered to each tap in the current step
     uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
     uint32_t *bits_local;  // [n_slots/32]
     uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
@@ -916,8 +921,16 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
         const uint32_t d = i / RS, n = i - d * RS;
         if (n >= npad) continue; // trash entry
-        // a neuron behind a gated delay line (SANAFE_IN_GATED; per neuron: a core may mix dendrite units)
-        const bool gated = HAS_DELAY && ((im.slot_cls[nbase + n] >> 3) & 7u) == SANAFE_IN_GATED;
+        // per neuron: a core may mix dendrite units
+        const uint32_t post_kind = HAS_DELAY ? (im.slot_cls[nbase + n] >> 3) & 7u : (uint32_t) SANAFE_IN_BUFFERED;
+        if (post_kind == SANAFE_IN_TAPS)
+        {
+            // row d is tap d of the neuron's dendrite: taps_kernel integrates it after this launch
+            atomicAdd(&st.tap_in[(size_t) im.slot_aux[nbase + n] * 8u + d], acc[i]);
+            st.arrived[nbase + n] = 1;
+            continue;
+        }
+        const bool gated = post_kind == SANAFE_IN_GATED; // a neuron behind a gated delay line
         const uint32_t wslot = (uint32_t) ((t + 1 + d + (gated ? 1 : 0)) % R);
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
         if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
@@ -1059,6 +1072,52 @@ __device__ void reduce_step(const DevImage &im, const DevState &st, const PrevSt
             *st.rec = prev.rec_index + 1;
         }
         *st.t = *st.t + 1;
+    }
+}
+
+// `taps` dendrites, after the delivery launch of step t (one thread per neuron): advance the RC line by one step
+// (MultiTapModel1D::calculate_next_state, src/models.cpp:167-205 -- the reference catches up lazily at the first
+// event, which is the same sequence of operations), add the charge delivered to each tap in this step, and hand
+// tap 0 to the soma through the time-step buffer of step t+1 if an event reached the neuron (src/models.cpp:240-262).
+__global__ void taps_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= im.n_taps) return;
+    const uint32_t taps = im.tap_count[i], g = im.tap_slot[i];
+    double v[8], nv[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = st.tap_v[(size_t) i * 8 + k];
+    const double *tc = im.tap_tc + (size_t) i * 8, *sc = im.tap_sc + (size_t) i * 8;
+    for (uint32_t k = 0; k < taps; k++) nv[k] = v[k] * tc[k];
+    for (uint32_t s = 0; s < taps; s++)
+    {
+        if (s > 0)
+        {
+            const double c = v[s] * sc[s - 1];
+            nv[s - 1] += c;
+            nv[s] -= c;
+        }
+        if (s + 1 < taps)
+        {
+            const double c = v[s] * sc[s];
+            nv[s + 1] += c;
+            nv[s] -= c;
+        }
+    }
+    for (uint32_t k = 0; k < taps; k++)
+    {
+        // the events of the step add to the advanced state one by one; their sum per tap arrives here
+        v[k] = nv[k] + st.tap_in[(size_t) i * 8 + k];
+        st.tap_in[(size_t) i * 8 + k] = 0.0;
+        st.tap_v[(size_t) i * 8 + k] = v[k];
+    }
+    if (st.arrived[g] != 0)
+    {
+        st.arrived[g] = 0;
+        const long long t = done + 1;
+        const size_t gi = (size_t) ((t + 1) % im.ring_slots) * im.n_slots + g;
+        st.ring[gi] = v[0];
+        st.ring_valid[gi] = 1;
     }
 }
 

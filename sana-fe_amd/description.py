@@ -352,6 +352,10 @@ class Neuron:
         attributes = attributes or {}
         w = attributes.get("w", attributes.get("weight", 0.0))
         d = attributes.get("delay", attributes.get("d", None))
+        if "tap" in attributes:
+            if d is not None:
+                raise NotImplementedError("an edge with both `delay` and `tap`")
+            d = 64 + int(attributes["tap"])  # include/sanafe_desc.h: edge_delay carries 64 + tap index
         net = self.group.net
         net._add_edges(np.array([self.group.base + self.offset]), np.array([dest.group.base + dest.offset]),
                        np.array([float(np.float32(w)) if isinstance(w, float) else float(w)]),
@@ -478,9 +482,13 @@ class NeuronGroup:
         attributes = attributes or {}
         w = attributes.get("w", attributes.get("weight"))
         d = attributes.get("delay", attributes.get("d"))
-        extra = set(attributes) - {"w", "weight", "delay", "d"}
+        if "tap" in attributes:
+            if d is not None:
+                raise NotImplementedError("edges with both `delay` and `tap`")
+            d = 64 + np.asarray(attributes["tap"], dtype=np.int64)  # include/sanafe_desc.h: 64 + tap index
+        extra = set(attributes) - {"w", "weight", "delay", "d", "tap"}
         if extra:
-            raise NotImplementedError("edge attributes other than weight/delay: %s" % sorted(extra))
+            raise NotImplementedError("edge attributes other than weight/delay/tap: %s" % sorted(extra))
         return w, d
 
     @staticmethod

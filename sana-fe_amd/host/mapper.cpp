@@ -412,6 +412,11 @@ sanafe_hip_image MappedChip::image() const
     im.in_train_len = in_train_len.data();
     im.in_rate_period = in_rate_period.data();
     im.in_train_bits = in_train_bits.data();
+    im.n_taps = static_cast<uint32_t>(tap_slot.size());
+    im.tap_slot = tap_slot.data();
+    im.tap_count = tap_count.data();
+    im.tap_tc = tap_tc.data();
+    im.tap_sc = tap_sc.data();
     im.n_ext = static_cast<uint32_t>(ext.size());
     im.slot_ext = ext.empty() ? nullptr : slot_ext.data();
     im.slice_core = slice_core.data();
@@ -623,7 +628,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     mc.slot_model.assign(LS, SANAFE_SOMA_NONE);
     std::map<ClassKey, uint32_t> class_ids;
     std::map<CostKey, uint32_t> cost_ids;
-    bool any_delay_dendrite = false, any_gated_delay = false;
+    bool any_delay_dendrite = false, any_gated_delay = false, any_taps = false;
+    std::vector<int32_t> taps_index(N, -1); // neuron -> entry of the tap tables (local neurons only)
     std::vector<uint8_t> neuron_dend_kind(N, 0); // 0 buffered accumulator, 1 zero, 2 delay line
     // InputModel seeds: every unit of every core is constructed up front, cores in id order, units in
     // template order (src/chip.cpp:83-87), and each `input` instance takes ++counter (src/models.hpp:347).
@@ -650,12 +656,15 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE && bp != SANAFE_BUF_BEFORE_DENDRITE)
             throw UnsupportedError("buffer position " + std::to_string(bp) +
                     " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside, dendrite/outside)");
-        if (du.model == M_TAPS || du.model == M_PLUGIN)
+        if (du.model == M_PLUGIN)
             throw UnsupportedError("dendrite model of unit '" + du.name + "' is not implemented on the MI355X backend");
+        if (du.model == M_TAPS && bp != SANAFE_BUF_BEFORE_SOMA)
+            throw UnsupportedError("`taps` dendrites are implemented for `buffer_position: soma` (outside the unit) only");
         if (du.log || su.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
         uint8_t kind = SANAFE_IN_BUFFERED;
         if (bp == SANAFE_BUF_INSIDE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_ZERO, neuron_dend_kind[gid] = 1;
         if (bp == SANAFE_BUF_BEFORE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_LAST;
+        if (du.model == M_TAPS) kind = SANAFE_IN_TAPS, neuron_dend_kind[gid] = 3, any_taps = true;
         if (du.model == M_ACC_DELAY)
         {
             if (bp == SANAFE_BUF_BEFORE_DENDRITE)
@@ -719,6 +728,50 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         else if (su.model == M_TRUENORTH) model = SANAFE_SOMA_TRUENORTH, p.leak_decay = 0.0;
         else if (su.model == M_INPUT) model = SANAFE_SOMA_INPUT;
         else model = SANAFE_SOMA_HOST;
+        if (du.model == M_TAPS)
+        {
+            // MultiTapModel1D::set_attribute_neuron in attribute (key) order, src/models.cpp:263-329
+            std::vector<double> v(1, 0.0), tc(1, 0.0), space;
+            for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+            {
+                const Attr a{&d.neuron_attrs, i, &d};
+                if (!(a.fwd() & SANAFE_FWD_DENDRITE)) continue;
+                const std::string k = a.key();
+                auto list_of = [&]() {
+                    if (a.type() != SANAFE_ATTR_LIST) throw std::runtime_error("Error: Attribute " + k + " is not a list");
+                    return std::vector<double>(d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i], d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i + 1]);
+                };
+                if (k == "taps")
+                {
+                    const size_t n_taps = static_cast<size_t>(a.as_int());
+                    if (n_taps == 0) throw std::invalid_argument("Number of taps must be > 0\n");
+                    v.resize(n_taps);
+                    tc.resize(n_taps);
+                    space.resize(n_taps - 1);
+                }
+                else if (k == "time_constants")
+                {
+                    tc = list_of();
+                    if (tc.size() < v.size())
+                        throw std::invalid_argument("Expected " + std::to_string(v.size()) + " but received " + std::to_string(tc.size()) + "time constants.");
+                }
+                else if (k == "space_constants")
+                {
+                    space = list_of();
+                    if (space.size() < v.size() - 1)
+                        throw std::invalid_argument("Expected " + std::to_string(v.size() - 1) + " but received " + std::to_string(tc.size()) + "time constants.");
+                }
+            }
+            if (v.size() > 8) throw UnsupportedError("`taps` dendrites with more than 8 taps are not implemented on the MI355X backend");
+            taps_index[gid] = static_cast<int32_t>(mc.tap_slot.size());
+            mc.tap_slot.push_back(ls);
+            mc.tap_count.push_back(static_cast<uint32_t>(v.size()));
+            for (size_t k = 0; k < 8; k++)
+            {
+                mc.tap_tc.push_back(k < v.size() ? tc[k] : 0.0);
+                mc.tap_sc.push_back(k + 1 < v.size() ? space[k] : 0.0);
+            }
+        }
         std::vector<double> train;
         double rate = 0.0, poisson = 0.0;
         uint32_t tn_mask = 0;
@@ -853,6 +906,11 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             pcls = it->second;
         }
         mc.slot_cls[ls] = model | (static_cast<uint32_t>(kind) << 3) | (cit->second << 6) | (pcls << 16);
+        if (du.model == M_TAPS)
+        {
+            if (model == SANAFE_SOMA_INPUT) throw UnsupportedError("an input soma behind a `taps` dendrite");
+            mc.slot_aux[ls] = static_cast<uint32_t>(taps_index[gid]);
+        }
         mc.slot_model[ls] = static_cast<uint8_t>(model);
         mc.slot_log_spikes[ls] = d.neuron_log_spikes[gid];
         mc.slot_log_potential[ls] = d.neuron_log_potential[gid];
@@ -885,6 +943,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});
     mc.ring_slots = any_gated_delay ? 7 : any_delay_dendrite ? 6 : 1; // gated delay lines mature one step later
+    if (any_taps) mc.ring_slots = 8; // the delay field doubles as the tap index (<= 7): the image contract is field < ring_slots
 
     lap("neurons + slots");
     // ------------------------------------------------------------------ map_connections, src/chip.cpp:334-380
@@ -917,7 +976,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             edge_syn_unit[e] = su;
         }
     });
-    if (d.edge_delay && any_delay_dendrite)
+    if (d.edge_delay && (any_delay_dendrite || any_taps))
     {
         // The delay dendrite stores delays[] indexed by the SYNAPSE unit's address of the
         // connection (src/mapped.cpp:60-89, src/models.cpp:133-152): connections that reach the
@@ -948,20 +1007,29 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             {
                 auto &tab = delays[{c, dend_unit[dst]}];
                 if (tab.size() <= addr) tab.resize(addr + 1, 0); // every forwarded attribute resizes (weight included)
-                if (d.edge_delay[e] >= 0)
+                if (d.edge_delay[e] >= 0 && d.edge_delay[e] < 64) // (a `tap` attribute means nothing to this unit)
                 {
                     if (d.edge_delay[e] > 5) throw std::runtime_error("Error: delay > max delay\n");
                     tab[addr] = static_cast<uint8_t>(d.edge_delay[e]);
                 }
+            }
+            else if (neuron_dend_kind[dst] == 3 && d.edge_delay[e] >= 64)
+            {
+                // MultiTapModel1D::set_attribute_edge "tap": synapse_to_tap[address], src/models.cpp:330-342
+                auto &tab = delays[{c, dend_unit[dst]}];
+                if (tab.size() <= addr) tab.resize(addr + 1, 0);
+                tab[addr] = static_cast<uint8_t>(d.edge_delay[e] - 64);
             }
         }
         edge_delay_eff.assign(E, 0);
         for (int64_t e = 0; e < E; e++)
         {
             const int64_t dst = d.edge_dst[e];
-            if (neuron_dend_kind[dst] != 2) continue;
+            if (neuron_dend_kind[dst] != 2 && neuron_dend_kind[dst] != 3) continue;
             const auto &tab = delays[{static_cast<uint32_t>(d.neuron_core[dst]), dend_unit[dst]}];
             edge_delay_eff[e] = syn_addr[e] < tab.size() ? tab[syn_addr[e]] : 0;
+            if (neuron_dend_kind[dst] == 3 && taps_index[dst] >= 0 && edge_delay_eff[e] >= mc.tap_count[taps_index[dst]])
+                throw std::logic_error("Tap should be >= 0 and less than taps.\n"); // src/models.cpp:232-237 (raised at load here)
         }
     }
 
@@ -1056,7 +1124,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     const uint32_t post = offset_in_core[dst];
                     if (post > 0xffffu) throw UnsupportedError("more than 65536 neurons on one core");
                     uint32_t meta = post;
-                    if (neuron_dend_kind[dst] == 2) meta |= static_cast<uint32_t>(edge_delay_eff.empty() ? 0 : edge_delay_eff[e]) << 16;
+                    if (neuron_dend_kind[dst] == 2 || neuron_dend_kind[dst] == 3) // delay value, or tap index
+                        meta |= static_cast<uint32_t>(edge_delay_eff.empty() ? 0 : edge_delay_eff[e]) << 16;
                     if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
                     mc.syn_meta[static_cast<size_t>(k - local_beg)] = meta;
                     mc.syn_weight[static_cast<size_t>(k - local_beg)] = d.edge_weight[e];

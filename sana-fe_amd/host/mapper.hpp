@@ -103,6 +103,9 @@ struct MappedChip
         std::string path;
         long random_mask{0x7f}, sign_mask{0x100}; // src/models.hpp:271-272, src/models.cpp:367-371
     };
+    // ---- `taps` dendrites (MultiTapModel1D, src/models.cpp:167-348): one entry per neuron behind such a unit ----
+    std::vector<uint32_t> tap_slot, tap_count; // local slot, number of taps (<= 8)
+    std::vector<double> tap_tc, tap_sc;        // [n][8] time constants, [n][8] space constants (first taps-1 used)
     std::vector<ExtColumn> ext;        // in column order == ascending slot
     std::vector<uint32_t> slot_ext;    // [n_slots] column or 0xffffffff; empty when there is no column
     std::vector<NoiseStream> noise_streams;

@@ -357,6 +357,10 @@ def _parse_edge(net, desc, attrs):
             conv[k] = _typed(v)[1]
         w = conv.get("w", conv.get("weight", 0.0))
         d = conv.get("delay", conv.get("d"))
+        if "tap" in conv:
+            if d is not None:
+                raise NotImplementedError("an edge with both `delay` and `tap`")
+            d = 64 + int(conv["tap"])
         import numpy as np
         net._add_edges(np.array([src.base + so]), np.array([dst.base + to]), np.array([float(w)]),
                        None if d is None else np.array([int(d)]), np.array([dst.synapse_hw[to]]))

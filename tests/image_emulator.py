@@ -22,7 +22,10 @@ class ImageEmulator:
         self.ext_next = 0
         self.last_w = np.zeros(n)           # SANAFE_IN_LAST cores: current of the last event of the previous step
         self.last_set = np.zeros(n, dtype=bool)
-        self.arrived = np.zeros(n, dtype=bool)  # SANAFE_IN_GATED: an event reached the neuron in the previous step
+        self.arrived = np.zeros(n, dtype=bool)  # SANAFE_IN_GATED / _TAPS: an event reached the neuron in the previous step
+        nt = int(im.get("n_taps", 0))
+        self.tap_v = np.zeros((nt, 8))
+        self.tap_in = np.zeros((nt, 8))
         cls = im["slot_cls"]
         self.model = cls & 7
         self.inkind = (cls >> 3) & 7
@@ -50,15 +53,15 @@ class ImageEmulator:
         rs = t % self.R
         n = im["n_slots"]
         status = np.zeros(n, dtype=np.uint8)
-        has_in = np.where(self.inkind >= 1, True, self.valid[rs])
+        has_in = np.where((self.inkind == 1) | (self.inkind == 2), True, self.valid[rs])  # kinds 0 and 4 read the buffer
         cur = np.where(self.inkind == 1, 0.0, np.where(self.valid[rs], self.ring[rs], 0.0))
         cur = np.where(self.inkind == 2, np.where(self.last_set, 0.0 + self.last_w, 0.0), cur)
         self.last_set[:] = False
         gated = self.inkind == 3
         has_in = np.where(gated, self.arrived & self.valid[rs], has_in)
         cur = np.where(gated, np.where(self.arrived & self.valid[rs], self.ring[rs], 0.0), cur)
-        self.arrived[:] = False
-        buf = ((self.inkind == 0) | gated) & self.valid[rs] & (self.model != 0)
+        self.arrived[gated] = False
+        buf = ((self.inkind == 0) | (self.inkind == 4) | gated) & self.valid[rs] & (self.model != 0)
         self.ring[rs][buf] = 0.0
         self.valid[rs][buf] = False
         bias = im["slot_bias"]
@@ -196,12 +199,40 @@ class ImageEmulator:
                         self.last_w[nb + post] = im["syn_weight"][s0 + k]
                         self.last_set[nb + post] = True
                         continue
+                    if self.inkind[nb + post] == 4:  # tap d of the neuron's dendrite
+                        self.tap_in[im["slot_aux"][nb + post], d] += im["syn_weight"][s0 + k]
+                        self.arrived[nb + post] = True
+                        continue
                     if self.inkind[nb + post] == 3:
                         d += 1
                         self.arrived[nb + post] = True
                     ws = (t + 1 + d) % self.R
                     self.ring[ws][nb + post] += im["syn_weight"][s0 + k]
                     self.valid[ws][nb + post] = True
+        # ---- taps_kernel ----
+        for i in range(int(im.get("n_taps", 0))):
+            taps, g = int(im["tap_count"][i]), int(im["tap_slot"][i])
+            v, tc, sc = self.tap_v[i].copy(), im["tap_tc"][i * 8:i * 8 + 8], im["tap_sc"][i * 8:i * 8 + 8]
+            nv = np.zeros(8)
+            for k in range(taps):
+                nv[k] = v[k] * tc[k]
+            for s_ in range(taps):
+                if s_ > 0:
+                    c_ = v[s_] * sc[s_ - 1]
+                    nv[s_ - 1] += c_
+                    nv[s_] -= c_
+                if s_ + 1 < taps:
+                    c_ = v[s_] * sc[s_]
+                    nv[s_ + 1] += c_
+                    nv[s_] -= c_
+            for k in range(taps):
+                self.tap_v[i][k] = nv[k] + self.tap_in[i][k]
+                self.tap_in[i][k] = 0.0
+            if self.arrived[g]:
+                self.arrived[g] = False
+                ws = (t + 1) % self.R
+                self.ring[ws][g] = self.tap_v[i][0]
+                self.valid[ws][g] = True
         tot["sim_time"] = float(max(proc.max(), gen.max()) + im["sync_delay"])
         self.t = t
         return tot

@@ -218,6 +218,63 @@ def stochastic_truenorth(S, n_tiles=6, neurons_per_core=64, seed=2):
     return arch, net
 
 
+def taps_dendrites(S, n=24, n_in=10, seed=3):
+    """`taps` dendrites (MultiTapModel1D) in the style of arch/demo_with_dendrites.yaml + snn/dendrite.yaml: one
+    dendrite unit per neuron, 1..5 taps with their own time/space constants, synapses that name their tap, inputs
+    that spike from trains, recurrent edges between the dendritic neurons."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    arch = D.Architecture("dendrite", 2, 1, 4)
+    for t in range(2):
+        tile = arch.create_tile("tile[%d]" % t, energy_north_hop=2.0e-12, latency_north_hop=1.4e-9, energy_east_hop=2.5e-12,
+                                latency_east_hop=1.2e-9, energy_south_hop=2.0e-12, latency_south_hop=1.5e-9,
+                                energy_west_hop=1.8e-12, latency_west_hop=2.0e-9)
+        core = arch.create_core("core[0]", tile.id, "soma", False, 100)
+        core.create_axon_in("axon_in", 0.0, 0.0)
+        core.create_synapse("synapse", "current_based", {"energy_process_spike": 20.0e-12, "latency_process_spike": 3.0e-9})
+        for i in range(n):
+            core.create_dendrite("dendrite[%d]" % i, "taps", {"energy_update": 0.0, "latency_update": 0.0})
+        core.create_dendrite("plain", "accumulator", {"energy_update": 0.0, "latency_update": 0.0})
+        core.create_soma("soma", "leaky_integrate_fire",
+                         {"energy_access_neuron": 20.0e-12, "latency_access_neuron": 3.0e-9, "energy_update_neuron": 10.0e-12,
+                          "latency_update_neuron": 1.0e-9, "energy_spike_out": 60.0e-12, "latency_spike_out": 30.0e-9})
+        for i in range(n_in):
+            core.create_soma("dummy_input[%d]" % i, "input",
+                             {"energy_access_neuron": 0.0, "latency_access_neuron": 0.0, "energy_update_neuron": 0.0,
+                              "latency_update_neuron": 0.0, "energy_spike_out": 0.0, "latency_spike_out": 0.0})
+        core.create_axon_out("axon_out", 100.0e-12, 5.0e-9)
+    cores = arch.cores()
+    net = D.Network("dendrites")
+    gin = net.create_neuron_group("inputs", n_in, {}, "synapse", "plain", False, True)
+    for i in range(n_in):
+        train = [float(x) for x in (rng.random(40) < 0.35)]
+        gin.apply_config(i, i + 1, soma_hw_name="dummy_input[%d]" % i,
+                         attrs={"spikes": ((D.ATTR_LIST, 0.0, None, train), D.FWD_ALL)})
+    g = net.create_neuron_group("dendrite", n, {"threshold": 12, "reset": 0, "leak_decay": 0.9}, "synapse", "", True, True,
+                                "soma")
+    taps = rng.integers(1, 6, size=n)
+    for i in range(n):
+        k = int(taps[i])
+        attrs = {"taps": ((D.ATTR_INT, float(k), None, None), D.FWD_ALL),
+                 "time_constants": ((D.ATTR_LIST, 0.0, None, [float(x) for x in rng.choice([0.5, 0.75, 0.875], size=k)]), D.FWD_ALL),
+                 "space_constants": ((D.ATTR_LIST, 0.0, None, [float(x) for x in rng.choice([0.125, 0.25], size=max(k - 1, 0))]),
+                                     D.FWD_ALL)}
+        g.apply_config(i, i + 1, dendrite_hw_name="dendrite[%d]" % (i % (n // 2)), attrs=attrs)
+    # inputs -> dendritic neurons, each synapse naming a tap of its target
+    pairs = np.stack([rng.integers(0, n_in, size=90), rng.integers(0, n, size=90)], axis=1)
+    gin.connect_neurons_sparse(g, {"weight": rng.integers(2, 9, size=90).astype(np.float64),
+                                   "tap": [int(rng.integers(0, taps[d])) for d in pairs[:, 1]]}, pairs, narrow_float=False)
+    pairs = np.stack([rng.integers(0, n, size=60), rng.integers(0, n, size=60)], axis=1)
+    g.connect_neurons_sparse(g, {"weight": rng.integers(1, 5, size=60).astype(np.float64),
+                                 "tap": [int(rng.integers(0, taps[d])) for d in pairs[:, 1]]}, pairs, narrow_float=False)
+    half = n // 2
+    g.map_to_core(cores[0], 0, half)
+    g.map_to_core(cores[1], half, n)
+    gin.map_to_core(cores[0], 0, n_in // 2)
+    gin.map_to_core(cores[1], n_in // 2, n_in)
+    return arch, net
+
+
 def hh_plugin_path():
     return os.path.join(os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0], "sana-fe_amd", "plugins",
                         "libhodgkin_huxley.so")

@@ -217,6 +217,20 @@ def test_random_configurations(S, seed, monkeypatch):
         assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-9, atol=1e-12)
 
 
+def test_taps_dendrites(S):
+    """Row a21 on the GPU: `taps` dendrites -- per-tap charge through the delivery rows, the RC line advanced by
+    taps_kernel, tap 0 handed to the soma through the time-step buffer."""
+    arch, net = nets.taps_dendrites(S)
+    chip, orc, tot = check_batched(S, arch, net, steps=45)
+    assert tot["neurons_fired"] > 300
+    chip.reset()
+    orc.reset()
+    for t in range(5):
+        a, b = chip.run(1, "simple"), orc.step("simple")
+        assert a["neurons_fired"] == b["neurons_fired"]
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

@@ -73,6 +73,11 @@ def test_delay_line_behind_the_time_step_buffer(S):
     compare(S, arch, net, steps=40)
 
 
+def test_taps_dendrites(S):
+    """Row a21: MultiTapModel1D dendrites (one unit per neuron), synapses naming their tap."""
+    compare(S, *nets.taps_dendrites(S), steps=45, exact_v=False)
+
+
 def test_truenorth(S):
     compare(S, *nets.truenorth_net(S, n_tiles=6, neurons_per_core=32), steps=25)
 
