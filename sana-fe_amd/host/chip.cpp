@@ -98,7 +98,8 @@ private:
 struct ExtStreams
 {
     const MappedChip *mc{nullptr};
-    std::vector<std::mt19937> poisson_gen; // per Poisson column (src/models.hpp:366-374)
+    std::vector<std::mt19937> poisson_gen; // per input unit instance (src/models.hpp:366-374)
+    std::vector<size_t> poisson_col_gen;   // per Poisson column: its unit's generator
     std::uniform_real_distribution<double> uni{0.0, 1.0};
     GlibcRand rand;
     std::vector<std::vector<int>> noise_values; // per stream: the file's entries
@@ -107,8 +108,17 @@ struct ExtStreams
     void init(const MappedChip &m)
     {
         mc = &m;
+        std::map<uint32_t, size_t> gen_of_unit; // one generator per input unit instance
         for (const MappedChip::ExtColumn &c : m.ext)
-            if (c.kind == MappedChip::ExtColumn::Poisson) poisson_gen.emplace_back(c.seed);
+            if (c.kind == MappedChip::ExtColumn::Poisson)
+            {
+                if (!gen_of_unit.count(c.gen))
+                {
+                    gen_of_unit[c.gen] = poisson_gen.size();
+                    poisson_gen.emplace_back(c.seed);
+                }
+                poisson_col_gen.push_back(gen_of_unit[c.gen]);
+            }
         for (const MappedChip::NoiseStream &ns : m.noise_streams)
         {
             // LoihiLifModel::set_attribute_hw "noise", src/models.cpp:354-366
@@ -146,7 +156,7 @@ struct ExtStreams
             const MappedChip::ExtColumn &c = mc->ext[k];
             if (c.kind == MappedChip::ExtColumn::Poisson)
             {
-                row[k] = (c.poisson > uni(poisson_gen[pg++])) ? 1 : 0;
+                row[k] = (c.poisson > uni(poisson_gen[poisson_col_gen[pg++]])) ? 1 : 0;
             }
             else if (c.kind == MappedChip::ExtColumn::TrueNorthRand)
             {
@@ -244,6 +254,9 @@ struct sanafe_chip
     int set_input_attribute(uint32_t ls, const std::string &key, int type, double num, const double *list, int64_t n_list)
     {
         const uint32_t a = mc.slot_aux[ls];
+        if (a < mc.in_shared.size() && mc.in_shared[a])
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: attributes of neurons that share one `input` unit cannot change after "
+                                                    "load() on the MI355X backend (the unit's train is interleaved over them)");
         if (input_rewind.size() != mc.in_train_beg.size()) input_rewind.assign(mc.in_train_beg.size(), 0);
         if (key == "spikes")
         {

@@ -893,13 +893,20 @@ void parse_edge(SpikingNetwork &net, const std::string &desc, const YamlNode &at
         if (so >= src.count) throw std::invalid_argument("Invalid source neuron id: " + sp);
         if (to >= dst.count) throw std::invalid_argument("Invalid target neuron id: " + tp);
         double w = 0.0;
-        int delay = -1;
+        int delay = -1, tap = -1;
         for (const auto &kv : ea)
         {
             AttrValue a;
             if (!typed_attr(*kv.second, a)) continue;
             if (kv.first == "w" || kv.first == "weight") w = a.num;
             else if (kv.first == "d" || kv.first == "delay") delay = static_cast<int>(a.num);
+            else if (kv.first == "tap") tap = static_cast<int>(a.num);
+        }
+        if (tap >= 0) // include/sanafe_desc.h: the edge's dendrite attribute is a delay, or 64 + a tap index
+        {
+            if (delay >= 0) throw std::invalid_argument("an edge with both `delay` and `tap` is not supported");
+            if (tap > 63) throw std::invalid_argument("tap index out of range");
+            delay = 64 + tap;
         }
         net.add_edge(src.base + so, dst.base + to, w, delay, dst.synapse_hw[to]);
         return;
@@ -932,6 +939,12 @@ void parse_edge(SpikingNetwork &net, const std::string &desc, const YamlNode &at
         {
             const std::vector<double> dl = number_list(*kv.second, k);
             delay.assign(dl.begin(), dl.end());
+        }
+        else if (k == "tap")
+        {
+            const std::vector<double> tl = number_list(*kv.second, k);
+            if (!delay.empty()) throw std::invalid_argument("edges with both `delay` and `tap` are not supported");
+            for (double t : tl) delay.push_back(64 + static_cast<int>(t));
         }
         else
         {

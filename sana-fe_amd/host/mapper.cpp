@@ -196,8 +196,8 @@ Template read_template(const sanafe_desc &d, int tm)
         else if (model == "current_based") ui.model = M_CURRENT_BASED, want_syn = true;
         else if (model == "accumulator") ui.model = M_ACCUMULATOR, want_dend = true, ui.capacity = 1024;
         else if (model == "accumulator_with_delay") ui.model = M_ACC_DELAY, want_dend = true, ui.capacity = 1024;
-        else if (model == "taps") ui.model = M_TAPS, want_dend = true, ui.capacity = 1;
-        else if (model == "input") ui.model = M_INPUT, want_soma = true, ui.capacity = 1;
+        else if (model == "taps") ui.model = M_TAPS, want_dend = true; // one RC line per unit; see shared_taps in map_and_lower
+        else if (model == "input") ui.model = M_INPUT, want_soma = true; // no bound: neurons on one unit SHARE its state
         else if (model == "leaky_integrate_fire") ui.model = M_LIF, want_soma = true, ui.capacity = 1024;
         else if (model == "truenorth") ui.model = M_TRUENORTH, want_soma = true, ui.capacity = 4096;
         else throw std::invalid_argument("Pipeline model not supported (" + model + ")\n"); // src/models.cpp:964-966
@@ -644,6 +644,91 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     int32_t random_mask_key = -1;
     for (int32_t k = 0; k < d.n_strings; k++)
         if (std::strcmp(d.strings[k], "random_mask") == 0) random_mask_key = k;
+    // An `input` unit keeps ONE spike train, cursor, rate and generator (src/models.hpp:344-378), and nothing stops a
+    // network from putting several neurons on it (snn/dendrite.yaml does): they then share that state -- every
+    // neuron's attributes overwrite the unit's in mapping order, and at run time each update consumes the next
+    // train element / Poisson draw.  With k neurons on the unit, the j-th in update order therefore sees elements
+    // j, j+k, j+2k, ... of the final train.
+    struct SharedInput
+    {
+        std::vector<double> train;
+        double rate{0.0}, poisson{0.0};
+        std::vector<int64_t> members; // in update (= mapping) order
+        uint32_t gen{0};
+    };
+    std::map<std::pair<int32_t, int>, SharedInput> shared_inputs;
+    for (int64_t gid : order)
+    {
+        const int32_t c = d.neuron_core[gid];
+        const Template &t = tmpl_of(c);
+        if (t.units[soma_unit[gid]].model != M_INPUT) continue;
+        SharedInput &sh = shared_inputs[{c, soma_unit[gid]}];
+        sh.members.push_back(gid);
+        for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+        {
+            const Attr a{&d.neuron_attrs, i, &d};
+            if (!(a.fwd() & SANAFE_FWD_SOMA)) continue;
+            const std::string k = a.key();
+            if (k == "spikes")
+            {
+                if (a.type() != SANAFE_ATTR_LIST) throw std::runtime_error("Error: Attribute spikes is not a list");
+                sh.train.assign(d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i], d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i + 1]);
+            }
+            else if (k == "poisson") sh.poisson = a.as_double();
+            else if (k == "rate") sh.rate = a.as_double();
+        }
+    }
+    {
+        uint32_t next_gen = 0;
+        for (auto &kv : shared_inputs) kv.second.gen = next_gen++;
+    }
+    // A `taps` unit is ONE RC line (src/models.hpp:104-156), whatever is mapped to it (snn/dendrite.yaml leaves its
+    // input neurons on the default dendrite unit, the same line as its dendritic neuron).  Its configuration is what
+    // all mapped neurons' attributes leave behind, applied in mapping order (MultiTapModel1D::set_attribute_neuron,
+    // src/models.cpp:263-329).  At most one of those neurons may receive synapses (checked with the edges):
+    // the others never touch the line, so giving each neuron a private copy is unobservable.
+    struct SharedTaps
+    {
+        std::vector<double> v{0.0}, tc{0.0}, space;
+    };
+    std::map<std::pair<int32_t, int>, SharedTaps> shared_taps;
+    for (int64_t gid : order)
+    {
+        const int32_t c = d.neuron_core[gid];
+        const Template &t = tmpl_of(c);
+        if (t.units[dend_unit[gid]].model != M_TAPS) continue;
+        SharedTaps &sh = shared_taps[{c, dend_unit[gid]}];
+        for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+        {
+            const Attr a{&d.neuron_attrs, i, &d};
+            if (!(a.fwd() & SANAFE_FWD_DENDRITE)) continue;
+            const std::string k = a.key();
+            auto list_of = [&]() {
+                if (a.type() != SANAFE_ATTR_LIST) throw std::runtime_error("Error: Attribute " + k + " is not a list");
+                return std::vector<double>(d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i], d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i + 1]);
+            };
+            if (k == "taps")
+            {
+                const size_t n_taps = static_cast<size_t>(a.as_int());
+                if (n_taps == 0) throw std::invalid_argument("Number of taps must be > 0\n");
+                sh.v.resize(n_taps);
+                sh.tc.resize(n_taps);
+                sh.space.resize(n_taps - 1);
+            }
+            else if (k == "time_constants")
+            {
+                sh.tc = list_of();
+                if (sh.tc.size() < sh.v.size())
+                    throw std::invalid_argument("Expected " + std::to_string(sh.v.size()) + " but received " + std::to_string(sh.tc.size()) + "time constants.");
+            }
+            else if (k == "space_constants")
+            {
+                sh.space = list_of();
+                if (sh.space.size() < sh.v.size() - 1)
+                    throw std::invalid_argument("Expected " + std::to_string(sh.v.size() - 1) + " but received " + std::to_string(sh.tc.size()) + "time constants.");
+            }
+        }
+    }
     std::vector<uint32_t> rand_slots; // global slots of all TrueNorth neurons with random_mask != 0
     std::map<std::pair<int32_t, int>, uint32_t> noise_stream_ids; // (core, unit) -> stream
     for (int64_t gid = 0; gid < N; gid++)
@@ -728,40 +813,12 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         else if (su.model == M_TRUENORTH) model = SANAFE_SOMA_TRUENORTH, p.leak_decay = 0.0;
         else if (su.model == M_INPUT) model = SANAFE_SOMA_INPUT;
         else model = SANAFE_SOMA_HOST;
-        if (du.model == M_TAPS)
+        // (an `input` soma never asks its dendrite for anything: such a neuron merely sits on the unit)
+        if (du.model == M_TAPS && model == SANAFE_SOMA_INPUT) kind = SANAFE_IN_BUFFERED;
+        if (du.model == M_TAPS && model != SANAFE_SOMA_INPUT)
         {
-            // MultiTapModel1D::set_attribute_neuron in attribute (key) order, src/models.cpp:263-329
-            std::vector<double> v(1, 0.0), tc(1, 0.0), space;
-            for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
-            {
-                const Attr a{&d.neuron_attrs, i, &d};
-                if (!(a.fwd() & SANAFE_FWD_DENDRITE)) continue;
-                const std::string k = a.key();
-                auto list_of = [&]() {
-                    if (a.type() != SANAFE_ATTR_LIST) throw std::runtime_error("Error: Attribute " + k + " is not a list");
-                    return std::vector<double>(d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i], d.neuron_attrs.list_num + d.neuron_attrs.list_ptr[i + 1]);
-                };
-                if (k == "taps")
-                {
-                    const size_t n_taps = static_cast<size_t>(a.as_int());
-                    if (n_taps == 0) throw std::invalid_argument("Number of taps must be > 0\n");
-                    v.resize(n_taps);
-                    tc.resize(n_taps);
-                    space.resize(n_taps - 1);
-                }
-                else if (k == "time_constants")
-                {
-                    tc = list_of();
-                    if (tc.size() < v.size())
-                        throw std::invalid_argument("Expected " + std::to_string(v.size()) + " but received " + std::to_string(tc.size()) + "time constants.");
-                }
-                else if (k == "space_constants")
-                {
-                    space = list_of();
-                    if (space.size() < v.size() - 1)
-                        throw std::invalid_argument("Expected " + std::to_string(v.size() - 1) + " but received " + std::to_string(tc.size()) + "time constants.");
-                }
-            }
+            const SharedTaps &sh = shared_taps.at({c, dend_unit[gid]});
+            const std::vector<double> &v = sh.v, &tc = sh.tc, &space = sh.space;
             if (v.size() > 8) throw UnsupportedError("`taps` dendrites with more than 8 taps are not implemented on the MI355X backend");
             taps_index[gid] = static_cast<int32_t>(mc.tap_slot.size());
             mc.tap_slot.push_back(ls);
@@ -840,6 +897,13 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         }
         else if (model == SANAFE_SOMA_INPUT)
         {
+            const SharedInput &sh = shared_inputs.at({c, soma_unit[gid]});
+            const size_t k_members = sh.members.size();
+            const size_t j_member = static_cast<size_t>(std::find(sh.members.begin(), sh.members.end(), gid) - sh.members.begin());
+            train.clear();
+            for (size_t b = j_member; b < sh.train.size(); b += k_members) train.push_back(sh.train[b]);
+            rate = sh.rate;
+            poisson = sh.poisson;
             if (poisson > 0.0) // the draw happens at every update; it can only matter when p > 0
             {
                 MappedChip::ExtColumn col;
@@ -847,6 +911,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 col.kind = MappedChip::ExtColumn::Poisson;
                 col.poisson = poisson;
                 col.seed = core_input_base[c] + static_cast<uint32_t>(su.input_rank) + 1u;
+                col.gen = sh.gen; // the unit's generator: its neurons draw from it one after the other
                 mc.ext.push_back(col);
             }
             mc.slot_aux[ls] = static_cast<uint32_t>(mc.in_train_beg.size());
@@ -863,6 +928,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 if (period == 0) throw std::invalid_argument("input rate > 1 makes the reference divide by zero (SURVEY quirk 14)");
             }
             mc.in_rate_period.push_back(period);
+            mc.in_shared.push_back(k_members > 1 ? 1 : 0);
         }
         else
         {
@@ -906,11 +972,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             pcls = it->second;
         }
         mc.slot_cls[ls] = model | (static_cast<uint32_t>(kind) << 3) | (cit->second << 6) | (pcls << 16);
-        if (du.model == M_TAPS)
-        {
-            if (model == SANAFE_SOMA_INPUT) throw UnsupportedError("an input soma behind a `taps` dendrite");
-            mc.slot_aux[ls] = static_cast<uint32_t>(taps_index[gid]);
-        }
+        if (du.model == M_TAPS && model != SANAFE_SOMA_INPUT) mc.slot_aux[ls] = static_cast<uint32_t>(taps_index[gid]);
         mc.slot_model[ls] = static_cast<uint8_t>(model);
         mc.slot_log_spikes[ls] = d.neuron_log_spikes[gid];
         mc.slot_log_potential[ls] = d.neuron_log_potential[gid];
@@ -976,7 +1038,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             edge_syn_unit[e] = su;
         }
     });
-    if (d.edge_delay && (any_delay_dendrite || any_taps))
+    if ((d.edge_delay && any_delay_dendrite) || any_taps)
     {
         // The delay dendrite stores delays[] indexed by the SYNAPSE unit's address of the
         // connection (src/mapped.cpp:60-89, src/models.cpp:133-152): connections that reach the
@@ -996,6 +1058,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         std::map<std::pair<uint32_t, int>, uint64_t> syn_count;            // (core, synapse unit) -> next address
         std::map<std::pair<uint32_t, int>, std::vector<uint8_t>> delays;   // (core, dendrite unit) -> delays[]
         std::vector<uint64_t> syn_addr(E);
+        std::map<std::pair<uint32_t, int>, int64_t> taps_owner; // (core, taps unit) -> the neuron that receives synapses
         for (int64_t pos = 0; pos < E; pos++)
         {
             const uint64_t e = eo[pos];
@@ -1003,22 +1066,33 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const uint32_t c = d.neuron_core[dst];
             const uint64_t addr = syn_count[{c, edge_syn_unit[e]}]++;
             syn_addr[e] = addr;
+            const int edge_attr = d.edge_delay ? d.edge_delay[e] : -1;
+            if (neuron_dend_kind[dst] == 3)
+            {
+                auto it = taps_owner.emplace(std::make_pair(c, dend_unit[dst]), dst).first;
+                const bool local_dst = mc.slot_of_gid[dst] >= SO && mc.slot_of_gid[dst] < SO + LS;
+                if (local_dst && taps_index[dst] < 0)
+                    throw UnsupportedError("synapses into an input neuron that sits on a `taps` dendrite unit");
+                if (it->second != dst)
+                    throw UnsupportedError("several neurons receive synapses through one `taps` dendrite unit (they would share its RC "
+                                           "line): not implemented on the MI355X backend");
+            }
             if (neuron_dend_kind[dst] == 2)
             {
                 auto &tab = delays[{c, dend_unit[dst]}];
                 if (tab.size() <= addr) tab.resize(addr + 1, 0); // every forwarded attribute resizes (weight included)
-                if (d.edge_delay[e] >= 0 && d.edge_delay[e] < 64) // (a `tap` attribute means nothing to this unit)
+                if (edge_attr >= 0 && edge_attr < 64) // (a `tap` attribute means nothing to this unit)
                 {
-                    if (d.edge_delay[e] > 5) throw std::runtime_error("Error: delay > max delay\n");
-                    tab[addr] = static_cast<uint8_t>(d.edge_delay[e]);
+                    if (edge_attr > 5) throw std::runtime_error("Error: delay > max delay\n");
+                    tab[addr] = static_cast<uint8_t>(edge_attr);
                 }
             }
-            else if (neuron_dend_kind[dst] == 3 && d.edge_delay[e] >= 64)
+            else if (neuron_dend_kind[dst] == 3 && edge_attr >= 64)
             {
                 // MultiTapModel1D::set_attribute_edge "tap": synapse_to_tap[address], src/models.cpp:330-342
                 auto &tab = delays[{c, dend_unit[dst]}];
                 if (tab.size() <= addr) tab.resize(addr + 1, 0);
-                tab[addr] = static_cast<uint8_t>(d.edge_delay[e] - 64);
+                tab[addr] = static_cast<uint8_t>(edge_attr - 64);
             }
         }
         edge_delay_eff.assign(E, 0);

@@ -85,6 +85,7 @@ struct MappedChip
     std::vector<double> slot_bias, slot_v0, slot_e_net, slot_e_syn, slot_e_dend;
     std::vector<uint32_t> in_train_beg, in_train_len, in_train_bits;
     std::vector<int64_t> in_rate_period;
+    std::vector<uint8_t> in_shared;    // per input neuron: its `input` unit instance holds other neurons too
     // ---- external per-step value streams (include/sanafe_hip.h: slot_ext, sanafe_hip_write_ext) ----
     // One column per neuron that consumes a sequential host-side source at every update.
     struct ExtColumn
@@ -94,6 +95,7 @@ struct MappedChip
         uint8_t kind{0};
         double poisson{0.0};       // InputModel::poisson_probability
         uint32_t seed{0};          // std::mt19937 seed of the unit instance (src/models.hpp:347)
+        uint32_t gen{0};           // which unit instance (neurons sharing an input unit share its generator)
         uint32_t mask{0};          // TrueNorth random_range_mask
         uint64_t rand_index{0};    // position of the neuron among ALL rand()-consuming neurons of the chip
         uint32_t stream{0};        // LIF noise: index into noise_streams

@@ -79,9 +79,14 @@ void edge_lists(const py::dict &attributes, std::vector<double> &weight, std::ve
             delay.clear();
             for (const py::handle &e : kv.second) delay.push_back(static_cast<int>(py_to_attr(e, true).num));
         }
+        else if (k == "tap") // include/sanafe_desc.h: the edge's dendrite attribute is a delay, or 64 + a tap index
+        {
+            delay.clear();
+            for (const py::handle &e : kv.second) delay.push_back(64 + static_cast<int>(py_to_attr(e, true).num));
+        }
         else
         {
-            throw std::invalid_argument("edge attributes other than weight/delay are not supported: " + k);
+            throw std::invalid_argument("edge attributes other than weight/delay/tap are not supported: " + k);
         }
     }
 }
@@ -228,7 +233,8 @@ PYBIND11_MODULE(sanafecpp_amd, m)
                                 const std::string k = kv.first.cast<std::string>();
                                 if (k == "w" || k == "weight") w = py_to_attr(kv.second, true).num;
                                 else if (k == "d" || k == "delay") delay = static_cast<int>(py_to_attr(kv.second, true).num);
-                                else throw std::invalid_argument("edge attributes other than weight/delay are not supported: " + k);
+                                else if (k == "tap") delay = 64 + static_cast<int>(py_to_attr(kv.second, true).num);
+                                else throw std::invalid_argument("edge attributes other than weight/delay/tap are not supported: " + k);
                             }
                         SpikingNetwork &net = *r.group->net;
                         net.add_edge(r.group->base + r.offset, dest.group->base + dest.offset, w, delay, dest.group->synapse_hw[dest.offset]);

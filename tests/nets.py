@@ -275,6 +275,37 @@ def taps_dendrites(S, n=24, n_in=10, seed=3):
     return arch, net
 
 
+def shared_input_units(S, seed=8):
+    """Several neurons on ONE `input` unit share its spike train, cursor and Poisson generator (as the three inputs of
+    snn/dendrite.yaml do on `dummy_input`): every update consumes the next element / draw."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    arch = S.presets.loihi(n_inputs=4, api=S.description)
+    cores = arch.cores()
+    net = D.Network("shared_inputs")
+    gin = net.create_neuron_group("in", 9, {}, "loihi_sparse_synapse", "loihi_dendrites", False, True)
+    unit_of = [0, 0, 0, 1, 1, 2, 0, 0, 3]      # per neuron: loihi_inputs[k] of its core
+    core_of = [0, 0, 0, 0, 0, 0, 1, 1, 1]
+    for i in range(9):
+        attrs = {}
+        if i in (0, 2, 4, 6):
+            attrs["spikes"] = ((D.ATTR_LIST, 0.0, None, [float(x) for x in (rng.random(40) < 0.5)]), D.FWD_ALL)
+        if i in (1, 7):
+            attrs["poisson"] = ((D.ATTR_DOUBLE, 0.25 + 0.25 * (i == 7), None, None), D.FWD_ALL)
+        if i == 3:
+            attrs["rate"] = ((D.ATTR_DOUBLE, 0.25, None, None), D.FWD_ALL)
+        gin.apply_config(i, i + 1, soma_hw_name="loihi_inputs[%d]" % unit_of[i], attrs=attrs)
+    g = net.create_neuron_group("lif", 40, {"threshold": 30, "reset": 0, "leak_decay": 0.875}, "loihi_sparse_synapse",
+                                "loihi_dendrites", False, True, "loihi_lif")
+    pairs = np.stack([rng.integers(0, 9, size=200), rng.integers(0, 40, size=200)], axis=1)
+    gin.connect_neurons_sparse(g, {"weight": rng.integers(1, 12, size=200).astype(np.float64)}, pairs, narrow_float=False)
+    # mapping order decides both whose attributes the unit keeps and the update order
+    for i in (2, 0, 1, 4, 3, 5, 8, 6, 7):
+        gin.map_to_core(cores[core_of[i]], i, i + 1)
+    g.map_to_core(cores[2], 0, 40)
+    return arch, net
+
+
 def hh_plugin_path():
     return os.path.join(os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0], "sana-fe_amd", "plugins",
                         "libhodgkin_huxley.so")

@@ -231,6 +231,10 @@ def test_taps_dendrites(S):
         assert np.array_equal(chip.potentials(), orc.potentials()), t
 
 
+def test_neurons_sharing_an_input_unit(S):
+    check_batched(S, *nets.shared_input_units(S), steps=60)
+
+
 def test_plain_accumulator_inside_dendrite_quirk(S):
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=12, arch_kind="large")
     for g in net._order:

@@ -78,6 +78,39 @@ def test_taps_dendrites(S):
     compare(S, *nets.taps_dendrites(S), steps=45, exact_v=False)
 
 
+def test_neurons_sharing_an_input_unit(S):
+    compare(S, *nets.shared_input_units(S), steps=60, ext=True)
+
+
+@pytest.mark.parametrize("api", ["cpp", "twin"])
+def test_reference_dendrite_demo(S, api):
+    """arch/demo_with_dendrites.yaml + snn/dendrite.yaml, read from the reference tree when it is there: `taps`
+    dendrite, synapses naming taps, three input neurons left on one `input` unit and on the default dendrite unit."""
+    import os
+    ref = "/root/reference"
+    if not os.path.exists(os.path.join(ref, "snn", "dendrite.yaml")):
+        pytest.skip("reference tree not present")
+    if api == "cpp":
+        arch = S.load_arch(os.path.join(ref, "arch", "demo_with_dendrites.yaml"))
+        net = S.load_net(os.path.join(ref, "snn", "dendrite.yaml"), arch)
+        desc = S.cpp.to_desc(arch, net)
+    else:
+        arch = S.yaml_io.load_arch(os.path.join(ref, "arch", "demo_with_dendrites.yaml"))
+        net = S.yaml_io.load_net(os.path.join(ref, "snn", "dendrite.yaml"), arch)
+        desc = S.to_desc(arch, net)
+    im, slot_of = S.map_only(arch, net)
+    assert im["n_taps"] == 1 and im["tap_count"][0] == 3
+    emu, orc = ImageEmulator(im), OracleChip(desc)
+    fired = 0
+    for t in range(20):
+        a, b = emu.step(), orc.step("simple")
+        fired += b["neurons_fired"]
+        assert a["neurons_fired"] == b["neurons_fired"], t
+        assert np.array_equal(emu.status[slot_of], orc.status()), t
+        assert np.array_equal(emu.v[slot_of], orc.potentials()), t
+    assert fired == 1 and orc.potentials().max() == 10.0  # the shared train [1, 0] reaches input 0 at step 1
+
+
 def test_truenorth(S):
     compare(S, *nets.truenorth_net(S, n_tiles=6, neurons_per_core=32), steps=25)
 
