@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         // per-slot arrays), so the class-table lookups overlap with them instead of preceding them
         const uint32_t cls_raw = im.slot_cls[g];
         const uint8_t in_valid = rvalid[g];
-        const double in_value = ring[g];
+        const double in_value = (in_valid != 0) ? ring[g] : 0.0; // (8 bytes per neuron saved when nothing arrived)
         const double bias = im.slot_bias[g];
         const double v_in = st.v[g];
         uint32_t cls = live ? cls_raw : 0u;
@@ -535,7 +535,7 @@ extern __shared__ __align__(16) unsigned char deliver_lds[];
 // instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
 // (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
 template <int SYN_FMT, bool HAS_DELAY, bool LAST>
-__global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, SANAFE_DELIVER_WAVES_PER_EU)))
+__global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
