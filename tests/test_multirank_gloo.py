@@ -10,9 +10,19 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS = 12
+# (arch kind, synaptic delays, dendrite unit): delay line inside the dendrite unit; last-event buffer before the
+# dendrite unit; gated delay line behind the buffer of arch/loihi.yaml
+CONFIGS = {"inside_delay": ("large", True, None), "before_dendrite": ("before_dendrite", False, None),
+           "gated_delay": ("loihi", True, "loihi_dendrites_delay")}
 
 
-def _worker(rank, world, port, out):
+def _network(S, nets, config):
+    kind, delays, dendrite = CONFIGS[config]
+    return nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=20, arch_kind=kind, delays=delays, seed=9,
+                             dendrite=dendrite)
+
+
+def _worker(rank, world, port, out, config):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch
@@ -24,7 +34,7 @@ def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=20, arch_kind="large", delays=True, seed=9)
+    arch, net = _network(S, nets, config)
     im, slot_of = S.map_only(arch, net, n_ranks=world, rank=rank)
     emu = ImageEmulator(im)
     n_local, n_global, off = im["n_slots"], im["n_global_slots"], im["slot_offset"]
@@ -52,15 +62,16 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_ranks_match_oracle(S, tmp_path):
+@pytest.mark.parametrize("config", sorted(CONFIGS))
+def test_two_ranks_match_oracle(S, tmp_path, config):
     import nets
     from oracle.oracle import OracleChip
     out = str(tmp_path / "mr")
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * sorted(CONFIGS).index(config)
+    mp.spawn(_worker, args=(2, port, out, config), nprocs=2, join=True)
     rows = np.load(out + ".rows.npy")
     v = np.where(np.isnan(np.load(out + ".v0.npy")), np.load(out + ".v1.npy"), np.load(out + ".v0.npy"))
-    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=20, arch_kind="large", delays=True, seed=9)
+    arch, net = _network(S, nets, config)
     orc = OracleChip(S.to_desc(arch, net))
     for t in range(STEPS):
         b = orc.step("simple")
