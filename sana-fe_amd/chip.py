@@ -160,8 +160,14 @@ class MappedNeuronRef:
 
     def set_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None, log_spikes=None):
         """MappedNeuron::set_attributes (src/mapped.cpp:113-166): every attribute goes to the neuron's soma unit as at
-        load().  The built-in dendrites (accumulators) have no per-neuron attributes, so ``dendrite_attributes`` and the
-        dendrite copy of ``model_attributes`` change nothing, as in the reference."""
+        load().  The accumulator dendrites have no per-neuron attributes, so ``dendrite_attributes`` and the dendrite
+        copy of ``model_attributes`` change nothing there, as in the reference; the constants of a `taps` dendrite
+        cannot be changed after load() on this backend."""
+        frozen = {"taps", "time_constants", "space_constants"}
+        hit = frozen & (set(model_attributes or {}) | set(dendrite_attributes or {}))
+        if hit:
+            raise NotImplementedError("`taps` dendrite attributes cannot change after load() on the MI355X backend: %s"
+                                      % sorted(hit))
         attrs = dict(model_attributes or {})
         attrs.update(soma_attributes or {})
         for key, value in attrs.items():
