@@ -3,6 +3,8 @@
 Integer outputs (statuses, spike lists, counters, message ids/hops) are compared exactly;
 potentials bit-for-bit where weights are integers (all reference configs) and within 1e-9
 relative otherwise; energies and simulated time within 1e-9 relative (north_star asks 1e-6)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -194,7 +196,16 @@ def _random_configuration(S, seed):
                              dendrite="loihi_dendrites_delay" if kind == "loihi_delay" else None)
 
 
-@pytest.mark.parametrize("seed", list(range(11, 27)))
+def _fuzz_seeds():
+    """16 seeds by default; SANAFE_FUZZ_SEEDS="lo:hi" widens the sweep for a one-off soak run."""
+    spec = os.environ.get("SANAFE_FUZZ_SEEDS")
+    if spec:
+        lo, hi = (int(x) for x in spec.split(":"))
+        return list(range(lo, hi))
+    return list(range(11, 27))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds())
 def test_random_configurations(S, seed, monkeypatch):
     if seed % 2:
         monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
