@@ -202,8 +202,9 @@ int sanafe_hip_chip_create(const sanafe_hip_image *image, int device, sanafe_hip
 void sanafe_hip_chip_destroy(sanafe_hip_chip *chip);
 
 /* Runs `n_steps` timesteps back to back on the chip's stream (asynchronous).
- * `record` != 0 keeps a per-step record (totals + spike bitmap) for
- * sanafe_hip_read_step_*; `simple_timing` != 0 evaluates the simple timing
+ * `record` bit 0 keeps a per-step record (totals + spike bitmap) for sanafe_hip_read_step_*, bit 1 additionally the
+ * NeuronStatus of every slot (sanafe_hip_read_step_status; what the host needs to rebuild a step's messages for the
+ * detailed timing model without a round trip per step); `simple_timing` != 0 evaluates the simple timing
  * model on the device (src/schedule.cpp:61-102). */
 int sanafe_hip_step(sanafe_hip_chip *chip, int64_t n_steps, int simple_timing, int record);
 /* Queues the external stream values of the next n_steps timesteps: values[step][column], int32:
@@ -242,6 +243,8 @@ int sanafe_hip_read_step_totals(sanafe_hip_chip *chip, int64_t first, int64_t co
 int sanafe_hip_read_step_spikes(sanafe_hip_chip *chip, int64_t index, uint32_t *bits_out);
 /* NeuronStatus (0..3) per local slot after the last step. */
 int sanafe_hip_read_status(sanafe_hip_chip *chip, uint8_t *out);
+/* NeuronStatus of recorded steps [first, first + count) of the last sanafe_hip_step(record & 2): out[count][n_slots] */
+int sanafe_hip_read_step_status(sanafe_hip_chip *chip, int64_t first, int64_t count, uint8_t *out);
 int sanafe_hip_read_potentials(sanafe_hip_chip *chip, double *out);
 int sanafe_hip_read_input_current(sanafe_hip_chip *chip, double *out); /* LIF `u` trace */
 /* Per-core sums of the last step: generation-delay sum and processing-delay sum. */

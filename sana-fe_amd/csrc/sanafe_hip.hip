@@ -646,6 +646,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     for (void *p : c->allocs) (void) hipFree(p);
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
+    if (c->st.status_log) (void) hipFree(c->st.status_log);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
                  (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
@@ -654,16 +655,24 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     delete c;
 }
 
-static int ensure_log(sanafe_hip_chip *c, long long steps)
+static int ensure_log(sanafe_hip_chip *c, long long steps, bool with_status)
 {
-    if (c->st.step_log && c->st.log_cap >= steps) return 0;
+    if (c->st.step_log && c->st.log_cap >= steps && (!with_status || c->st.status_log)) return 0;
     HIPCHK(hipStreamSynchronize(c->stream));
+    steps = std::max(steps, c->st.step_log ? c->st.log_cap : 1LL);
     if (c->st.step_log) HIPCHK(hipFree(c->st.step_log));
     if (c->st.spike_log) HIPCHK(hipFree(c->st.spike_log));
+    if (c->st.status_log) HIPCHK(hipFree(c->st.status_log));
     c->st.step_log = nullptr;
     c->st.spike_log = nullptr;
+    c->st.status_log = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.step_log), (size_t) steps * sizeof(sanafe_hip_totals)));
     HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.spike_log), (size_t) steps * (c->im.n_slots / 32) * sizeof(uint32_t)));
+    if (with_status)
+    {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.status_log), (size_t) steps * c->im.n_slots));
+        HIPCHK(hipMemset(c->st.status_log, 0, (size_t) steps * c->im.n_slots)); // padding slots stay 0
+    }
     c->st.log_cap = steps;
     return 0;
 }
@@ -742,7 +751,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     if (record)
     {
         TRY(flush_pending(c)); // an earlier step's record must not land in the resized log
-        TRY(ensure_log(c, n_steps));
+        TRY(ensure_log(c, n_steps, (record & 2) != 0));
         HIPCHK(hipMemsetAsync(c->st.rec, 0, sizeof(long long), c->stream));
     }
     if (!c->timing)
@@ -853,7 +862,7 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     if (record)
     {
         TRY(flush_pending(c));
-        TRY(ensure_log(c, 1));
+        TRY(ensure_log(c, 1, false));
     }
     if (!c->timing)
     {
@@ -957,6 +966,13 @@ extern "C" int sanafe_hip_read_step_spikes(sanafe_hip_chip *c, int64_t index, ui
     const size_t words = c->im.n_slots / 32;
     return d2h(c, bits_out, c->st.spike_log + (size_t) index * words, words);
 }
+extern "C" int sanafe_hip_read_step_status(sanafe_hip_chip *c, int64_t first, int64_t count, uint8_t *out)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.status_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "status records [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    return d2h(c, out, c->st.status_log + (size_t) first * c->im.n_slots, (size_t) count * c->im.n_slots);
+}
+
 extern "C" int sanafe_hip_read_status(sanafe_hip_chip *c, uint8_t *out)
 {
     if (!c || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");

@@ -98,6 +98,7 @@ struct DevState
     sanafe_hip_totals *run;       // run totals
     sanafe_hip_totals *step_log;  // [log_cap]
     uint32_t *spike_log;          // [log_cap][n_slots/32]
+    uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
 };
 
@@ -176,6 +177,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
     double *ring = st.ring + (size_t) rslot * im.n_slots;
     uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
     uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
+    uint8_t *stlog = (record & 2) ? st.status_log + (size_t) (rec % st.log_cap) * im.n_slots : nullptr;
 
     double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0, e_dspk = 0.0; // per lane
     long long n_pack = 0, n_hops = 0, n_ev = 0;                                         // per lane
@@ -360,6 +362,7 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
         // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
         if (live && model != SANAFE_SOMA_HOST) st.status[g] = (uint8_t) status;
+        if (stlog != nullptr && live) stlog[g] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
         // ---- default costing, src/pipeline.hpp:574-731.  Counters and class costs are taken per wavefront from
         //      ballots (no cross-lane reduction at the end); only what depends on the individual neuron -- the

@@ -6,6 +6,7 @@
 // (src/schedule.cpp:208-620), which is an inherently serial discrete-event simulation the
 // reference also runs on the CPU.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -948,11 +949,91 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                     if (th.joinable()) th.join();
             }
         } guard{pool, qmutex, qcv, done_submitting};
+        // one finished timestep: totals + the status of every slot -> records, or a job for the scheduler threads
+        auto process_step = [&](sanafe_hip_totals ts, const uint8_t *st_bytes) -> int {
+            chip->total_timesteps += 1;
+            ts.timesteps = chip->total_timesteps;
+            const int64_t mid_base = chip->total_messages_sent;
+            chip->total_messages_sent += ts.packets_sent;
+            std::vector<uint32_t> bits;
+            if (record)
+            {
+                bits.assign(mc.n_slots / 32, 0);
+                for (uint32_t k = 0; k < mc.n_slots; k++)
+                    if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
+            }
+            if (!detailed)
+            {
+                add_totals(run, ts);
+                if (record)
+                {
+                    chip->rec_totals.push_back(ts);
+                    chip->rec_messages.emplace_back();
+                    chip->rec_spike_bits.push_back(std::move(bits));
+                }
+                return 0;
+            }
+            // The NoC model of one timestep depends only on that timestep's messages (NocInfo is rebuilt per
+            // step, src/schedule.cpp:208-222), so timesteps are handed to scheduler threads like the
+            // reference's `-S n` does (src/schedule.cpp:182-206, 622-661) while the GPU simulates ahead.
+            jobs.emplace_back();
+            Job &job = jobs.back();
+            job.ts = ts;
+            job.mid_base = mid_base;
+            job.status.assign(st_bytes, st_bytes + mc.n_slots);
+            job.bits = std::move(bits);
+            if (pool.empty())
+            {
+                run_job(job);
+                if (!job.error.empty()) return fail(SANAFE_HIP_ERR_INVALID, job.error);
+            }
+            else
+            {
+                // the GPU runs far ahead of the schedulers: keep at most ~1k finished steps (with their status arrays)
+                // waiting, like the reference's bound on buffered timesteps (src/schedule.cpp:182-206)
+                for (;;)
+                {
+                    {
+                        std::lock_guard<std::mutex> lock(qmutex);
+                        if (ready.size() < 1024)
+                        {
+                            ready.push_back(&job);
+                            break;
+                        }
+                    }
+                    std::this_thread::sleep_for(std::chrono::microseconds(200));
+                }
+                qcv.notify_one();
+            }
+            return 0;
+        };
+        if (!host_units)
+        {
+            // `detailed` without plugin units: the device runs K steps back to back and logs every step's totals
+            // and slot statuses; the host fetches them in one go (no round trip per step) and rebuilds the messages.
+            const int64_t k_cap = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t{64} << 20) / std::max<uint32_t>(1, mc.n_slots)));
+            std::vector<sanafe_hip_totals> tsv;
+            std::vector<uint8_t> stv;
+            for (int64_t s = 0; s < timesteps;)
+            {
+                const int64_t k_steps = std::min(k_cap, timesteps - s);
+                if (int rc = chip->queue_ext(k_steps)) return rc;
+                DEV(sanafe_hip_step(chip->dev, k_steps, 0, 3));
+                DEV(sanafe_hip_synchronize(chip->dev));
+                tsv.resize(k_steps);
+                stv.resize(static_cast<size_t>(k_steps) * mc.n_slots);
+                DEV(sanafe_hip_read_step_totals(chip->dev, 0, k_steps, tsv.data()));
+                DEV(sanafe_hip_read_step_status(chip->dev, 0, k_steps, stv.data()));
+                for (int64_t k = 0; k < k_steps; k++)
+                    if (int rc = process_step(tsv[k], stv.data() + static_cast<size_t>(k) * mc.n_slots)) return rc;
+                s += k_steps;
+            }
+        }
+        else
         for (int64_t s = 0; s < timesteps; s++)
         {
             DEV(sanafe_hip_reset_totals(chip->dev));
             if (int rc = chip->queue_ext(1)) return rc;
-            if (host_units)
             {
                 const uint32_t n = static_cast<uint32_t>(chip->h_slots.size());
                 DEV(sanafe_hip_step_neurons(chip->dev));
@@ -969,57 +1050,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                         chip->h_energy.data(), chip->h_latency.data()));
                 DEV(sanafe_hip_step_deliver(chip->dev, detailed ? 0 : 1, 0));
             }
-            else
-            {
-                DEV(sanafe_hip_step(chip->dev, 1, 0, 0));
-            }
             sanafe_hip_totals ts{};
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
             DEV(sanafe_hip_read_status(chip->dev, status.data()));
-            chip->total_timesteps += 1;
-            ts.timesteps = chip->total_timesteps;
-            const int64_t mid_base = chip->total_messages_sent;
-            chip->total_messages_sent += ts.packets_sent;
-            std::vector<uint32_t> bits;
-            if (record)
-            {
-                bits.assign(mc.n_slots / 32, 0);
-                for (uint32_t k = 0; k < mc.n_slots; k++)
-                    if (status[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
-            }
-            if (!detailed)
-            {
-                add_totals(run, ts);
-                if (record)
-                {
-                    chip->rec_totals.push_back(ts);
-                    chip->rec_messages.emplace_back();
-                    chip->rec_spike_bits.push_back(std::move(bits));
-                }
-                continue;
-            }
-            // The NoC model of one timestep depends only on that timestep's messages (NocInfo is rebuilt per
-            // step, src/schedule.cpp:208-222), so timesteps are handed to scheduler threads like the
-            // reference's `-S n` does (src/schedule.cpp:182-206, 622-661) while the GPU simulates ahead.
-            jobs.emplace_back();
-            Job &job = jobs.back();
-            job.ts = ts;
-            job.mid_base = mid_base;
-            job.status = status;
-            job.bits = std::move(bits);
-            if (pool.empty())
-            {
-                run_job(job);
-                if (!job.error.empty()) return fail(SANAFE_HIP_ERR_INVALID, job.error);
-            }
-            else
-            {
-                {
-                    std::lock_guard<std::mutex> lock(qmutex);
-                    ready.push_back(&job);
-                }
-                qcv.notify_one();
-            }
+            if (int rc = process_step(ts, status.data())) return rc;
         }
         if (detailed)
         {
