@@ -459,6 +459,12 @@ struct sanafe_chip
             double next_delay = 0.0;
             const uint32_t base = mc.core_nbase[c];
             const uint32_t st = mc.core_tile[c];
+            {
+                size_t n_msgs = 1; // + the placeholder
+                for (uint32_t k = 0; k < mc.core_ncount[c]; k++)
+                    if (status[base + k] == 3) n_msgs += mc.out_ptr[base + k + 1] - mc.out_ptr[base + k];
+                per_core[c].reserve(n_msgs);
+            }
             const double lat_access = mc.core_axon_out_latency[c];
             int64_t last_gid = -1;
             for (uint32_t k = 0; k < mc.core_ncount[c]; k++)
@@ -584,7 +590,7 @@ struct sanafe_chip
     // order.  Here the in-flight messages sit in a min-heap on their received time; the ones due are popped,
     // put back into (destination core, arrival) order and retired -- the identical sequence of density and
     // rolling-average updates, so every timestamp is bit-identical (checked against the oracle, which keeps the scan).
-    double schedule_detailed(std::vector<std::vector<Msg>> &per_core) const
+    double schedule_detailed(std::vector<std::vector<Msg>> &per_core, bool keep_order) const
     {
         Noc noc;
         noc.w = mc.noc_width;
@@ -606,7 +612,7 @@ struct sanafe_chip
             bool operator()(const Pending &a, const Pending &b) const noexcept { return a.sent > b.sent; }
         };
         std::priority_queue<Pending, std::vector<Pending>, BySentHandle> pq;
-        std::deque<Msg> live; // messages taken off their source core's FIFO (stable addresses)
+        // messages are scheduled in place, in their source core's FIFO (the vectors do not move while this runs)
         struct InFlight
         {
             double received;
@@ -623,15 +629,14 @@ struct sanafe_chip
         for (uint32_t c = 0; c < mc.n_cores; c++)
             if (!per_core[c].empty())
             {
-                live.push_back(per_core[c][head[c]++]);
-                Msg &m = live.back();
+                Msg &m = per_core[c][head[c]++];
                 m.sent_timestamp = m.generation_delay;
                 pq.push(Pending{m.sent_timestamp, &m});
             }
         double last = 0.0;
         while (!pq.empty())
         {
-            Msg &m = *pq.top().m; // scheduled in place: `live` keeps addresses stable
+            Msg &m = *pq.top().m;
             pq.pop();
             last = std::max(last, m.sent_timestamp);
             const double tnow = m.sent_timestamp;
@@ -676,21 +681,23 @@ struct sanafe_chip
             const size_t sc = m.src_core_id;
             if (head[sc] < per_core[sc].size()) // schedule_push_next_message
             {
-                live.push_back(per_core[sc][head[sc]++]);
-                Msg &nx = live.back();
+                Msg &nx = per_core[sc][head[sc]++];
                 nx.sent_timestamp = m.sent_timestamp + nx.generation_delay;
                 pq.push(Pending{nx.sent_timestamp, &nx});
                 last = std::max(last, nx.sent_timestamp);
             }
-            sched_order[sc].push_back(&m);
+            if (keep_order) sched_order[sc].push_back(&m);
         }
-        std::vector<std::vector<Msg>> scheduled(mc.n_cores);
-        for (uint32_t c = 0; c < mc.n_cores; c++)
+        if (keep_order) // the message trace lists a core's messages in the order they were scheduled
         {
-            scheduled[c].reserve(sched_order[c].size());
-            for (const Msg *pm : sched_order[c]) scheduled[c].push_back(*pm);
+            std::vector<std::vector<Msg>> scheduled(mc.n_cores);
+            for (uint32_t c = 0; c < mc.n_cores; c++)
+            {
+                scheduled[c].reserve(sched_order[c].size());
+                for (const Msg *pm : sched_order[c]) scheduled[c].push_back(*pm);
+            }
+            per_core.swap(scheduled);
         }
-        per_core.swap(scheduled);
         return last + mc.sync_delay;
     }
 };
@@ -904,7 +911,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             {
                 std::vector<std::vector<Msg>> per_core;
                 chip->build_messages(job.ts.timesteps, job.status, per_core, job.mid_base);
-                job.ts.sim_time = chip->schedule_detailed(per_core);
+                job.ts.sim_time = chip->schedule_detailed(per_core, record != 0);
                 if (record)
                     for (auto &q : per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
             }
