@@ -83,7 +83,14 @@ struct sanafe_hip_chip
     bool own_stream{true};
     bool has_delay{false}, force_delay_variant{false};
     long long t_host{0};      // timesteps launched so far (the device's *st.t trails it by the pending reduction)
-    PrevStep pend{};          // the launched step whose reduction has not been launched yet
+    PendStep pend1{};         // the launched step that still needs level 1 of its reduction
+    PendStep pend2{};         // the step before it: level 1 done (or launched), level 2 not yet launched
+    std::vector<uint32_t> h_core_wg_beg, h_core_slice_beg; // host copies for sanafe_hip_read_core_delays
+    std::vector<double> h_core_out_lat;
+    int neuron_model{0};      // soma model every live slot runs (SANAFE_SOMA_LIF / _TRUENORTH), 0 when they differ
+    bool uni{false};          // every live slot carries the class word us.cls (UniformSoma)
+    UniformSoma us{};
+    std::vector<sanafe_hip_soma_class> h_soma_classes; // host copy of the class table the device uses
     int syn_format{2};        // 0: 2+1 B, 1: 4 B, 2: 4+8 B per synapse (DevImage)
     uint32_t n_compact_slices{0};
     DevImage im{};
@@ -325,20 +332,97 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     for (uint32_t k = 0; k < h.n_cores; k++) max_pad = std::max(max_pad, (h.core_ncount[k] + 63u) & ~63u);
     im.max_core_slots = max_pad;
     TRYC(upload(c, h.core_nbase, h.n_cores, &im.core_nbase));
-    TRYC(upload(c, h.core_ncount, h.n_cores, &im.core_ncount));
     TRYC(upload(c, h.core_axon_out_latency, h.n_cores, &im.core_axon_out_latency));
-    TRYC(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_axon_in_latency));
     TRYC(upload(c, h.soma_classes, h.n_soma_classes, &im.soma_classes));
     TRYC(upload(c, h.cost_classes, h.n_cost_classes, &im.cost_classes));
     TRYC(upload(c, h.slot_cls, h.n_slots, &im.slot_cls));
     TRYC(upload(c, h.slot_bias, h.n_slots, &im.slot_bias));
     TRYC(upload(c, h.slot_aux, h.n_slots, &im.slot_aux));
-    TRYC(upload(c, h.slot_packets, h.n_slots, &im.slot_packets));
-    TRYC(upload(c, h.slot_hops, h.n_slots, &im.slot_hops));
-    TRYC(upload(c, h.slot_events, h.n_slots, &im.slot_events));
-    TRYC(upload(c, h.slot_e_net, h.n_slots, &im.slot_e_net));
-    TRYC(upload(c, h.slot_e_syn, h.n_slots, &im.slot_e_syn));
-    TRYC(upload(c, h.slot_e_dend, h.n_slots, &im.slot_e_dend));
+    {
+        // what one spike of each neuron causes downstream: one 40-byte record per slot
+        std::vector<SpikeStatic> spike(h.n_slots);
+        for (uint32_t g = 0; g < h.n_slots; g++)
+        {
+            spike[g].e_net = h.slot_e_net[g];
+            spike[g].e_syn = h.slot_e_syn[g];
+            spike[g].e_dend = h.slot_e_dend[g];
+            spike[g].packets = h.slot_packets[g];
+            spike[g].hops = h.slot_hops[g];
+            spike[g].events = h.slot_events[g];
+            spike[g].pad = 0;
+        }
+        TRYC(upload(c, spike.data(), spike.size(), &im.slot_spike));
+    }
+    {
+        // neuron workgroups: up to 4 consecutive 64-slot chunks of one core each
+        std::vector<WgDesc> wgs;
+        std::vector<uint32_t> wg_beg(h.n_cores + 1, 0);
+        for (uint32_t k = 0; k < h.n_cores; k++)
+        {
+            wg_beg[k] = (uint32_t) wgs.size();
+            const uint32_t chunks = (h.core_ncount[k] + 63u) / 64u;
+            for (uint32_t q = 0; q < chunks; q += NEURON_BLOCK / WAVE)
+                wgs.push_back(WgDesc{h.core_nbase[k] + q * 64u, k, std::min<uint32_t>(NEURON_BLOCK / WAVE, chunks - q), 0u});
+        }
+        wg_beg[h.n_cores] = (uint32_t) wgs.size();
+        // Which neuron kernel: one soma model on the whole chip -> that model's kernel; and when every live slot
+        // carries the same class word on equal cores laid out back to back (the large synthetic configurations),
+        // the parameters travel as kernel arguments and the workgroup -> slot mapping is arithmetic (UniformSoma).
+        {
+            uint32_t cls0 = 0, ncount0 = 0, next_slot = 0;
+            bool same_cls = true, same_model = true, equal_cores = true;
+            for (uint32_t k = 0; k < h.n_cores; k++)
+            {
+                if (h.core_ncount[k] == 0) continue;
+                if (ncount0 == 0) ncount0 = h.core_ncount[k];
+                equal_cores = equal_cores && h.core_ncount[k] == ncount0 && h.core_nbase[k] == next_slot;
+                next_slot = h.core_nbase[k] + ((h.core_ncount[k] + 63u) & ~63u);
+                for (uint32_t q = 0; q < h.core_ncount[k]; q++)
+                {
+                    const uint32_t cl = h.slot_cls[h.core_nbase[k] + q];
+                    if (cls0 == 0) cls0 = cl;
+                    same_cls = same_cls && cl == cls0;
+                    same_model = same_model && (cl & 7u) == (cls0 & 7u);
+                }
+            }
+            const uint32_t model0 = cls0 & 7u;
+            c->neuron_model = (same_model && (model0 == SANAFE_SOMA_LIF || model0 == SANAFE_SOMA_TRUENORTH)) ? (int) model0 : 0;
+            const uint32_t cpc = (ncount0 + 63u) / 64u, wpc = (cpc + 3u) / 4u;
+            c->uni = c->neuron_model != 0 && same_cls && equal_cores && h.n_ext == 0 && (wpc & (wpc - 1u)) == 0u &&
+                    (cls0 >> 16) < h.n_soma_classes && ((cls0 >> 6) & 1023u) < h.n_cost_classes &&
+                    std::getenv("SANAFE_NEURON_GENERIC") == nullptr; // tests: force the table-driven kernel
+            if (c->uni)
+            {
+                c->us.p = h.soma_classes[cls0 >> 16];
+                c->us.c = h.cost_classes[(cls0 >> 6) & 1023u];
+                c->us.cls = cls0;
+                c->us.ncount = ncount0;
+                c->us.cpc = cpc;
+                c->us.wpc_shift = 0;
+                while ((1u << c->us.wpc_shift) < wpc) c->us.wpc_shift++;
+            }
+            c->h_soma_classes.assign(h.soma_classes, h.soma_classes + h.n_soma_classes);
+        }
+        im.spike_energy = 0;
+        for (uint32_t g = 0; g < h.n_slots; g++)
+        {
+            im.spike_energy |= (h.slot_e_syn[g] != 0.0 ? 1 : 0) | (h.slot_e_net[g] != 0.0 ? 2 : 0) | (h.slot_e_dend[g] != 0.0 ? 4 : 0);
+            if (h.slot_packets[g] >= (1u << 18)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "slot %u: a spike fans out to 2^18 cores or more", g));
+        }
+        im.n_wgs = (uint32_t) wgs.size();
+        im.n_groups = (h.n_cores + WAVE - 1) / WAVE;
+        im.n_reduce_wgs = (im.n_groups + (NEURON_BLOCK / WAVE) - 1) / (NEURON_BLOCK / WAVE);
+        TRYC(upload(c, wgs.data(), wgs.size(), &im.wg_desc));
+        TRYC(upload(c, wg_beg.data(), wg_beg.size(), &im.core_wg_beg));
+        c->h_core_wg_beg = wg_beg;
+        c->h_core_out_lat.assign(h.core_axon_out_latency, h.core_axon_out_latency + h.n_cores);
+    }
+    im.n_soma_classes = h.n_soma_classes;
+    im.n_cost_classes = h.n_cost_classes;
+    im.has_lif = 0;
+    for (uint32_t g = 0; g < h.n_slots && !im.has_lif; g++) im.has_lif = (h.slot_cls[g] & 7u) == SANAFE_SOMA_LIF;
+    im.any_refrac = 0;
+    for (uint32_t k = 0; k < h.n_soma_classes; k++) im.any_refrac |= h.soma_classes[k].refractory_delay > 0;
     TRYC(upload(c, h.in_train_beg, h.n_input, &im.in_train_beg));
     TRYC(upload(c, h.in_train_len, h.n_input, &im.in_train_len));
     TRYC(upload(c, reinterpret_cast<const long long *>(h.in_rate_period), h.n_input, &im.in_rate_period));
@@ -356,9 +440,6 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     im.n_ext = h.n_ext;
     im.slot_ext = nullptr;
     if (h.n_ext > 0) TRYC(upload(c, h.slot_ext, h.n_slots, &im.slot_ext));
-    TRYC(upload(c, h.slice_core, h.n_slices, &im.slice_core));
-    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_beg), h.n_slices, &im.slice_axon_beg));
-    TRYC(upload(c, reinterpret_cast<const unsigned long long *>(h.slice_axon_end), h.n_slices, &im.slice_axon_end));
     // ---- synapse format: the narrowest of the three that holds every weight exactly (see DevImage) ----
     //   0: post < 4096 and int8 weights; 1: 12-bit integer weights; 2: fp64 weights
     {
@@ -521,10 +602,33 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         });
         for (uint8_t x : exact) any_exact |= (x != 0);
         TRYC(upload(c, bytes.data(), bytes.size(), &im.ax_bytes));
-        TRYC(upload(c, rec_off.data(), rec_off.size(), &im.slice_rec_off));
-        TRYC(upload(c, mode.data(), mode.size(), &im.slice_mode));
-        TRYC(upload(c, slat.data(), slat.size(), &im.slice_lat_class));
-        TRYC(upload(c, chunk0.data(), chunk0.size(), &im.slice_chunk0));
+        {
+            std::vector<double> lat255(256, 0.0);
+            if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat255.begin());
+            std::vector<uint32_t> n_core_slices(h.n_cores, 0);
+            for (uint32_t sl = 0; sl < h.n_slices; sl++) n_core_slices[h.slice_core[sl]]++;
+            std::vector<SliceDesc> desc(h.n_slices);
+            for (uint32_t sl = 0; sl < h.n_slices; sl++)
+            {
+                const uint32_t core = h.slice_core[sl];
+                SliceDesc &d = desc[sl];
+                d.rec_off = rec_off[sl];
+                d.syn_base = dev_core_base[core];
+                d.a_beg = h.slice_axon_beg[sl];
+                d.ain_lat = h.core_axon_in_latency[core];
+                d.slice_lat = lat255[slat[sl]];
+                d.n_ax = (uint32_t) (h.slice_axon_end[sl] - h.slice_axon_beg[sl]);
+                d.nbase = h.core_nbase[core];
+                d.ncount = h.core_ncount[core];
+                d.chunk0 = chunk0[sl];
+                d.core = core;
+                d.mode = mode[sl];
+                d.inkind = (uint8_t) ((h.slot_cls[h.core_nbase[core]] >> 3) & 7u);
+                d.shared = n_core_slices[core] > 1 ? 1 : 0;
+                d.pad = 0;
+            }
+            TRYC(upload(c, desc.data(), desc.size(), &im.slice_desc));
+        }
         TRYC(upload(c, csyn.data(), csyn.size(), &im.chunk_syn0));
         TRYC(upload(c, cpre.data(), cpre.size(), &im.chunk_pre0));
         TRYC(upload(c, h.ax_proc_delay, any_exact ? h.n_axons : 0, &im.ax_proc_delay));
@@ -549,6 +653,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         for (uint32_t s = 0; s < h.n_slices; s++) beg[h.slice_core[s] + 1]++;
         for (uint32_t k = 0; k < h.n_cores; k++) beg[k + 1] += beg[k];
         TRYC(upload(c, beg.data(), beg.size(), &im.core_slice_beg));
+        c->h_core_slice_beg = beg;
     }
     DevState &st = c->st;
     TRYC(dalloc(c, h.n_slots, &st.v));
@@ -581,12 +686,15 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             TRYC(dalloc(c, (size_t) h.n_taps * 8, &st.tap_in));
         }
     }
-    TRYC(dalloc(c, h.n_slots / 32, &st.bits_local));
-    if (h.n_global_slots == h.n_slots) st.bits_global = st.bits_local;
-    else TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
-    TRYC(dalloc(c, 2 * (size_t) h.n_cores, &st.core_part));
-    TRYC(dalloc(c, h.n_slices, &st.slice_proc));
-    TRYC(dalloc(c, 2 * (size_t) h.n_cores, &st.core_proc));
+    // the local spike bitmap is this chip's window of the global one: local delivery can start right after the
+    // neuron launch, and the multi-GPU exchange gathers in place
+    TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
+    st.bits_local = st.bits_global + h.slot_offset / 32;
+    TRYC(dalloc(c, 2 * (size_t) im.n_wgs, &st.wg_part));
+    TRYC(dalloc(c, 2 * (size_t) h.n_slices, &st.slice_proc));
+    TRYC(dalloc(c, 2 * (size_t) im.n_groups, &st.group_part));
+    st.delay_log = nullptr;
+    st.delay_log_cap = 0;
     TRYC(dalloc(c, 1, &st.t));
     TRYC(dalloc(c, 1, &st.rec));
     TRYC(dalloc(c, 1, &st.run));
@@ -598,7 +706,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->v0.assign(h.slot_v0, h.slot_v0 + h.n_slots);
         HIPC(hipMemcpy(st.v, h.slot_v0, (size_t) h.n_slots * sizeof(double), hipMemcpyHostToDevice));
     }
-    c->neuron_grid = h.n_cores;
+    c->neuron_grid = im.n_reduce_wgs + im.n_wgs;
     {
         // LDS accumulator rows: one per synaptic delay value actually present in the image
         std::atomic<uint32_t> max_delay_seen{0};
@@ -680,18 +788,33 @@ static int ensure_log(sanafe_hip_chip *c, long long steps, bool with_status)
 // ---- one timestep = neuron launch (which first reduces the previous step) + delivery launch ----
 static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 {
-    const int *ext_row = nullptr;
+    StepArgs sa{};
     if (c->im.n_ext > 0)
     {
         if (c->ext_next >= c->ext_rows)
             return fail(SANAFE_HIP_ERR_INVALID, "external value streams exhausted: queue rows with sanafe_hip_write_ext before stepping");
-        ext_row = c->d_ext + (size_t) c->ext_next * c->im.n_ext;
+        sa.ext_row = c->d_ext + (size_t) c->ext_next * c->im.n_ext;
         c->ext_next++;
     }
-    hipLaunchKernelGGL(neuron_kernel, dim3(c->neuron_grid), dim3(NEURON_BLOCK), 0, c->stream, c->im, c->st, record, ext_row,
-            c->t_host, rec_index, c->pend);
+    sa.t = c->t_host + 1;
+    sa.parity = (int) (c->t_host & 1);
+    const size_t rslot = (size_t) (sa.t % c->im.ring_slots);
+    sa.ring = c->st.ring + rslot * c->im.n_slots;
+    sa.rvalid = c->st.ring_valid + rslot * c->im.n_slots;
+    if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
+    if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
+    const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
+#define SANAFE_LAUNCH_NEURON(M, U) \
+    hipLaunchKernelGGL((neuron_kernel<M, U>), grid, block, 0, c->stream, c->im, c->st, sa, c->us, c->pend1, c->pend2)
+    if (c->uni && c->neuron_model == SANAFE_SOMA_LIF) SANAFE_LAUNCH_NEURON(SANAFE_SOMA_LIF, true);
+    else if (c->uni && c->neuron_model == SANAFE_SOMA_TRUENORTH) SANAFE_LAUNCH_NEURON(SANAFE_SOMA_TRUENORTH, true);
+    else if (c->neuron_model == SANAFE_SOMA_LIF) SANAFE_LAUNCH_NEURON(SANAFE_SOMA_LIF, false);
+    else if (c->neuron_model == SANAFE_SOMA_TRUENORTH) SANAFE_LAUNCH_NEURON(SANAFE_SOMA_TRUENORTH, false);
+    else SANAFE_LAUNCH_NEURON(0, false);
+#undef SANAFE_LAUNCH_NEURON
     HIPCHK(hipGetLastError());
-    c->pend.valid = 0; // reduced by workgroup 0 of that launch
+    c->pend2 = c->pend1; // level 1 rides in that launch; level 2 in the next one
+    c->pend1.valid = 0;
     return 0;
 }
 static int launch_deliver(sanafe_hip_chip *c)
@@ -728,19 +851,23 @@ static int launch_taps(sanafe_hip_chip *c)
 // The reduction of the step just launched is left pending: the next neuron launch performs it, or flush_pending.
 static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long long rec_index)
 {
-    c->pend.valid = 1;
-    c->pend.simple_timing = simple_timing;
-    c->pend.record = record;
-    c->pend.parity = (int) (c->t_host & 1);
-    c->pend.rec_index = rec_index;
+    c->pend1.valid = 1;
+    c->pend1.simple_timing = simple_timing;
+    c->pend1.record = record;
+    c->pend1.parity = (int) (c->t_host & 1);
+    c->pend1.rec_index = rec_index;
     c->t_host += 1;
 }
 static int flush_pending(sanafe_hip_chip *c)
 {
-    if (!c->pend.valid) return 0;
-    hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(REDUCE_BLOCK), 0, c->stream, c->im, c->st, c->pend);
-    HIPCHK(hipGetLastError());
-    c->pend.valid = 0;
+    while (c->pend1.valid || c->pend2.valid)
+    {
+        const uint32_t grid = c->pend1.valid ? std::max(1u, c->im.n_reduce_wgs) : 1u;
+        hipLaunchKernelGGL(reduce_kernel, dim3(grid), dim3(REDUCE_BLOCK), 0, c->stream, c->im, c->st, c->pend1, c->pend2);
+        HIPCHK(hipGetLastError());
+        c->pend2 = c->pend1;
+        c->pend1.valid = 0;
+    }
     return 0;
 }
 
@@ -994,13 +1121,40 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
     HIPCHK(hipSetDevice(c->device));
     TRY(flush_pending(c));
     const size_t last_parity = (size_t) ((c->t_host > 0 ? c->t_host - 1 : 0) & 1); // the step launched last
-    if (gen_sum)
+    if (gen_sum) // as level 1 of the step reduction forms it
     {
-        std::vector<CorePart> cp(c->im.n_cores);
-        TRY(d2h(c, cp.data(), c->st.core_part + last_parity * c->im.n_cores, cp.size()));
-        for (uint32_t k = 0; k < c->im.n_cores; k++) gen_sum[k] = cp[k].gen_sum;
+        std::vector<WgPart> wp(std::max<uint32_t>(1, c->im.n_wgs));
+        TRY(d2h(c, wp.data(), c->st.wg_part + last_parity * c->im.n_wgs, c->im.n_wgs));
+        for (uint32_t k = 0; k < c->im.n_cores; k++)
+        {
+            double lat = 0.0;
+            long long packets = 0;
+            for (uint32_t w = c->h_core_wg_beg[k]; w < c->h_core_wg_beg[k + 1]; w++) lat += wp[w].lat, packets += wp[w].packets;
+            gen_sum[k] = lat + (double) packets * c->h_core_out_lat[k];
+        }
     }
-    if (proc_sum) TRY(d2h(c, proc_sum, c->st.core_proc + last_parity * c->im.n_cores, c->im.n_cores));
+    if (proc_sum)
+    {
+        std::vector<double> sp(std::max<uint32_t>(1, c->im.n_slices));
+        TRY(d2h(c, sp.data(), c->st.slice_proc + last_parity * c->im.n_slices, c->im.n_slices));
+        for (uint32_t k = 0; k < c->im.n_cores; k++)
+        {
+            // the association of reduce_l1
+            const uint32_t s0 = c->h_core_slice_beg[k], s1 = c->h_core_slice_beg[k + 1];
+            double p = 0.0;
+            if (s1 - s0 <= 2u)
+            {
+                for (uint32_t q = s0; q < s1; q++) p += sp[q];
+            }
+            else
+            {
+                double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t q = s0; q < s1; q++) a[(q - s0) & 7u] += sp[q];
+                p = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+            }
+            proc_sum[k] = p;
+        }
+    }
     return 0;
 }
 
@@ -1017,6 +1171,11 @@ extern "C" int sanafe_hip_write_potential(sanafe_hip_chip *c, uint32_t first, ui
 extern "C" int sanafe_hip_write_slot_class(sanafe_hip_chip *c, uint32_t first, uint32_t count, const uint32_t *cls)
 {
     if (!c || !cls || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
+    for (uint32_t k = 0; k < count; k++)
+    {
+        if (c->uni && cls[k] != c->us.cls) c->uni = false; // the chip is no longer one class word: table-driven kernel
+        if (c->neuron_model != 0 && (cls[k] & 7u) != (uint32_t) c->neuron_model) c->neuron_model = 0, c->uni = false;
+    }
     return h2d(c, const_cast<uint32_t *>(c->im.slot_cls) + first, cls, count);
 }
 extern "C" int sanafe_hip_write_inputs(sanafe_hip_chip *c, uint32_t n_input, const uint32_t *train_beg, const uint32_t *train_len,
@@ -1080,6 +1239,15 @@ extern "C" int sanafe_hip_write_soma_classes(sanafe_hip_chip *c, uint32_t n, con
     }
     HIPCHK(hipMemcpy(c->d_soma_classes, classes, (size_t) n * sizeof(sanafe_hip_soma_class), hipMemcpyHostToDevice));
     c->im.soma_classes = c->d_soma_classes;
+    c->im.n_soma_classes = n;
+    c->im.any_refrac = 0;
+    for (uint32_t k = 0; k < n; k++) c->im.any_refrac |= classes[k].refractory_delay > 0;
+    c->h_soma_classes.assign(classes, classes + n);
+    if (c->uni)
+    {
+        if ((c->us.cls >> 16) < n) c->us.p = classes[c->us.cls >> 16];
+        else c->uni = false;
+    }
     return 0;
 }
 static int ensure_host_staging(sanafe_hip_chip *c, uint32_t count)

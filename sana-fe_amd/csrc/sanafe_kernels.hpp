@@ -1,31 +1,82 @@
 // sanafe_kernels.hpp -- device side of libsanafe_hip: constants, device views of the image and state, and the
-// kernels (neuron_kernel, deliver_kernel, reduce_step / reduce_kernel, host-unit kernels).  Included by
+// kernels (neuron_kernel, deliver_kernel, the two-level step reduction, host-unit kernels).  Included by
 // sanafe_hip.hip inside its anonymous namespace; see the header comment there for the map of the kernels.
 #pragma once
 
 constexpr int WAVE = 64;
-constexpr int NEURON_BLOCK = 256;   // one workgroup per simulated core: 4 wavefronts share its 64-slot chunks
+constexpr int NEURON_BLOCK = 256;   // 4 wavefronts = up to 4 consecutive 64-slot chunks of ONE simulated core
 constexpr int DELIVER_BLOCK = 256;
 constexpr int AX_PER_THREAD = 4;    // axon records per lane: one 8-byte (compact) or two 16-byte (wide) loads
 constexpr int REDUCE_BLOCK = 256;
+constexpr uint32_t SOMA_LDS_MAX = 128; // soma parameter classes staged in LDS by the neuron kernel (7 KiB)
+constexpr uint32_t COST_LDS_MAX = 64;  // cost classes staged in LDS (4 KiB)
 
-// Per-core partial sums written by K1 (one record per core, one writer).
-struct CorePart
+// One neuron workgroup: up to 4 chunks of one core (a 256-neuron TrueNorth core is one workgroup, a 1024-neuron
+// Loihi core four).  One 16-byte scalar load tells the workgroup everything it needs before its slot loads.
+struct WgDesc
 {
-    double e_soma, e_dend, e_syn, e_net, gen_sum;
+    uint32_t slot0;   // first (local) slot
+    uint32_t core;    // local core
+    uint32_t nchunks; // 1..4
+    uint32_t pad;
+};
+// Partial sums of one neuron workgroup (one writer), by step parity.
+struct WgPart
+{
+    double e_soma, e_dend, e_syn, e_net, lat;
     long long updated, fired, packets, hops, events;
 };
+// Level-1 result of the step reduction: 64 consecutive cores folded by one wavefront.
+struct GroupPart
+{
+    double e_soma, e_dend, e_syn, e_net, gmax, pmax;
+    long long updated, fired, packets, hops, events;
+};
+// Everything one spike of a neuron causes downstream is static (its messages, their hops, the synaptic
+// events behind them, their energy): one 40-byte record per slot, read only by lanes whose neuron fired.
+struct SpikeStatic
+{
+    double e_net, e_syn, e_dend;
+    uint32_t packets, hops, events, pad;
+};
+
+// One delivery slice: everything its workgroup needs before the first record load, in one 64-byte scalar load.
+struct SliceDesc
+{
+    unsigned long long rec_off;  // byte offset of the slice's axon records in ax_bytes
+    unsigned long long syn_base; // first synapse of the destination core
+    unsigned long long a_beg;    // first axon of the slice (index into ax_proc_delay)
+    double ain_lat;              // AxonInUnit::latency_spike_message of the core
+    double slice_lat;            // per-event latency of the slice's latency class
+    uint32_t n_ax, nbase, ncount, chunk0;
+    uint32_t core;
+    uint8_t mode;                // 0 wide, 1 compact axon records
+    uint8_t inkind;              // input kind of the core's neurons (the buffer position belongs to the core)
+    uint8_t shared;              // the core has more than one slice: write back with atomics
+    uint8_t pad;
+};
+static_assert(sizeof(SliceDesc) == 64, "one scalar load");
 
 struct DevImage
 {
     uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots, delay_slots;
+    uint32_t n_wgs;          // neuron workgroups
+    uint32_t n_groups;       // ceil(n_cores / 64): level-1 reduction groups
+    uint32_t n_reduce_wgs;   // ceil(n_groups / 4): leading workgroups of a neuron launch that reduce earlier steps
+    uint32_t n_soma_classes, n_cost_classes;
+    int has_lif;             // some slot runs the LIF soma (its input current `icur` is state)
+    int spike_energy;        // bit 0/1/2: some neuron's spike costs synapse / network / message-side dendrite energy
+    int any_refrac;          // some soma class has refractory_delay > 0 (otherwise `refrac` is never touched)
     double sync_delay;
-    const uint32_t *core_nbase, *core_ncount;
-    const double *core_axon_out_latency, *core_axon_in_latency;
+    const WgDesc *wg_desc;          // [n_wgs]
+    const uint32_t *core_wg_beg;    // [n_cores + 1] neuron workgroups of each core
+    const uint32_t *core_nbase;
+    const double *core_axon_out_latency;
     const sanafe_hip_soma_class *soma_classes;
     const sanafe_hip_cost_class *cost_classes;
-    const uint32_t *slot_cls, *slot_aux, *slot_packets, *slot_hops, *slot_events;
-    const double *slot_bias, *slot_e_net, *slot_e_syn, *slot_e_dend;
+    const uint32_t *slot_cls, *slot_aux;
+    const SpikeStatic *slot_spike;
+    const double *slot_bias;
     const uint32_t *in_train_beg, *in_train_len, *in_train_bits;
     const long long *in_rate_period;
     const uint32_t *slot_ext; // column of the slot in a row of external stream values (0xffffffff: none)
@@ -33,8 +84,8 @@ struct DevImage
     uint32_t n_taps;          // neurons behind a `taps` dendrite (SANAFE_IN_TAPS); tables indexed by slot_aux
     const uint32_t *tap_slot, *tap_count;
     const double *tap_tc, *tap_sc; // [n_taps][8]
-    const uint32_t *slice_core;
-    const unsigned long long *slice_axon_beg, *slice_axon_end, *core_syn_base;
+    const SliceDesc *slice_desc;    // [n_slices]
+    const unsigned long long *core_syn_base;
     const uint32_t *core_slice_beg; // [n_cores+1]
     // Device layout of the inbound axons, chosen per delivery slice (slice_mode):
     //   wide    8 bytes/axon: bits 0-31 pre-synaptic GLOBAL slot | 32-47 synapse count | 48-55 latency class
@@ -44,10 +95,6 @@ struct DevImage
     //           Used when the slice's axons are dense in pre-slot order (gaps < 256), have < 256 synapses each
     //           and share a latency class -- the normal case of a large recurrent network.
     const unsigned char *ax_bytes;            // all slices' records, each slice 16-byte aligned
-    const unsigned long long *slice_rec_off;  // [n_slices] byte offset of the slice's records
-    const uint8_t *slice_mode;                // [n_slices] 0 wide, 1 compact
-    const uint8_t *slice_lat_class;           // [n_slices] latency class of a compact slice
-    const uint32_t *slice_chunk0;             // [n_slices] first entry of the slice in the chunk tables
     const uint32_t *chunk_syn0;               // per 256-axon chunk: first synapse (relative to the core)
     const uint32_t *chunk_pre0;               // per 256-axon chunk: pre slot of its first axon
     const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
@@ -65,13 +112,17 @@ struct DevImage
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
 };
 
-// The reduction of step s runs at the START of step s+1's neuron launch (its workgroup 0), so a timestep costs
-// two launches instead of three; the per-core partials of consecutive steps therefore live in two alternating
-// halves ("parity" = steps simulated before the step, & 1).  A trailing reduce_kernel flushes the last step
-// before anything reads results.
-struct PrevStep
+// The reduction of a step is split in two levels that ride in the leading workgroups of LATER neuron launches,
+// so a timestep stays two launches and no launch waits on a serial reduction:
+//   level 1 (step s, inside the neuron launch of step s+1, one wavefront per 64 cores): per core, the neuron
+//           workgroups' partials and the delivery slices' processing delays are summed in a fixed order, then
+//           folded over the 64 cores -> GroupPart[s & 1][group];
+//   level 2 (step s, inside the neuron launch of step s+2, one wavefront): the groups -> Timestep totals,
+//           simple timing model, run totals, records, t += 1.
+// Partials live in two halves by step parity.  reduce_kernel flushes what is pending before any read-back.
+struct PendStep
 {
-    int valid;          // 0: nothing to reduce
+    int valid;          // 0: nothing to do
     int simple_timing, record, parity;
     long long rec_index; // record slot of that step
 };
@@ -88,11 +139,11 @@ struct DevState
     double *tap_v;         // [n_taps][8] tap voltages
     double *tap_in;        // [n_taps][8] charge delivered to each tap in the current step
     uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
-    uint32_t *bits_local;  // [n_slots/32]
-    uint32_t *bits_global; // [n_global_slots/32] (aliases bits_local on one GPU)
-    CorePart *core_part;   // [2][n_cores], by step parity
-    double *slice_proc;    // [n_slices]
-    double *core_proc;     // [2][n_cores], by step parity
+    uint32_t *bits_local;  // [n_slots/32]; multi-GPU: this chip's window INSIDE bits_global
+    uint32_t *bits_global; // [n_global_slots/32] (== bits_local on one GPU)
+    WgPart *wg_part;       // [2][n_wgs], by step parity
+    double *slice_proc;    // [2][n_slices], by step parity: processing-delay sum of each delivery slice
+    GroupPart *group_part; // [2][n_groups], by step parity
     long long *t;          // timesteps simulated so far
     long long *rec;        // records written so far in this sim
     sanafe_hip_totals *run;       // run totals
@@ -100,11 +151,13 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
+    double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
+    long long delay_log_cap;
 };
 
-// Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles (the neuron kernel's
-// waves spent a third of their cycles waiting to issue those): Hillis-Steele inside each 16-lane row, row_bcast:15
-// and row_bcast:31 across rows, total in lane 63.  Lanes without a source read 0 bits = +0.0 / 0.  Fixed order.
+// Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles: Hillis-Steele inside
+// each 16-lane row, row_bcast:15 and row_bcast:31 across rows, total in lane 63.  Lanes without a source read
+// 0 bits = +0.0 / 0.  Fixed order.
 #define SANAFE_DPP_STEPS(STEP)                  \
     STEP(0x111, 0xf) /* row_shr:1 */            \
     STEP(0x112, 0xf) /* row_shr:2 */            \
@@ -138,6 +191,12 @@ __device__ __forceinline__ long long wave_sum(long long x)
     const unsigned hi = (unsigned) __builtin_amdgcn_readlane((int) (unsigned) ((unsigned long long) x >> 32), 63);
     return (long long) (((unsigned long long) hi << 32) | lo);
 }
+__device__ __forceinline__ double wave_max(double x)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, WAVE));
+    return x;
+}
 
 // static_cast<int>(double) as x86-64 performs it (cvttsd2si): out-of-range and NaN give INT_MIN.
 // The reference quantises with it (src/models.cpp:447-455).
@@ -147,57 +206,136 @@ __device__ __forceinline__ int cvt_int_x86(double x)
     return (int) x;
 }
 
-// ---------------------------------------------------------------------------------------
-// K1: neuron update.  grid = n_cores, block = 256: the core's 64-slot chunks are dealt to the
-// workgroup's 4 wavefronts (a 256-neuron TrueNorth core is one chunk per wave, a 1024-neuron
-// Loihi core four), every wave owns whole 64-slot chunks so the spike ballot maps 1:1 to bitmap words.
-// ---------------------------------------------------------------------------------------
-__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5]);
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group);
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev);
 
-__global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevState st, int record, const int *ext_row,
-        long long done /* steps simulated before this one */, long long rec, PrevStep prev)
+// Per-launch values the host works out (no 64-bit division or row arithmetic on the device).
+struct StepArgs
 {
-    static_assert(NEURON_BLOCK == REDUCE_BLOCK, "workgroup 0 reduces the previous step");
-    if (blockIdx.x == 0 && prev.valid)
+    double *ring;        // time-step buffer / delay-ring row of this step: st.ring + (t % ring_slots) * n_slots
+    uint8_t *rvalid;     // the matching row of ring_valid
+    uint32_t *slog;      // spike-log row of this step, or NULL
+    uint8_t *stlog;      // status-log row of this step, or NULL
+    const int *ext_row;  // external stream values of this step, or NULL
+    long long t;         // Timestep::timestep of this step (steps simulated before it + 1)
+    int parity;          // (t - 1) & 1: which half of the partials this step writes
+    int pad;
+};
+
+// A chip whose neurons all carry the same class word (one soma model, one parameter set, one cost class, one input
+// kind: the large synthetic configurations) gets its parameters as kernel arguments, i.e. in scalar registers:
+// the neuron kernel then loads no class word and no class table at all.
+struct UniformSoma
+{
+    sanafe_hip_soma_class p;
+    sanafe_hip_cost_class c;
+    uint32_t cls;        // the one slot class word
+    uint32_t ncount;     // neurons of every core that has any
+    uint32_t cpc;        // 64-slot chunks of such a core
+    uint32_t wpc_shift;  // log2(neuron workgroups per core)
+};
+
+// ---------------------------------------------------------------------------------------
+// K1: neuron update.  grid = n_reduce_wgs + n_wgs, block = 256.
+//   leading workgroups: level 1 / level 2 of the step reduction of the two previous steps (one wavefront per
+//                       group of 64 cores), independent of everything else in the launch;
+//   neuron workgroups:  one wavefront per 64-slot chunk (no loop), so the spike ballot maps 1:1 to bitmap words.
+// The kernel is bound by vector-instruction issue before it is bound by HBM (16 wavefronts per SIMD on a 1 M
+// neuron chip, fp64 at 8 cycles an instruction), so everything wave-uniform is kept in scalar registers: the
+// per-wave base pointers (every array is indexed by the lane alone), the counters and class costs (ballots and
+// popcounts), and -- UNI = true -- the soma parameters themselves.  MODEL = 0 decides the soma model per lane,
+// 1 / 2 compile the LIF / TrueNorth update alone.
+// The load chain is two round trips deep: (1) the workgroup descriptor (arithmetic when UNI), (2) every per-slot
+// array at once -- class word, time-step buffer value AND valid byte, bias, potential, input current, refractory
+// counter -- while the soma / cost class tables are staged in LDS, so no load depends on the class word;
+// lanes whose neuron fired add (3) one 40-byte record of what the spike causes downstream.
+// ---------------------------------------------------------------------------------------
+template <int MODEL, bool UNI>
+__global__ void __launch_bounds__(NEURON_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
+neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1, PendStep l2)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
+    if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
-        __shared__ double r_sd[REDUCE_BLOCK / WAVE][6];
-        __shared__ long long r_sl[REDUCE_BLOCK / WAVE][5];
-        reduce_step(im, st, prev, r_sd, r_sl);
-        __syncthreads();
+        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
+        const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
+        if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group);
+        return;
     }
-    const uint32_t parity_off = (uint32_t) (done & 1) * im.n_cores;
+    __shared__ sanafe_hip_soma_class s_soma[UNI ? 1 : SOMA_LDS_MAX];
+    __shared__ sanafe_hip_cost_class s_cost[UNI ? 1 : COST_LDS_MAX];
     __shared__ double s_d[NEURON_BLOCK / WAVE][5];
     __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    const uint32_t core = blockIdx.x;
-    const long long t = done + 1;      // Timestep::timestep of this step
-    const uint32_t nbase = im.core_nbase[core];
-    const uint32_t ncount = im.core_ncount[core];
-    const uint32_t rslot = (uint32_t) (t % im.ring_slots);
-    double *ring = st.ring + (size_t) rslot * im.n_slots;
-    uint8_t *rvalid = st.ring_valid + (size_t) rslot * im.n_slots;
-    uint32_t *slog = record ? st.spike_log + (size_t) (rec % st.log_cap) * (im.n_slots / 32) : nullptr;
-    uint8_t *stlog = (record & 2) ? st.status_log + (size_t) (rec % st.log_cap) * im.n_slots : nullptr;
-
-    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0, e_dspk = 0.0; // per lane
-    long long n_pack = 0, n_hops = 0, n_ev = 0;                                         // per lane
-    double w_e_soma = 0.0, w_e_dend = 0.0, w_lat = 0.0;                                 // per wavefront (uniform)
-    long long w_upd = 0, w_fire = 0;
-    bool mixed = false, any_fire = false;                                               // wave-uniform
-
-    for (uint32_t off = wave * WAVE; off < ncount; off += NEURON_BLOCK)
+    const uint32_t wg = blockIdx.x - im.n_reduce_wgs;
+    uint32_t slot0, nchunks, nlive = WAVE, core = 0xffffffffu;
+    if (UNI)
     {
-        const uint32_t g = nbase + off + lane;
-        const bool live = (off + lane) < ncount;
-        // every load that does not depend on the neuron's class is issued up front (padding slots exist in all
-        // per-slot arrays), so the class-table lookups overlap with them instead of preceding them
-        const uint32_t cls_raw = im.slot_cls[g];
-        const uint8_t in_valid = rvalid[g];
-        const double in_value = (in_valid != 0) ? ring[g] : 0.0; // (8 bytes per neuron saved when nothing arrived)
-        const double bias = im.slot_bias[g];
-        const double v_in = st.v[g];
-        uint32_t cls = live ? cls_raw : 0u;
-        const uint32_t model = cls & 7u;
+        const uint32_t k = wg >> us.wpc_shift, q = (wg & ((1u << us.wpc_shift) - 1u)) * 4u;
+        slot0 = (k * us.cpc + q) * WAVE;
+        nchunks = (us.cpc - q < 4u) ? us.cpc - q : 4u;
+        const uint32_t first = (q + wave) * WAVE; // offset of this wave's chunk inside its core
+        nlive = (first < us.ncount) ? ((us.ncount - first < (uint32_t) WAVE) ? us.ncount - first : (uint32_t) WAVE) : 0u;
+    }
+    else
+    {
+        const WgDesc wd = im.wg_desc[wg];
+        slot0 = wd.slot0;
+        nchunks = wd.nchunks;
+        core = wd.core;
+    }
+    const bool soma_lds = UNI || im.n_soma_classes <= SOMA_LDS_MAX, cost_lds = UNI || im.n_cost_classes <= COST_LDS_MAX;
+    const bool active = wave < nchunks; // wave-uniform
+    const long long t = sa.t;
+    const uint32_t c0 = slot0 + wave * WAVE; // first slot of this wave's chunk (scalar): arrays are indexed by the lane
+    double *p_ring = sa.ring + c0, *p_v = st.v + c0, *p_icur = st.icur + c0;
+    uint8_t *p_rvalid = sa.rvalid + c0;
+    int *p_refrac = st.refrac + c0;
+    const double *p_bias = im.slot_bias + c0;
+
+    // ---- every per-slot load, issued at once (padding slots exist in all per-slot arrays) ----
+    uint32_t cls = 0, ext_col = 0xffffffffu;
+    uint8_t in_valid = 0;
+    double in_value = 0.0, bias = 0.0, v_in = 0.0, ic_in = 0.0;
+    int rc_in = 0;
+    if (active)
+    {
+        if (UNI) cls = (lane < nlive) ? us.cls : 0u;
+        else cls = im.slot_cls[c0 + lane];
+        in_valid = p_rvalid[lane];
+        in_value = p_ring[lane];
+        bias = p_bias[lane];
+        v_in = p_v[lane];
+        if (MODEL != SANAFE_SOMA_TRUENORTH && im.has_lif) ic_in = p_icur[lane];
+        if (MODEL != SANAFE_SOMA_TRUENORTH && im.any_refrac) rc_in = p_refrac[lane];
+        if (!UNI && sa.ext_row != nullptr) ext_col = im.slot_ext[c0 + lane];
+    }
+    if (!UNI)
+    {
+        // ---- class tables -> LDS, in flight together with the slot loads ----
+        static_assert(sizeof(sanafe_hip_soma_class) % 8 == 0 && sizeof(sanafe_hip_cost_class) % 8 == 0, "copied in 8-byte words");
+        if (soma_lds)
+        {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(im.soma_classes);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_soma);
+            const uint32_t n = im.n_soma_classes * (uint32_t) (sizeof(sanafe_hip_soma_class) / 8);
+            for (uint32_t i = threadIdx.x; i < n; i += NEURON_BLOCK) dst[i] = src[i];
+        }
+        if (cost_lds)
+        {
+            const unsigned long long *src = reinterpret_cast<const unsigned long long *>(im.cost_classes);
+            unsigned long long *dst = reinterpret_cast<unsigned long long *>(s_cost);
+            const uint32_t n = im.n_cost_classes * (uint32_t) (sizeof(sanafe_hip_cost_class) / 8);
+            for (uint32_t i = threadIdx.x; i < n; i += NEURON_BLOCK) dst[i] = src[i];
+        }
+        __syncthreads(); // class tables staged
+    }
+
+    double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
+    long long n_pack = 0, n_hops = 0, n_ev = 0, n_upd = 0, n_fire = 0;
+    if (active)
+    {
+        const uint32_t model = cls & 7u; // padding slots carry SANAFE_SOMA_NONE
         int status = 0;
         if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
         {
@@ -218,12 +356,12 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 cur = 0.0;
                 if (in_valid != 0)
                 {
-                    ring[g] = 0.0;
-                    rvalid[g] = 0;
+                    p_ring[lane] = 0.0;
+                    p_rvalid[lane] = 0;
                 }
-                if (st.arrived[g] != 0)
+                if (st.arrived[c0 + lane] != 0)
                 {
-                    st.arrived[g] = 0;
+                    st.arrived[c0 + lane] = 0;
                     has_in = in_valid != 0;
                     cur = has_in ? in_value : 0.0;
                 }
@@ -234,14 +372,15 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 // (src/models.cpp:71-94): 0.0 + w_last, or plain 0.0 -- a value either way
                 has_in = true;
                 cur = 0.0;
-                const uint32_t last = st.ring_last[g];
+                const uint32_t last = st.ring_last[c0 + lane];
                 if (last != 0u)
                 {
-                    const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
+                    const uint32_t cr = (core != 0xffffffffu) ? core : im.wg_desc[wg].core;
+                    const unsigned long long pos = im.core_syn_base[cr] + (last - 1u);
                     const double w = (im.syn_format == 2) ? im.syn_weight[pos]
                                                           : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
                     cur = 0.0 + w;
-                    st.ring_last[g] = 0u;
+                    st.ring_last[c0 + lane] = 0u;
                 }
             }
             else
@@ -251,30 +390,28 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                 if (has_in)
                 {
                     cur = in_value;
-                    ring[g] = 0.0;
-                    rvalid[g] = 0;
+                    p_ring[lane] = 0.0;
+                    p_rvalid[lane] = 0;
                 }
             }
             // host-generated value of a sequential source this neuron consumes at every update
             // (Poisson draw, std::rand() & mask, noise file): include/sanafe_hip.h, slot_ext
-            bool has_ext = false;
-            int ext = 0;
-            if (ext_row != nullptr)
-            {
-                const uint32_t col = im.slot_ext[g];
-                has_ext = col != 0xffffffffu;
-                if (has_ext) ext = ext_row[col];
-            }
-            if (model == SANAFE_SOMA_LIF)
+            const bool has_ext = !UNI && ext_col != 0xffffffffu;
+            const int ext = has_ext ? sa.ext_row[ext_col] : 0;
+            sanafe_hip_soma_class p;
+            if (UNI) p = us.p;
+            else if (model == SANAFE_SOMA_INPUT) p = sanafe_hip_soma_class{};
+            else if (soma_lds) p = s_soma[cls >> 16];
+            else p = im.soma_classes[cls >> 16];
+            if ((MODEL == 0 || MODEL == SANAFE_SOMA_LIF) && model == SANAFE_SOMA_LIF)
             {
                 // LoihiLifModel::update, src/models.cpp:497-567
-                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
                 double v = v_in;
-                double ic = st.icur[g];
-                int rc = st.refrac[g];
+                double ic = ic_in;
+                int rc = rc_in;
                 status = 1;
                 if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
-                if (done > 0)
+                if (t > 1)
                 {
                     ic *= p.input_decay;
                     v *= p.leak_decay;
@@ -303,14 +440,13 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                     if (fired) status = 3;
                 }
                 rc = rc - 1 > 0 ? rc - 1 : 0;
-                st.v[g] = v;
-                st.icur[g] = ic;
-                st.refrac[g] = rc;
+                p_v[lane] = v;
+                p_icur[lane] = ic;
+                if (im.any_refrac) p_refrac[lane] = rc;
             }
-            else if (model == SANAFE_SOMA_TRUENORTH)
+            else if ((MODEL == 0 || MODEL == SANAFE_SOMA_TRUENORTH) && model == SANAFE_SOMA_TRUENORTH)
             {
                 // TrueNorthModel::update, src/models.cpp:724-830
-                const sanafe_hip_soma_class &p = im.soma_classes[cls >> 16];
                 double v = v_in;
                 status = 1;
                 if (fabs(v) > 0.0 || has_in || fabs(bias) > 0.0 || p.force_update) status = 2;
@@ -340,11 +476,11 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
                     else if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v += p.reverse_threshold;
                     else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
                 }
-                st.v[g] = v;
+                p_v[lane] = v;
             }
-            else // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903
+            else if (MODEL == 0) // SANAFE_SOMA_INPUT: InputModel::update, src/models.cpp:863-903
             {
-                const uint32_t a = im.slot_aux[g];
+                const uint32_t a = im.slot_aux[c0 + lane];
                 const uint32_t pos = st.in_pos[a];
                 bool send = false;
                 if (pos < im.in_train_len[a])
@@ -361,89 +497,78 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         }
         // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
         // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
-        if (live && model != SANAFE_SOMA_HOST) st.status[g] = (uint8_t) status;
-        if (stlog != nullptr && live) stlog[g] = (uint8_t) status;
+        const bool live = model != SANAFE_SOMA_NONE;
+        if (live && model != SANAFE_SOMA_HOST) st.status[c0 + lane] = (uint8_t) status;
+        if (sa.stlog != nullptr && live) sa.stlog[c0 + lane] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
+        if (lane == 0)
+        {
+            const uint32_t w = c0 >> 5;
+            st.bits_local[w] = (uint32_t) fired_mask;
+            st.bits_local[w + 1] = (uint32_t) (fired_mask >> 32);
+            if (sa.slog != nullptr)
+            {
+                sa.slog[w] = (uint32_t) fired_mask;
+                sa.slog[w + 1] = (uint32_t) (fired_mask >> 32);
+            }
+        }
         // ---- default costing, src/pipeline.hpp:574-731.  Counters and class costs are taken per wavefront from
-        //      ballots (no cross-lane reduction at the end); only what depends on the individual neuron -- the
-        //      static totals of a spike, or costs when the 64 neurons do not share one cost class -- is summed
-        //      per lane and reduced once, and only by wavefronts that saw such a case. ----
+        //      ballots; only what depends on the individual neuron -- the static totals of a spike, or costs when
+        //      the 64 neurons do not share one cost class -- is summed per lane and reduced once. ----
         const bool counted = (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST);
         const unsigned long long m_cnt = __ballot(counted);
         if (m_cnt != 0ull) // wave-uniform
         {
             const unsigned long long m_upd = __ballot(status >= 2);
-            w_upd += __popcll(m_upd);
-            w_fire += __popcll(fired_mask);
+            n_upd = __popcll(m_upd);
+            n_fire = __popcll(fired_mask);
             const uint32_t ccid = (cls >> 6) & 1023u;
-            const uint32_t cc0 = (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
-            if (__ballot(counted && ccid != cc0) == 0ull)
+            const uint32_t cc0 = UNI ? 0u : (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
+            if (UNI || __ballot(counted && ccid != cc0) == 0ull)
             {
-                const sanafe_hip_cost_class &c0 = im.cost_classes[cc0];
+                sanafe_hip_cost_class c0c;
+                if (UNI) c0c = us.c;
+                else if (cost_lds) c0c = s_cost[cc0];
+                else c0c = im.cost_classes[cc0];
                 const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_mask),
                              n_u = (double) __popcll(m_upd & ~fired_mask), n_i = (double) __popcll(m_cnt & ~m_upd);
-                w_e_soma += (n_i * c0.soma_energy[0] + n_u * c0.soma_energy[1]) + n_f * c0.soma_energy[2];
-                w_e_dend += n_all * c0.dendrite_energy;
-                w_lat += n_all * (0.0 + c0.dendrite_latency) + ((n_i * c0.soma_latency[0] + n_u * c0.soma_latency[1]) + n_f * c0.soma_latency[2]);
+                e_soma = (n_i * c0c.soma_energy[0] + n_u * c0c.soma_energy[1]) + n_f * c0c.soma_energy[2];
+                e_dend = n_all * c0c.dendrite_energy;
+                lat = n_all * (0.0 + c0c.dendrite_latency) + ((n_i * c0c.soma_latency[0] + n_u * c0c.soma_latency[1]) + n_f * c0c.soma_latency[2]);
             }
             else
             {
-                mixed = true;
+                double le_soma = 0.0, le_dend = 0.0, l_lat = 0.0;
                 if (counted)
                 {
-                    const sanafe_hip_cost_class &cc = im.cost_classes[ccid];
-                    e_dend += cc.dendrite_energy;
-                    e_soma += cc.soma_energy[status - 1];
-                    lat += (0.0 + cc.dendrite_latency) + cc.soma_latency[status - 1];
+                    // (static indices + selects: a runtime index into a by-value copy would go to scratch)
+                    const sanafe_hip_cost_class cc = cost_lds ? s_cost[ccid] : im.cost_classes[ccid];
+                    le_dend = cc.dendrite_energy;
+                    le_soma = status == 1 ? cc.soma_energy[0] : status == 2 ? cc.soma_energy[1] : cc.soma_energy[2];
+                    l_lat = (0.0 + cc.dendrite_latency) +
+                            (status == 1 ? cc.soma_latency[0] : status == 2 ? cc.soma_latency[1] : cc.soma_latency[2]);
                 }
+                e_soma = wave_sum(le_soma);
+                e_dend = wave_sum(le_dend);
+                lat = wave_sum(l_lat);
             }
             if (fired_mask != 0ull)
             {
-                any_fire = true;
-                if (status == 3 && counted)
-                {
-                    // everything this spike causes downstream is static per neuron
-                    // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
-                    n_pack += im.slot_packets[g];
-                    n_hops += im.slot_hops[g];
-                    n_ev += im.slot_events[g];
-                    e_net += im.slot_e_net[g];
-                    e_syn += im.slot_e_syn[g];
-                    e_dspk += im.slot_e_dend[g];
-                }
-            }
-        }
-        if (lane == 0)
-        {
-            const uint32_t w = (nbase + off) >> 5;
-            st.bits_local[w] = (uint32_t) fired_mask;
-            st.bits_local[w + 1] = (uint32_t) (fired_mask >> 32);
-            if (record)
-            {
-                slog[w] = (uint32_t) fired_mask;
-                slog[w + 1] = (uint32_t) (fired_mask >> 32);
+                // everything this spike causes downstream is static per neuron
+                // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
+                SpikeStatic ss{};
+                if (status == 3 && counted) ss = im.slot_spike[c0 + lane];
+                // messages and hops of a chunk fit 24 + 40 bits: one integer reduction for both
+                const long long ph = wave_sum((long long) (((unsigned long long) ss.packets << 40) | (unsigned long long) ss.hops));
+                n_pack = (long long) ((unsigned long long) ph >> 40);
+                n_hops = (long long) ((unsigned long long) ph & ((1ull << 40) - 1ull));
+                n_ev = wave_sum((long long) ss.events);
+                if (im.spike_energy & 1) e_syn = wave_sum(ss.e_syn);
+                if (im.spike_energy & 2) e_net = wave_sum(ss.e_net);
+                if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
             }
         }
     }
-    if (mixed)
-    {
-        w_e_soma += wave_sum(e_soma);
-        w_e_dend += wave_sum(e_dend);
-        w_lat += wave_sum(lat);
-    }
-    if (any_fire)
-    {
-        e_syn = wave_sum(e_syn);
-        e_net = wave_sum(e_net);
-        w_e_dend += wave_sum(e_dspk);
-        n_pack = wave_sum(n_pack);
-        n_hops = wave_sum(n_hops);
-        n_ev = wave_sum(n_ev);
-    }
-    e_soma = w_e_soma;
-    e_dend = w_e_dend;
-    lat = w_lat;
-    const long long n_upd = w_upd, n_fire = w_fire;
     if (lane == 0)
     {
         s_d[wave][0] = e_soma;
@@ -458,31 +583,23 @@ __global__ void __launch_bounds__(NEURON_BLOCK) neuron_kernel(DevImage im, DevSt
         s_l[wave][4] = n_ev;
     }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x < 10)
     {
-        double d[5] = {0, 0, 0, 0, 0};
-        long long l[5] = {0, 0, 0, 0, 0};
-        for (int w = 0; w < NEURON_BLOCK / WAVE; w++) // fixed order: deterministic
-            for (int k = 0; k < 5; k++)
-            {
-                d[k] += s_d[w][k];
-                l[k] += s_l[w][k];
-            }
-        CorePart cp;
-        cp.e_soma = d[0];
-        cp.e_dend = d[1];
-        cp.e_syn = d[2];
-        cp.e_net = d[3];
-        // sum of Message::generation_delay over the core's messages incl. the placeholder
-        // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81)
-        cp.gen_sum = d[4] + (double) l[2] * im.core_axon_out_latency[core];
-        cp.updated = l[0];
-        cp.fired = l[1];
-        cp.packets = l[2];
-        cp.hops = l[3];
-        cp.events = l[4];
-        st.core_part[parity_off + core] = cp;
-        st.core_proc[parity_off + core] = 0.0; // the delivery slices of this step add their processing delays
+        // ten lanes, one field each: the waves are combined in a fixed order (deterministic)
+        const int k = (int) threadIdx.x;
+        WgPart *out = st.wg_part + (size_t) sa.parity * im.n_wgs + wg;
+        if (k < 5)
+        {
+            double d = 0.0;
+            for (uint32_t w = 0; w < nchunks; w++) d += s_d[w][k];
+            reinterpret_cast<double *>(out)[k] = d;
+        }
+        else
+        {
+            long long l = 0;
+            for (uint32_t w = 0; w < nchunks; w++) l += s_l[w][k - 5];
+            reinterpret_cast<long long *>(out)[k] = l;
+        }
     }
 }
 
@@ -547,25 +664,25 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     const uint32_t slice = blockIdx.x;
-    const uint32_t core = im.slice_core[slice];
-    const uint32_t ncount = im.core_ncount[core];
+    const SliceDesc sd = im.slice_desc[slice];
+    const uint32_t ncount = sd.ncount;
     const uint32_t npad = (ncount + 63u) & ~63u;
-    const uint32_t nbase = im.core_nbase[core];
+    const uint32_t nbase = sd.nbase;
     const uint32_t R = im.ring_slots;
     const uint32_t D = HAS_DELAY ? im.delay_slots : 1u; // LDS holds one accumulator row per delay value in use
     // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
     // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
     const uint32_t RS = (SYN_FMT == 0) ? npad + 1u : npad;
     const long long t = done + 1;
-    const unsigned long long a_beg = im.slice_axon_beg[slice];
-    const uint32_t n_ax = (uint32_t) (im.slice_axon_end[slice] - a_beg); // slices hold < 2^32 axons
-    const unsigned long long syn_base = im.core_syn_base[core];
-    const double ain_lat = im.core_axon_in_latency[core];
-    const bool compact = im.slice_mode[slice] != 0; // workgroup-uniform
-    const unsigned char *rec = im.ax_bytes + im.slice_rec_off[slice];
-    const uint32_t *chunk_syn0 = im.chunk_syn0 + im.slice_chunk0[slice];
-    const uint32_t *chunk_pre0 = im.chunk_pre0 + im.slice_chunk0[slice];
-    const double slice_lat = im.lat_class[im.slice_lat_class[slice]];
+    const unsigned long long a_beg = sd.a_beg;
+    const uint32_t n_ax = sd.n_ax; // slices hold < 2^32 axons
+    const unsigned long long syn_base = sd.syn_base;
+    const double ain_lat = sd.ain_lat;
+    const bool compact = sd.mode != 0; // workgroup-uniform
+    const unsigned char *rec = im.ax_bytes + sd.rec_off;
+    const uint32_t *chunk_syn0 = im.chunk_syn0 + sd.chunk0;
+    const uint32_t *chunk_pre0 = im.chunk_pre0 + sd.chunk0;
+    const double slice_lat = sd.slice_lat;
     double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
     // Which accumulators received a synaptic event (the buffer holds a value, even a zero one: src/chip.cpp:759)?
     // Integer-weight formats start every accumulator at -0.0, which no addition of weights can produce again;
@@ -573,28 +690,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
-    const uint32_t core_inkind = (im.slot_cls[nbase] >> 3) & 7u;  // the buffer position belongs to the core
+    const uint32_t core_inkind = sd.inkind;  // the buffer position belongs to the core
     const bool last_mode = LAST && core_inkind == SANAFE_IN_LAST; // workgroup-uniform
 
     uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
-
-    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
-    {
-        if (LAST && last_mode)
-        {
-            reinterpret_cast<unsigned long long *>(acc)[i] = 0ull; // two `lastv` entries
-        }
-        else if (TOUCH_BYTES)
-        {
-            acc[i] = 0.0;
-            touched[i] = 0;
-        }
-        else
-        {
-            reinterpret_cast<unsigned long long *>(acc)[i] = ACC_UNTOUCHED;
-        }
-    }
-    __syncthreads();
 
     double proc = 0.0;
     const uint32_t *bits = st.bits_global;
@@ -698,6 +797,24 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         decode_and_probe(c0);
         if (c0 + stride < n_ax) load4(c0 + stride + (uint32_t) lane * AX_PER_THREAD, cur);
     }
+    // The accumulators are cleared while the first records and bitmap words are in flight.
+    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
+    {
+        if (LAST && last_mode)
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = 0ull; // two `lastv` entries
+        }
+        else if (TOUCH_BYTES)
+        {
+            acc[i] = 0.0;
+            touched[i] = 0;
+        }
+        else
+        {
+            reinterpret_cast<unsigned long long *>(acc)[i] = ACC_UNTOUCHED;
+        }
+    }
+    __syncthreads();
     for (; c0 < n_ax; c0 += stride)
     {
         if (SYN_FMT == 0 && hot) stream_preload();
@@ -909,9 +1026,19 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         }
         wave_lds_fence(); // the lists are rewritten by the next chunk
     }
+    // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
+    proc = wave_sum(proc);
+    if (lane == 0) s_red[wave] = proc;
     __syncthreads();
-    // ---- write the accumulated charge back (one RMW per touched neuron and delay value) ----
-    const bool shared_core = (im.core_slice_beg[core + 1] - im.core_slice_beg[core]) > 1;
+    if (threadIdx.x == 0)
+    {
+        double p = 0.0;
+        for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
+        // one value per slice; level 1 of the step reduction adds a core's slices in order (reproducible)
+        st.slice_proc[(size_t) (done & 1) * im.n_slices + slice] = p;
+    }
+    // ---- write the accumulated charge back (one access per touched neuron and delay value) ----
+    const bool shared_core = sd.shared != 0;
     if (LAST && last_mode)
     {
         // the latest event over all slices of the core wins: positions grow in delivery order
@@ -936,60 +1063,124 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         const bool gated = post_kind == SANAFE_IN_GATED; // a neuron behind a gated delay line
         const uint32_t wslot = (uint32_t) ((t + 1 + d + (gated ? 1 : 0)) % R);
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
+        // Without synaptic delays all charge for step t+1 arrives in step t and the neuron launch of step t left
+        // every consumed entry at 0.0: a core with one slice stores, it need not read.
         if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
+        else if (!HAS_DELAY) st.ring[gi] = acc[i];
         else st.ring[gi] += acc[i];
         st.ring_valid[gi] = 1;
         if (gated) st.arrived[nbase + n] = 1;
     }
-    // ---- processing-delay sum of this slice (simple timing model) ----
-    proc = wave_sum(proc);
-    if (lane == 0) s_red[wave] = proc;
-    __syncthreads();
-    if (threadIdx.x == 0)
+}
+
+// ---------------------------------------------------------------------------------------
+// K3: per-step reduction in two levels (see PendStep), every association fixed: results are reproducible
+// run to run.  sim_calculate_ts_energy, sim_update_ts_counters, schedule_messages_timestep_simple
+// (src/chip.cpp:1028-1051, 1171-1261; src/schedule.cpp:61-102), update_run_data (src/chip.cpp:462-475).
+// ---------------------------------------------------------------------------------------
+// Level 1: one wavefront folds 64 consecutive cores, one core per lane.  Per core: its neuron workgroups'
+// partials in workgroup order, the generation-delay sum of its messages incl. the placeholder
+// (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81) and the processing-delay sum of its
+// delivery slices in slice (= reference delivery) order.
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+    const uint32_t c = group * WAVE + (uint32_t) lane;
+    double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gen = 0, proc = 0;
+    long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
+    if (c < im.n_cores)
     {
-        double p = 0.0;
-        for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
-        // one add per slice; the order over a core's slices is not fixed, which moves the simple
-        // timing model's per-core sum by at most an ulp or two (tolerance on sim_time is 1e-6)
-        atomicAdd(&st.core_proc[(uint32_t) (done & 1) * im.n_cores + core], p);
+        const WgPart *part = st.wg_part + (size_t) parity * im.n_wgs;
+        const uint32_t w0 = im.core_wg_beg[c], w1 = im.core_wg_beg[c + 1];
+        const uint32_t s0 = im.core_slice_beg[c], s1 = im.core_slice_beg[c + 1];
+        const double out_lat = im.core_axon_out_latency[c];
+        double lat = 0;
+        for (uint32_t w = w0; w < w1; w++)
+        {
+            const WgPart p = part[w];
+            e_soma += p.e_soma;
+            e_dend += p.e_dend;
+            e_syn += p.e_syn;
+            e_net += p.e_net;
+            lat += p.lat;
+            upd += p.updated;
+            fired += p.fired;
+            packets += p.packets;
+            hops += p.hops;
+            events += p.events;
+        }
+        gen = lat + (double) packets * out_lat;
+        // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
+        const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
+        if (s1 - s0 <= 2u)
+        {
+            for (uint32_t s = s0; s < s1; s++) proc += sp[s];
+        }
+        else
+        {
+            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t s = s0;
+            for (; s + 8u <= s1; s += 8u)
+            {
+#pragma unroll
+                for (int j = 0; j < 8; j++) a[j] += sp[s + j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (s + j < s1) a[j] += sp[s + j];
+            proc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+        }
+    }
+    e_soma = wave_sum(e_soma);
+    e_dend = wave_sum(e_dend);
+    e_syn = wave_sum(e_syn);
+    e_net = wave_sum(e_net);
+    upd = wave_sum(upd);
+    fired = wave_sum(fired);
+    packets = wave_sum(packets);
+    hops = wave_sum(hops);
+    events = wave_sum(events);
+    const double gmax = wave_max(gen), pmax = wave_max(proc);
+    if (lane == 0)
+    {
+        GroupPart gp;
+        gp.e_soma = e_soma;
+        gp.e_dend = e_dend;
+        gp.e_syn = e_syn;
+        gp.e_net = e_net;
+        gp.gmax = gmax;
+        gp.pmax = pmax;
+        gp.updated = upd;
+        gp.fired = fired;
+        gp.packets = packets;
+        gp.hops = hops;
+        gp.events = events;
+        st.group_part[(size_t) parity * im.n_groups + group] = gp;
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// K3: per-step reduction (one workgroup, fixed summation order): inside the next neuron launch, or reduce_kernel
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_max(double x)
+// Level 2: one wavefront folds the groups (lane = group, further groups in rounds of 64) into the Timestep
+// totals, applies the simple timing model, accumulates RunData and writes the step record.
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) x = fmax(x, __shfl_xor(x, o, WAVE));
-    return x;
-}
-
-// One 256-thread workgroup reduces a finished step: per-thread partial over its cores -> wave reduction (shuffles)
-// -> one LDS slot per wave -> thread 0 combines the waves in order.  One barrier; the association is fixed, so
-// results are reproducible.  sim_calculate_ts_energy, sim_update_ts_counters, schedule_messages_timestep_simple
-// (src/chip.cpp:1028-1051, 1171-1261; src/schedule.cpp:61-102), update_run_data (src/chip.cpp:462-475).
-__device__ void reduce_step(const DevImage &im, const DevState &st, const PrevStep &prev, double (*sd)[6], long long (*sl)[5])
-{
-    const int simple_timing = prev.simple_timing, record = prev.record;
-    const CorePart *core_part = st.core_part + (size_t) prev.parity * im.n_cores;
-    const double *core_proc = st.core_proc + (size_t) prev.parity * im.n_cores;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const GroupPart *gp = st.group_part + (size_t) prev.parity * im.n_groups;
     double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
     long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
-    for (uint32_t c = threadIdx.x; c < im.n_cores; c += REDUCE_BLOCK)
+    for (uint32_t g = (uint32_t) lane; g < im.n_groups; g += WAVE)
     {
-        const CorePart cp = core_part[c];
-        e_soma += cp.e_soma;
-        e_dend += cp.e_dend;
-        e_syn += cp.e_syn;
-        e_net += cp.e_net;
-        upd += cp.updated;
-        fired += cp.fired;
-        packets += cp.packets;
-        hops += cp.hops;
-        events += cp.events;
-        gmax = fmax(gmax, cp.gen_sum);
-        pmax = fmax(pmax, core_proc[c]);
+        const GroupPart p = gp[g];
+        e_soma += p.e_soma;
+        e_dend += p.e_dend;
+        e_syn += p.e_syn;
+        e_net += p.e_net;
+        gmax = fmax(gmax, p.gmax);
+        pmax = fmax(pmax, p.pmax);
+        upd += p.updated;
+        fired += p.fired;
+        packets += p.packets;
+        hops += p.hops;
+        events += p.events;
     }
     e_soma = wave_sum(e_soma);
     e_dend = wave_sum(e_dend);
@@ -1002,44 +1193,7 @@ __device__ void reduce_step(const DevImage &im, const DevState &st, const PrevSt
     packets = wave_sum(packets);
     hops = wave_sum(hops);
     events = wave_sum(events);
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
     if (lane == 0)
-    {
-        sd[wave][0] = e_soma;
-        sd[wave][1] = e_dend;
-        sd[wave][2] = e_syn;
-        sd[wave][3] = e_net;
-        sd[wave][4] = gmax;
-        sd[wave][5] = pmax;
-        sl[wave][0] = upd;
-        sl[wave][1] = fired;
-        sl[wave][2] = packets;
-        sl[wave][3] = hops;
-        sl[wave][4] = events;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        e_soma = e_dend = e_syn = e_net = 0.0;
-        upd = fired = packets = hops = events = 0;
-        gmax = sd[0][4];
-        pmax = sd[0][5];
-        for (int w = 0; w < REDUCE_BLOCK / WAVE; w++)
-        {
-            e_soma += sd[w][0];
-            e_dend += sd[w][1];
-            e_syn += sd[w][2];
-            e_net += sd[w][3];
-            gmax = fmax(gmax, sd[w][4]);
-            pmax = fmax(pmax, sd[w][5]);
-            upd += sl[w][0];
-            fired += sl[w][1];
-            packets += sl[w][2];
-            hops += sl[w][3];
-            events += sl[w][4];
-        }
-    }
-    if (threadIdx.x == 0)
     {
         sanafe_hip_totals ts;
         ts.timesteps = 1;
@@ -1053,7 +1207,10 @@ __device__ void reduce_step(const DevImage &im, const DevState &st, const PrevSt
         ts.soma_energy = e_soma;
         ts.network_energy = e_net;
         ts.total_energy = ((e_net + e_syn) + e_dend) + e_soma;
-        ts.sim_time = simple_timing ? fmax(pmax, gmax) + im.sync_delay : 0.0;
+        // multi-GPU: the largest per-core delay of THIS rank; the host library takes the maximum over the ranks
+        // before adding the sync delay (record bit 2: keep the raw maximum in the step record)
+        const double local_max = fmax(pmax, gmax);
+        ts.sim_time = prev.simple_timing ? local_max + im.sync_delay : 0.0;
         sanafe_hip_totals r = *st.run; // update_run_data, src/chip.cpp:462-475
         r.timesteps += 1;
         r.spikes += ts.spikes;
@@ -1068,14 +1225,24 @@ __device__ void reduce_step(const DevImage &im, const DevState &st, const PrevSt
         r.network_energy += ts.network_energy;
         r.sim_time += ts.sim_time;
         *st.run = r;
-        if (record)
+        if (prev.record)
         {
             ts.timesteps = *st.t + 1; // the record carries the timestep number
             st.step_log[prev.rec_index % st.log_cap] = ts;
             *st.rec = prev.rec_index + 1;
         }
+        if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;
     }
+}
+
+// Flushes pending reductions when no further neuron launch follows: grid = n_reduce_wgs (or 1 for level 2 only).
+__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PendStep l1, PendStep l2)
+{
+    const int wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
+    const uint32_t group = blockIdx.x * (REDUCE_BLOCK / WAVE) + (uint32_t) wave;
+    if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group);
 }
 
 // `taps` dendrites, after the delivery launch of step t (one thread per neuron): advance the RC line by one step
@@ -1122,14 +1289,6 @@ __global__ void taps_kernel(DevImage im, DevState st, long long done /* steps si
         st.ring[gi] = v[0];
         st.ring_valid[gi] = 1;
     }
-}
-
-// Flushes the reduction of the last launched step when no further neuron launch follows it.
-__global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PrevStep prev)
-{
-    __shared__ double sd[REDUCE_BLOCK / WAVE][6];
-    __shared__ long long sl[REDUCE_BLOCK / WAVE][5];
-    reduce_step(im, st, prev, sd, sl);
 }
 
 __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, double *cur, uint8_t *has,
@@ -1188,6 +1347,10 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
     }
 }
 
+// Status, energy and latency of the host-evaluated (plugin) somas of one step, folded into the partial of the
+// first neuron workgroup of each neuron's core.  The neuron kernel skipped these slots entirely, so the
+// dendrite's per-update cost of the neuron-processing pipeline (buffer before or inside the dendrite unit,
+// src/pipeline.hpp:574-629) is added here as well.
 __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status,
         const uint32_t *core, const double *energy, const double *latency, int parity)
 {
@@ -1196,20 +1359,22 @@ __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, con
     const uint32_t g = slots[i];
     const uint8_t s = status[i];
     st.status[g] = s;
-    CorePart *cp = st.core_part + (size_t) parity * im.n_cores + core[i];
+    const sanafe_hip_cost_class &cc = im.cost_classes[(im.slot_cls[g] >> 6) & 1023u];
+    WgPart *cp = st.wg_part + (size_t) parity * im.n_wgs + im.core_wg_beg[core[i]];
     atomicAdd(&cp->e_soma, energy[i]);
-    atomicAdd(&cp->gen_sum, latency[i]);
+    atomicAdd(&cp->e_dend, cc.dendrite_energy);
+    atomicAdd(&cp->lat, (0.0 + cc.dendrite_latency) + latency[i]);
     if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
     if (s == 3)
     {
+        const SpikeStatic ss = im.slot_spike[g];
         atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
         atomicAdd((unsigned long long *) &cp->fired, 1ull);
-        atomicAdd((unsigned long long *) &cp->packets, (unsigned long long) im.slot_packets[g]);
-        atomicAdd((unsigned long long *) &cp->hops, (unsigned long long) im.slot_hops[g]);
-        atomicAdd((unsigned long long *) &cp->events, (unsigned long long) im.slot_events[g]);
-        atomicAdd(&cp->e_net, im.slot_e_net[g]);
-        atomicAdd(&cp->e_syn, im.slot_e_syn[g]);
-        atomicAdd(&cp->e_dend, im.slot_e_dend[g]);
-        atomicAdd(&cp->gen_sum, (double) im.slot_packets[g] * im.core_axon_out_latency[core[i]]);
+        atomicAdd((unsigned long long *) &cp->packets, (unsigned long long) ss.packets);
+        atomicAdd((unsigned long long *) &cp->hops, (unsigned long long) ss.hops);
+        atomicAdd((unsigned long long *) &cp->events, (unsigned long long) ss.events);
+        atomicAdd(&cp->e_net, ss.e_net);
+        atomicAdd(&cp->e_syn, ss.e_syn);
+        atomicAdd(&cp->e_dend, ss.e_dend);
     }
 }

@@ -439,7 +439,11 @@ struct sanafe_chip
             h_status[i] = static_cast<uint8_t>(r.status);
             h_energy[i] = *r.energy;
             h_latency[i] = *r.latency;
-            if (!slot_lat[0].empty()) slot_lat[k][mc.slot_offset + hn.slot] = *r.latency; // exact generation delays (detailed model)
+            if (!slot_lat[0].empty()) // exact generation delays (detailed model): dendrite of the neuron pipeline + the soma
+            {
+                const sanafe_hip_cost_class &cc = mc.cost_classes[(mc.slot_cls[hn.slot] >> 6) & 1023u];
+                slot_lat[k][mc.slot_offset + hn.slot] = (0.0 + cc.dendrite_latency) + *r.latency;
+            }
         }
     }
 
