@@ -92,24 +92,69 @@ def build_c4(S, n_gpus, rank, tiles_per_gpu, seed):
     return arch, net
 
 
+def host_info():
+    """CPU model, physical cores, logical CPUs and RAM of the machine the baseline is timed on."""
+    model, phys = "unknown", set()
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    ram = 0
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemTotal"):
+                ram = int(line.split()[1]) * 1024
+    except OSError:
+        pass
+    return {"cpu_model": model, "physical_cores": len(phys) or None, "logical_cpus": os.cpu_count(),
+            "usable_cpus": len(os.sched_getaffinity(0)), "ram_bytes": ram}
+
+
+def _time_oracle(chip, timing, seconds, repeats=3):
+    """`repeats` timed windows of seconds/repeats each; returns the window with the MEDIAN step rate."""
+    for _ in range(3):
+        chip.step(timing)
+    runs = []
+    for _ in range(repeats):
+        steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
+        while time.perf_counter() - t0 < seconds / repeats:
+            r = chip.step(timing)
+            steps += 1
+            events += r["spike_count"]
+            updates += r["neurons_updated"]
+        dt = time.perf_counter() - t0
+        runs.append(dict(steps=steps, seconds=dt, events_per_s=events / dt, updates_per_s=updates / dt, steps_per_s=steps / dt))
+    runs.sort(key=lambda r: r["steps_per_s"])
+    med = runs[len(runs) // 2]
+    med["all_steps_per_s"] = [r["steps_per_s"] for r in runs]
+    return med
+
+
 def cpu_baseline_same_net(S, args, arch, net, what):
     """The oracle on the very network the GPU ran (small configurations), for about --cpu-seconds."""
     from oracle.oracle import OracleChip
     lower = S.cpp.to_desc if isinstance(net, S.cpp.Network) else S.to_desc
     chip = OracleChip(lower(arch, net))
     timing = args.timing
-    for _ in range(3):
-        chip.step(timing)
-    steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        r = chip.step(timing)
-        steps += 1
-        events += r["spike_count"]
-        updates += r["neurons_updated"]
-    dt = time.perf_counter() - t0
-    return {"value": steps / dt, "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": "oracle (scalar C++ port, 1 thread), %s timing, on %s: %d steps in %.1f s" % (timing, what, steps, dt),
-            "measured": {"synaptic_events_per_s": events / dt, "neuron_updates_per_s": updates / dt}}
+    m = _time_oracle(chip, timing, args.cpu_seconds)
+    return {"value": m["steps_per_s"], "unit": "timesteps/s", "cores": 1, "kind": "port",
+            "sample": "oracle (scalar C++ port, 1 thread), %s timing, on %s: median of 3 windows (%d steps in %.1f s)"
+                      % (timing, what, m["steps"], m["seconds"]),
+            "host": host_info(),
+            "measured": {"synaptic_events_per_s": m["events_per_s"], "neuron_updates_per_s": m["updates_per_s"],
+                         "timesteps_per_s_windows": m["all_steps_per_s"]}}
 
 
 def cpu_baseline(S, args):
@@ -131,18 +176,10 @@ def cpu_baseline(S, args):
     for c in range(cores):
         g.map_to_core(ac[c], c * npc, (c + 1) * npc)
     chip = OracleChip(S.cpp.to_desc(arch, net))
-    for _ in range(3):
-        chip.step("simple")
-    steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
-    while time.perf_counter() - t0 < args.cpu_seconds:
-        r = chip.step("simple")
-        steps += 1
-        events += r["spike_count"]
-        updates += r["neurons_updated"]
-    dt = time.perf_counter() - t0
-    return dict(steps=steps, seconds=dt, events_per_s=events / dt, updates_per_s=updates / dt, steps_per_s=steps / dt,
-                sample="oracle (scalar C++ port, 1 thread) on %d LIF neurons / %d cores, out-degree %d, %d steps in %.1f s"
-                       % (n, cores, deg, steps, dt))
+    m = _time_oracle(chip, "simple", args.cpu_seconds)
+    m["sample"] = ("oracle (scalar C++ port, 1 thread) on %d LIF neurons / %d cores, out-degree %d: median of 3 windows "
+                   "(%d steps in %.1f s)" % (n, cores, deg, m["steps"], m["seconds"]))
+    return m
 
 
 def main():
@@ -222,73 +259,27 @@ def main():
 
     dist = None
     multi = world > 1 or args.force_dist
-    if multi and args.exchange == "host":
-        import torch
+    if multi:
+        # Control plane (rendezvous, barrier, max-over-ranks of the wall time): torch.distributed over gloo.
+        # Data plane: the product's own per-step spike exchange inside chip.sim() -- RCCL all-gather on the device
+        # bitmap (host/comm.cpp), or the host callback path for two ranks sharing one GPU (--exchange host).
         import torch.distributed as dist_mod
         dist = dist_mod
         dist.init_process_group("gloo")
-        bufs = chip.spike_buffers()
-        h_local = torch.zeros(bufs["local_bytes"], dtype=torch.uint8)
-        h_global = torch.zeros(bufs["global_bytes"], dtype=torch.uint8)
-
-        def run_steps(k):
-            for _ in range(k):
-                chip.step_neurons()
-                assert H.sanafe_hip_export_spikes(dev, h_local.data_ptr()) == 0
-                dist.all_gather_into_tensor(h_global, h_local)
-                assert H.sanafe_hip_import_spikes(dev, h_global.data_ptr()) == 0
-                chip.step_deliver("simple")
-
-        def sync():
-            chip.synchronize()
-    elif multi:
-        import torch
-        import torch.distributed as dist_mod
-        dist = dist_mod
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        stream = torch.cuda.current_stream()
-        assert H.sanafe_hip_set_stream(dev, C.c_void_p(stream.cuda_stream)) == 0
-        bufs = chip.spike_buffers()
-
-        class _Dev:
-            def __init__(self, ptr, nbytes):
-                self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
-
-        t_local = torch.as_tensor(_Dev(bufs["local_ptr"], bufs["local_bytes"]), device="cuda")
-        t_global = torch.as_tensor(_Dev(bufs["global_ptr"], bufs["global_bytes"]), device="cuda")
-        assert bufs["global_bytes"] == bufs["local_bytes"] * world, "ranks must hold equal slot counts"
-
-        def run_steps(k):
-            for _ in range(k):
-                chip.step_neurons()
-                dist.all_gather_into_tensor(t_global, t_local)  # RCCL over xGMI: the per-step spike exchange
-                chip.step_deliver("simple")
-
-        def sync():
-            torch.cuda.synchronize()
-    elif args.timing == "detailed":
+        chip.comm_init_torch(dist, "rccl" if args.exchange == "nccl" else "host")
+    if args.timing == "detailed":
         L = S.chip.lib()
         L.sanafe_chip_set_scheduler_threads(chip._h, args.scheduler_threads)
 
-        def run_steps(k):
-            # GPU steps + host NoC schedule on scheduler threads; returns when both are done.  The stepwise
-            # loop restarts the device totals every step, so the counts come from the returned RunData.
-            return chip.run(k, "detailed")
+    def run_steps(k):
+        # one SpikingChip.sim-level call: on N ranks it returns the totals of the WHOLE chip on every rank
+        return chip.run(k, args.timing)
 
-        def sync():
-            chip.synchronize()
-    else:
-        def run_steps(k):
-            if H.sanafe_hip_step(dev, k, 1, 0) != 0:
-                raise RuntimeError(H.sanafe_hip_last_error().decode())
-
-        def sync():
-            chip.synchronize()
+    def sync():
+        chip.synchronize()
 
     run_steps(args.warmup)
     sync()
-    before = chip.read_totals()
     if dist:
         dist.barrier()
     sync()
@@ -298,31 +289,19 @@ def main():
     if dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    after = chip.read_totals()
-    local = {k: after[k] - before[k] for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")}
-    if run_data is not None:
-        local = {k: run_data[k] for k in local}
+    agg = {k: float(run_data[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")}
     if dist:
         import torch
-        t = torch.tensor([elapsed] + [float(local[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")],
-                         dtype=torch.float64, device="cuda" if args.exchange == "nccl" else "cpu")
-        tmax = t.clone()
+        tmax = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
         elapsed = float(tmax[0])
-        agg = dict(zip(("spikes", "packets_sent", "neurons_updated", "neurons_fired"), [float(x) for x in t[1:]]))
-    else:
-        agg = {k: float(v) for k, v in local.items()}
 
-    # ---- roofline pass: HIP events around every kernel on its own stream (single-GPU path) ----
+    # ---- roofline pass: HIP events around every kernel on its own stream (one rank, the chip's own stream) ----
     roof = None
-    if args.timed_steps > 0 and args.timing == "simple":
+    if args.timed_steps > 0 and args.timing == "simple" and not multi:
         H.sanafe_hip_set_timing(dev, 1)
         b2 = chip.read_totals()
-        if multi:
-            run_steps(args.timed_steps)  # the same exchange loop, with events around this rank's kernels
-            sync()
-        elif H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
+        if H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
             raise RuntimeError(H.sanafe_hip_last_error().decode())
         a2 = chip.read_totals()
         nm, dm, rm, ln = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
@@ -331,22 +310,42 @@ def main():
         ev = (a2["spikes"] - b2["spikes"]) / args.timed_steps
         msgs = (a2["packets_sent"] - b2["packets_sent"]) / args.timed_steps
         upd = (a2["neurons_updated"] - b2["neurons_updated"]) / args.timed_steps
-        # 48 B per neuron update, 28 B per synaptic event, 96 B per message.
-        # The delivery kernel does the per-event and per-message work, the neuron kernel the per-neuron work.
+        fired = (a2["neurons_fired"] - b2["neurons_fired"]) / args.timed_steps
+        # (1) the contract's figure -- SURVEY 8(d): 48 B per neuron update, 28 B per synaptic event, 96 B per message.
+        #     The delivery kernel does the per-event and per-message work, the neuron kernel the per-neuron work.
         deliver_bytes = 28.0 * ev + 96.0 * msgs
         achieved = deliver_bytes / (dm.value * 1e-3) / 1e9 if dm.value > 0 else 0.0
+        # (2) what THIS design has to move per launch, from the chip's own layout (sanafe_hip_layout_bytes):
+        #     delivery = synapse words + axon records + chunk tables + slice descriptors + spike bitmap, each read once
+        #     when every chunk is streamed (an upper bound when few axons spike), + one 17-byte write-back per neuron;
+        #     neuron launch = per-slot state read + written, + 40 B per fired neuron.
+        lay = (C.c_uint64 * 8)()
+        H.sanafe_hip_layout_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        if H.sanafe_hip_layout_bytes(dev, lay, 8) != 0:
+            raise RuntimeError(H.sanafe_hip_last_error().decode())
+        lay = [int(x) for x in lay]
+        design_deliver = float(sum(lay[0:5])) + 17.0 * upd
+        design_neuron = float(lay[5] + lay[6]) + lay[7] * fired
         roof = {"bound": "hbm", "kernel": "deliver_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "algorithmic_bytes_per_launch": deliver_bytes, "avg_launch_ms": dm.value,
+                "design_bytes_per_launch": design_deliver,
+                "design_bytes_parts": {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
+                                       "slice_descriptors": lay[3], "spike_bitmap": lay[4], "write_back": 17.0 * upd},
+                "frac_design": design_deliver / (dm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if dm.value > 0 else 0.0,
                 "neuron_kernel": {"avg_launch_ms": nm.value, "algorithmic_bytes_per_launch": 48.0 * upd,
-                                  "achieved_GBps": (48.0 * upd) / (nm.value * 1e-3) / 1e9 if nm.value > 0 else 0.0},
+                                  "achieved_GBps": (48.0 * upd) / (nm.value * 1e-3) / 1e9 if nm.value > 0 else 0.0,
+                                  "frac": (48.0 * upd) / (nm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if nm.value > 0 else 0.0,
+                                  "design_bytes_per_launch": design_neuron,
+                                  "frac_design": design_neuron / (nm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if nm.value > 0 else 0.0},
                 "reduce_kernel_avg_ms": rm.value, "launches": ln.value,
                 "whole_step": {"algorithmic_bytes": 48.0 * upd + deliver_bytes,
                                "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
 
     if roof is not None:
-        # HBM bytes per launch from the PMC passes of this very workload (profiles/collect.sh, summarize.py):
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE.
+        # (3) HBM bytes per launch as the PMC counters saw them on this very workload (profiles/collect.sh,
+        #     summarize.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; separate
+        #     --pmc passes, so they come from an earlier run of the same command -- source and date are given).
         import glob
         newest = -1
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
@@ -358,25 +357,34 @@ def main():
                     newest = summ.get("collected_unix", 0)
                     roof["traffic"] = summ["kernels"]["deliver_kernel"]["hbm_bytes_per_launch"]
                     roof["traffic_source"] = os.path.relpath(path, ROOT)
+                    roof["traffic_collected_utc"] = time.strftime("%Y-%m-%d %H:%M", time.gmtime(newest)) if newest > 0 else None
+                    nk = summ["kernels"].get("neuron_kernel", {})
+                    if "hbm_bytes_per_launch" in nk:
+                        roof["neuron_kernel"]["traffic"] = nk["hbm_bytes_per_launch"]
             except (KeyError, TypeError, ValueError, OSError):
                 continue
         if roof["traffic"]:
             roof["traffic_GBps"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
             roof["traffic_frac_of_peak"] = roof["traffic_GBps"] / HBM_PEAK_GBS
-        roof["note"] = ("achieved/frac use SURVEY 8(d)'s algorithmic bytes (28 B/event + 96 B/message); the design moves fewer real "
-                        "bytes than that model, so frac can exceed 1 -- traffic* are the measured HBM bytes (PMC) over the same "
-                        "event-timed launch duration" + ("; rank 0's kernels" if multi else ""))
+        roof["note"] = ("achieved/frac price the launch with SURVEY 8(d)'s byte model (28 B per synaptic event + 96 B per message), "
+                        "which assumes materialised 40-byte messages and 12-byte synapses"
+                        + ("; frac > 1 because this design never materialises messages and packs a synapse in %.1f bytes, so it moves "
+                           "%.1fx fewer bytes than the model" % (lay[0] / max(1.0, float(info["n_synapses"])), deliver_bytes / max(1.0, design_deliver))
+                           if roof["frac"] > 1.0 else "")
+                        + "; frac_design prices the same event-timed launch with the bytes of the chip's own layout "
+                          "(design_bytes_parts); traffic* are the HBM bytes the PMC counters measured for this workload "
+                          "(traffic_source, traffic_collected_utc) over the event-timed duration of this run")
 
     cpu = None
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3" and args.timing == "simple":
         c = cpu_baseline(S, args)
         events_per_step = agg["spikes"] / args.steps
         est = c["events_per_s"] / events_per_step if events_per_step > 0 else c["steps_per_s"]
-        cpu = {"value": est, "unit": "timesteps/s", "cores": 1, "kind": "port",
+        cpu = {"value": est, "unit": "timesteps/s", "cores": 1, "kind": "port", "host": host_info(),
                "sample": c["sample"] + "; value = measured synaptic-events/s (%.3g) / events per step of the GPU workload (%.3g)"
                          % (c["events_per_s"], events_per_step),
                "measured": {"timesteps_per_s_on_sample": c["steps_per_s"], "synaptic_events_per_s": c["events_per_s"],
-                            "neuron_updates_per_s": c["updates_per_s"]}}
+                            "neuron_updates_per_s": c["updates_per_s"], "timesteps_per_s_windows": c["all_steps_per_s"]}}
 
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c2":
         cpu = cpu_baseline_same_net(S, args, arch, net, "the same network")
@@ -393,7 +401,8 @@ def main():
             "config": {"workload": workload,
                        "neurons": n_total, "synapses_per_gpu": int(info["n_synapses"]), "axons_per_gpu": int(info["n_axons"]),
                        "timing_model": args.timing, "device_layout": chip.device_layout(),
-                       "exchange": ("rccl all_gather of spike bitmaps" if args.exchange == "nccl" else "gloo via host") if world > 1 else "none"},
+                       "exchange": ("in-place RCCL all-gather of the spike bitmap windows inside chip.sim() (host/comm.cpp)"
+                                    if args.exchange == "nccl" else "host all-gather callback (gloo)") if multi else "none"},
             "totals_in_timed_region": agg,
             "neuron_updates_per_s": agg["neurons_updated"] / elapsed,
             "synaptic_events_per_s": agg["spikes"] / elapsed, "messages_per_s": agg["packets_sent"] / elapsed,

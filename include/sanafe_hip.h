@@ -218,13 +218,38 @@ int sanafe_hip_synchronize(sanafe_hip_chip *chip);
  * whose axon records use the 2-byte delta form instead of the 8-byte form. */
 int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_compact_slices);
 
+/* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.
+ *   [0] synapse words (+ fp64 weights in format 2)   [1] axon records   [2] chunk tables   [3] slice descriptors
+ *   [4] global spike bitmap   -- one delivery launch reads [0..4] once when every chunk is streamed, less when
+ *       few axons spike (gather path), plus 8 + 8 + 1 bytes per post-synaptic neuron and delay value it touches;
+ *   [5] / [6] bytes the neuron launch reads / writes per step for the per-slot state (all mapped neurons)
+ *   [7] bytes read per FIRED neuron on top (static downstream totals of its spike). */
+#define SANAFE_HIP_LAYOUT_FIELDS 8
+int sanafe_hip_layout_bytes(sanafe_hip_chip *chip, uint64_t *out, int n);
+
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)
  * soma units: neurons -> [exchange spike bitmaps] -> deliver. */
 int sanafe_hip_step_neurons(sanafe_hip_chip *chip);
 int sanafe_hip_step_deliver(sanafe_hip_chip *chip, int simple_timing, int record);
+/* Tile-sharded runs overlap the exchange with delivery: the slices whose axons all start on this chip are
+ * delivered first (they need only the local window of the bitmap, which the neuron launch wrote in place),
+ * the others once the gathered bitmap is there; `_remote` also finishes the step (like step_deliver).
+ * The reference delivers in one pass after its serial routing loop, src/chip.cpp:656-692. */
+int sanafe_hip_step_deliver_local(sanafe_hip_chip *chip);
+int sanafe_hip_step_deliver_remote(sanafe_hip_chip *chip, int simple_timing);
+int sanafe_hip_slice_split(sanafe_hip_chip *chip, uint32_t *n_local, uint32_t *n_remote);
+/* Simple timing model across GPUs: sim_time of a step = max over ALL cores of the chip + sync delay
+ * (src/schedule.cpp:61-102), so each rank logs the largest per-core delay of every step it simulates
+ * (entry `timestep % capacity`) and the caller takes the maximum over the ranks.  Allocates / returns the
+ * device log; next_index = entry the next simulated step will write. */
+int sanafe_hip_delay_log(sanafe_hip_chip *chip, int64_t capacity, double **device_log, int64_t *next_index);
+int sanafe_hip_read_delay_log(sanafe_hip_chip *chip, int64_t first, int64_t count, double *out);
+/* Device address of the run totals (sanafe_hip_totals), for a device-side gather over the ranks. */
+void *sanafe_hip_run_totals_device(sanafe_hip_chip *chip);
 /* Device pointer + size (bytes) of this chip's local spike bitmap and of the
- * global bitmap the delivery kernel reads; the caller moves bytes between
- * them (on one GPU they alias).  RCCL all-gather runs directly on these. */
+ * global bitmap the delivery kernel reads.  The local bitmap IS this chip's window
+ * of the global one (local_bits == global_bits + slot_offset / 8), so the RCCL
+ * all-gather runs in place on these. */
 int sanafe_hip_spike_buffers(sanafe_hip_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,
         uint64_t *global_bytes);
 /* Host-staged variant of the exchange (tests, or no device-to-device path): copy the local

@@ -95,7 +95,26 @@ int64_t sanafe_chip_get_step_messages(sanafe_chip *chip, int64_t index, sanafe_m
 /* MappedNeuron::set_attributes between sim() calls (src/mapped.cpp:113-166): bias and potential */
 int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int64_t *neurons, const double *bias);
 
-/* Split step for multi-GPU runs; the caller exchanges the spike bitmaps (RCCL all-gather). */
+/* ---- tile-sharded chips: one process per GPU, rank r of n_ranks holds a contiguous block of tiles ----
+ * sanafe_chip_sim on such a chip exchanges the spike bitmap windows of all ranks once per timestep (the device
+ * form of the reference's serial routing loop, src/chip.cpp:656-692) and returns the RunData of the WHOLE chip on
+ * every rank: counters and energies summed over the ranks in rank order, sim_time from the per-step maximum over
+ * all cores of all ranks (simple timing model, src/schedule.cpp:61-102).  The exchange must be set up first;
+ * without one, sim() on a sharded chip fails.  `detailed` timing, traces and plugin units need the whole chip in
+ * one process and are refused.
+ *   RCCL:     rank 0 calls sanafe_comm_unique_id, ships the 128 bytes to the others by whatever channel launched
+ *             them, and every rank calls sanafe_chip_comm_init_rccl (collective: ncclCommInitRank).  The all-gather
+ *             runs on a communication stream directly on the device bitmap, overlapped with the delivery of the
+ *             slices fed by local neurons.
+ *   callback: the caller supplies a blocking all-gather over host memory -- recv[r] (bytes each) = rank r's send;
+ *             returns 0 on success.  For tests on one GPU and for MPI-style bindings. */
+#define SANAFE_COMM_ID_BYTES 128
+typedef int (*sanafe_allgather_fn)(void *ctx, const void *send, uint64_t bytes, void *recv);
+int sanafe_comm_unique_id(uint8_t id[SANAFE_COMM_ID_BYTES]);
+int sanafe_chip_comm_init_rccl(sanafe_chip *chip, const uint8_t id[SANAFE_COMM_ID_BYTES]);
+int sanafe_chip_comm_init_callback(sanafe_chip *chip, sanafe_allgather_fn fn, void *ctx);
+
+/* Split step for callers that drive the exchange themselves. */
 int sanafe_chip_step_neurons(sanafe_chip *chip);
 int sanafe_chip_step_deliver(sanafe_chip *chip, int timing_model);
 int sanafe_chip_spike_buffers(sanafe_chip *chip, void **local_bits, uint64_t *local_bytes, void **global_bits,

@@ -77,6 +77,9 @@ MSG_DBL = ("generation_delay", "processing_delay", "network_delay", "blocking_de
 MSG_DTYPE = np.dtype([(n, np.int64) for n in MSG_INT] + [(n, np.float64) for n in MSG_DBL])
 
 _lib = None
+COMM_ID_BYTES = 128
+# int (*sanafe_allgather_fn)(void *ctx, const void *send, uint64_t bytes, void *recv)  (include/sanafe_host.h)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
 
 
 class BackendMissingError(RuntimeError):
@@ -120,6 +123,9 @@ def lib():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sanafe_chip_synchronize.argtypes = [C.c_void_p]
     L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
+    L.sanafe_comm_unique_id.argtypes = [C.c_void_p]
+    L.sanafe_chip_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
+    L.sanafe_chip_comm_init_callback.argtypes = [C.c_void_p, ALLGATHER_FN, C.c_void_p]
     L.sanafe_generate_random_edges.argtypes = [C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.c_int64,
                                                C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = L
@@ -447,7 +453,58 @@ class SpikingChip:
     def get_power(self):
         return self._L.sanafe_chip_get_power(self._h)
 
-    # -- multi-GPU split step ------------------------------------------------------------------
+    # -- tile-sharded chips: the per-step spike exchange lives in the host library (host/comm.cpp) ----------
+    @staticmethod
+    def comm_unique_id():
+        """Rank 0: the 128-byte RCCL id every rank passes to ``comm_init_rccl`` (ncclGetUniqueId)."""
+        buf = (C.c_uint8 * COMM_ID_BYTES)()
+        if lib().sanafe_comm_unique_id(buf) != 0:
+            raise RuntimeError(lib().sanafe_last_error().decode())
+        return bytes(buf)
+
+    def comm_init_rccl(self, comm_id):
+        """Collective over all ranks (ncclCommInitRank): afterwards ``sim()`` exchanges spikes over RCCL."""
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(bytes(comm_id))
+        self._check(self._L.sanafe_chip_comm_init_rccl(self._h, buf))
+
+    def comm_init_callback(self, allgather):
+        """``allgather(send: bytes-like numpy uint8 array) -> numpy uint8 array [n_ranks, len(send)]``: a blocking
+        all-gather over host memory (tests on one GPU, MPI-style bindings)."""
+        n_ranks = self._n_ranks
+
+        def _cb(_ctx, send, nbytes, recv):
+            try:
+                src = np.ctypeslib.as_array(C.cast(send, C.POINTER(C.c_uint8)), shape=(nbytes,))
+                out = np.ascontiguousarray(allgather(src), dtype=np.uint8).reshape(n_ranks, nbytes)
+                C.memmove(recv, out.ctypes.data, n_ranks * nbytes)
+                return 0
+            except Exception as e:  # the C side reports a failed exchange
+                self._callback_error = e
+                return -1
+
+        self._allgather_cb = ALLGATHER_FN(_cb)  # keep the thunk alive as long as the chip
+        self._check(self._L.sanafe_chip_comm_init_callback(self._h, self._allgather_cb, None))
+
+    def comm_init_torch(self, dist, backend="rccl"):
+        """Sets the exchange up from an initialised ``torch.distributed`` process group: ``rccl`` ships the unique
+        id through the group's store and creates the library's own RCCL communicator; ``host`` gathers through
+        the group (gloo) in host memory."""
+        if backend == "rccl":
+            box = [self.comm_unique_id() if dist.get_rank() == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            self.comm_init_rccl(box[0])
+            return
+        import torch
+
+        def allgather(send):
+            t = torch.from_numpy(np.array(send, copy=True))
+            out = torch.empty(dist.get_world_size() * t.numel(), dtype=torch.uint8)
+            dist.all_gather_into_tensor(out, t)
+            return out.numpy()
+
+        self.comm_init_callback(allgather)
+
+    # -- split step for callers that drive the exchange themselves -------------------------------
     def _set_attribute(self, gid, key, attr_type, num, sval):
         L = self._L
         L.sanafe_chip_set_attribute.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_double, C.c_char_p]

@@ -87,6 +87,8 @@ struct sanafe_hip_chip
     PendStep pend2{};         // the step before it: level 1 done (or launched), level 2 not yet launched
     std::vector<uint32_t> h_core_wg_beg, h_core_slice_beg; // host copies for sanafe_hip_read_core_delays
     std::vector<double> h_core_out_lat;
+    uint64_t layout_bytes[SANAFE_HIP_LAYOUT_FIELDS]{};
+    uint32_t n_local_slices{0}; // leading slice descriptors whose axons all start on this chip
     int neuron_model{0};      // soma model every live slot runs (SANAFE_SOMA_LIF / _TRUENORTH), 0 when they differ
     bool uni{false};          // every live slot carries the class word us.cls (UniformSoma)
     UniformSoma us{};
@@ -621,13 +623,28 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 d.nbase = h.core_nbase[core];
                 d.ncount = h.core_ncount[core];
                 d.chunk0 = chunk0[sl];
-                d.core = core;
+                d.slice_id = sl;
                 d.mode = mode[sl];
                 d.inkind = (uint8_t) ((h.slot_cls[h.core_nbase[core]] >> 3) & 7u);
                 d.shared = n_core_slices[core] > 1 ? 1 : 0;
                 d.pad = 0;
             }
-            TRYC(upload(c, desc.data(), desc.size(), &im.slice_desc));
+            // launch order: slices fed by this chip's own neurons only, then the ones that need the gathered bitmap
+            std::vector<uint8_t> local_only(h.n_slices, 1);
+            if (h.n_global_slots != h.n_slots)
+                parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
+                    for (uint64_t sl = lo; sl < hi; sl++)
+                        for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl] && local_only[sl]; a++)
+                            local_only[sl] = h.ax_pre[a] >= h.slot_offset && h.ax_pre[a] < h.slot_offset + h.n_slots;
+                });
+            std::vector<SliceDesc> ordered;
+            ordered.reserve(h.n_slices);
+            for (uint32_t sl = 0; sl < h.n_slices; sl++)
+                if (local_only[sl]) ordered.push_back(desc[sl]);
+            c->n_local_slices = (uint32_t) ordered.size();
+            for (uint32_t sl = 0; sl < h.n_slices; sl++)
+                if (!local_only[sl]) ordered.push_back(desc[sl]);
+            TRYC(upload(c, ordered.data(), ordered.size(), &im.slice_desc));
         }
         TRYC(upload(c, csyn.data(), csyn.size(), &im.chunk_syn0));
         TRYC(upload(c, cpre.data(), cpre.size(), &im.chunk_pre0));
@@ -636,6 +653,12 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat.begin());
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
         for (uint8_t m : mode) c->n_compact_slices += m;
+        // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
+        c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * 4ull;
+        c->layout_bytes[1] = n_bytes;
+        c->layout_bytes[2] = n_chunks * 8ull;
+        c->layout_bytes[3] = (uint64_t) h.n_slices * sizeof(SliceDesc);
+        c->layout_bytes[4] = h.n_global_slots / 8;
         im.syn_meta = nullptr;
         im.syn_weight = nullptr;
         if (c->syn_format == 2)
@@ -708,6 +731,16 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     }
     c->neuron_grid = im.n_reduce_wgs + im.n_wgs;
     {
+        // per neuron slot and step: bytes the neuron kernel reads / writes (see neuron_kernel)
+        uint64_t live = 0;
+        for (uint32_t k = 0; k < h.n_cores; k++) live += h.core_ncount[k];
+        const uint64_t rd = (c->uni ? 0u : 4u) + 8u + 8u + 8u + 1u + (im.has_lif ? 8u : 0u) + (im.any_refrac ? 4u : 0u) + (h.n_ext ? 4u : 0u);
+        const uint64_t wr = 8u + 1u + (im.has_lif ? 8u : 0u) + (im.any_refrac ? 4u : 0u);
+        c->layout_bytes[5] = live * rd;
+        c->layout_bytes[6] = live * wr;
+        c->layout_bytes[7] = sizeof(SpikeStatic);
+    }
+    {
         // LDS accumulator rows: one per synaptic delay value actually present in the image
         std::atomic<uint32_t> max_delay_seen{0};
         parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
@@ -755,6 +788,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     if (c->st.status_log) (void) hipFree(c->st.status_log);
+    if (c->st.delay_log) (void) hipFree(c->st.delay_log);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
                  (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
@@ -817,15 +851,16 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     c->pend1.valid = 0;
     return 0;
 }
-static int launch_deliver(sanafe_hip_chip *c)
+// Delivers the slices [first, first + count) of the launch order.
+static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
-    if (c->im.n_slices > 0)
+    if (count > 0)
     {
-        const dim3 grid(c->im.n_slices), block(DELIVER_BLOCK);
+        const dim3 grid(count), block(DELIVER_BLOCK);
 #define SANAFE_LAUNCH_DELIVER(F, DLY) \
-    hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
+    hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
 #define SANAFE_LAUNCH_DELIVER_LAST(F) \
-    hipLaunchKernelGGL((deliver_kernel<F, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host)
+    hipLaunchKernelGGL((deliver_kernel<F, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
         if (c->im.has_last && c->syn_format == 0) SANAFE_LAUNCH_DELIVER_LAST(0);
         else if (c->im.has_last && c->syn_format == 1) SANAFE_LAUNCH_DELIVER_LAST(1);
         else if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(2);
@@ -886,7 +921,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         for (int64_t s = 0; s < n_steps; s++)
         {
             TRY(launch_neurons(c, record, s));
-            TRY(launch_deliver(c));
+            TRY(launch_deliver(c, 0, c->im.n_slices));
             TRY(launch_taps(c));
             finish_step(c, simple_timing, record, s);
         }
@@ -901,7 +936,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         HIPCHK(hipEventRecord(ev[s * 4 + 0], c->stream));
         TRY(launch_neurons(c, record, s));
         HIPCHK(hipEventRecord(ev[s * 4 + 1], c->stream));
-        TRY(launch_deliver(c));
+        TRY(launch_deliver(c, 0, c->im.n_slices));
         TRY(launch_taps(c));
         HIPCHK(hipEventRecord(ev[s * 4 + 2], c->stream));
         finish_step(c, simple_timing, record, s);
@@ -952,6 +987,13 @@ extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32
     return 0;
 }
 
+extern "C" int sanafe_hip_layout_bytes(sanafe_hip_chip *c, uint64_t *out, int n)
+{
+    if (!c || !out || n < SANAFE_HIP_LAYOUT_FIELDS) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    for (int k = 0; k < SANAFE_HIP_LAYOUT_FIELDS; k++) out[k] = c->layout_bytes[k];
+    return 0;
+}
+
 extern "C" int sanafe_hip_synchronize(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
@@ -993,19 +1035,71 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     }
     if (!c->timing)
     {
-        TRY(launch_deliver(c));
+        TRY(launch_deliver(c, 0, c->im.n_slices));
         TRY(launch_taps(c));
         finish_step(c, simple_timing, 0, 0);
         return 0;
     }
     TRY(timed_event(c));
-    TRY(launch_deliver(c));
+    TRY(launch_deliver(c, 0, c->im.n_slices));
     TRY(launch_taps(c));
     TRY(timed_event(c));
     finish_step(c, simple_timing, 0, 0);
     TRY(flush_pending(c));
     return timed_event(c);
 }
+
+extern "C" int sanafe_hip_step_deliver_local(sanafe_hip_chip *c)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    return launch_deliver(c, 0, c->n_local_slices);
+}
+extern "C" int sanafe_hip_step_deliver_remote(sanafe_hip_chip *c, int simple_timing)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(launch_deliver(c, c->n_local_slices, c->im.n_slices - c->n_local_slices));
+    TRY(launch_taps(c));
+    finish_step(c, simple_timing, 0, 0);
+    return 0;
+}
+extern "C" int sanafe_hip_slice_split(sanafe_hip_chip *c, uint32_t *n_local, uint32_t *n_remote)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (n_local) *n_local = c->n_local_slices;
+    if (n_remote) *n_remote = c->im.n_slices - c->n_local_slices;
+    return 0;
+}
+extern "C" int sanafe_hip_delay_log(sanafe_hip_chip *c, int64_t capacity, double **log, int64_t *next_index)
+{
+    if (!c || capacity < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (capacity > c->st.delay_log_cap)
+    {
+        if (c->st.delay_log) HIPCHK(hipFree(c->st.delay_log));
+        c->st.delay_log = nullptr;
+        c->st.delay_log_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.delay_log), (size_t) capacity * sizeof(double)));
+        c->st.delay_log_cap = capacity;
+    }
+    if (log) *log = c->st.delay_log;
+    if (next_index) *next_index = c->st.delay_log_cap > 0 ? c->t_host % c->st.delay_log_cap : 0;
+    return 0;
+}
+extern "C" int sanafe_hip_read_delay_log(sanafe_hip_chip *c, int64_t first, int64_t count, double *out)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->st.delay_log_cap)
+        return fail(SANAFE_HIP_ERR_INVALID, "delay log entries [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
+    HIPCHK(hipMemcpyAsync(out, c->st.delay_log + first, (size_t) count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+extern "C" void *sanafe_hip_run_totals_device(sanafe_hip_chip *c) { return c ? c->st.run : nullptr; }
 
 template <typename T> static int d2h(sanafe_hip_chip *c, T *dst, const T *src, size_t n);
 

@@ -49,7 +49,7 @@ struct SliceDesc
     double ain_lat;              // AxonInUnit::latency_spike_message of the core
     double slice_lat;            // per-event latency of the slice's latency class
     uint32_t n_ax, nbase, ncount, chunk0;
-    uint32_t core;
+    uint32_t slice_id;           // index of the slice in core order (slice_proc, core_slice_beg); descriptors are in LAUNCH order
     uint8_t mode;                // 0 wide, 1 compact axon records
     uint8_t inkind;              // input kind of the core's neurons (the buffer position belongs to the core)
     uint8_t shared;              // the core has more than one slice: write back with atomics
@@ -656,15 +656,17 @@ extern __shared__ __align__(16) unsigned char deliver_lds[];
 // (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
 template <int SYN_FMT, bool HAS_DELAY, bool LAST>
 __global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
-deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, uint32_t first_slice)
 {
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
     __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
 
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
-    const uint32_t slice = blockIdx.x;
-    const SliceDesc sd = im.slice_desc[slice];
+    // Descriptors are in launch order: slices whose axons all start on this GPU first (delivered while the
+    // spike bitmaps of the other GPUs are still being gathered), the rest after them.
+    const SliceDesc sd = im.slice_desc[first_slice + blockIdx.x];
+    const uint32_t slice = sd.slice_id;
     const uint32_t ncount = sd.ncount;
     const uint32_t npad = (ncount + 63u) & ~63u;
     const uint32_t nbase = sd.nbase;

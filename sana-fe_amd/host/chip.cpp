@@ -29,6 +29,7 @@
 #include <mutex>
 
 #include "../../include/sanafe_host.h"
+#include "comm.hpp"
 #include "mapper.hpp"
 #include "plugin_abi/pipeline.hpp"
 
@@ -194,6 +195,8 @@ struct sanafe_chip
 {
     MappedChip mc;
     sanafe_hip_chip *dev{nullptr};
+    int device{-1}, n_ranks{1}, rank{0};
+    sanafe_amd::Exchange xc; // the per-step spike exchange of a tile-sharded chip
     int64_t n_neurons{0};
     int64_t total_timesteps{0};
     int64_t total_messages_sent{0};
@@ -735,6 +738,15 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
         return fail(SANAFE_HIP_ERR_INVALID, e.what());
     }
     chip->n_neurons = desc->n_neurons;
+    chip->device = device;
+    chip->n_ranks = n_ranks;
+    chip->rank = rank;
+    chip->xc.n_ranks = n_ranks;
+    chip->xc.rank = rank;
+    chip->xc.slot_begin = chip->mc.rank_slot_begin;
+    if (n_ranks > 1 && (chip->mc.rank_slot_begin[rank] != chip->mc.slot_offset ||
+                               chip->mc.rank_slot_begin[rank + 1] - chip->mc.rank_slot_begin[rank] != chip->mc.n_slots))
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a rank of a tile-sharded chip holds no mapped neurons");
     try
     {
         chip->ext.init(chip->mc); // opens the LIF noise files: a missing file fails the load, as in the reference
@@ -835,6 +847,118 @@ static void add_totals(sanafe_hip_totals &a, const sanafe_hip_totals &b)
     a.sim_time += b.sim_time;
 }
 
+// sim() of one rank of a tile-sharded chip: a pure enqueue loop -- neurons, gather of the spike windows (RCCL on
+// its own stream) beside the delivery of the slices fed by local neurons, then the remaining slices.  Counters
+// and energies of the ranks are added in rank order; the simple timing model needs the largest per-core delay
+// over ALL ranks of every step, so each rank logs its own per-step maximum and the logs are max-reduced once
+// per chunk of steps.
+static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &run)
+{
+    sanafe_amd::Exchange &xc = chip->xc;
+    if (xc.kind == sanafe_amd::Exchange::None)
+        return fail(SANAFE_HIP_ERR_INVALID, "this chip holds rank " + std::to_string(chip->rank) + " of " + std::to_string(chip->n_ranks) +
+                        " of a tile-sharded chip: set the spike exchange up first (sanafe_chip_comm_init_rccl / _callback)");
+    MappedChip &mc = chip->mc;
+    DEV(sanafe_hip_reset_totals(chip->dev));
+    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(timesteps, 1 << 16));
+    double *d_log = nullptr;
+    int64_t next = 0;
+    DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &next));
+    void *local_bits = nullptr, *global_bits = nullptr;
+    uint64_t local_bytes = 0, global_bytes = 0;
+    DEV(sanafe_hip_spike_buffers(chip->dev, &local_bits, &local_bytes, &global_bits, &global_bytes));
+    std::vector<uint32_t> h_local, h_global;
+    if (xc.kind == sanafe_amd::Exchange::Callback)
+    {
+        h_local.resize(local_bytes / 4);
+        h_global.resize(global_bytes / 4);
+    }
+    std::vector<double> maxima(cap);
+    double sim_time = 0.0;
+    const size_t n_ext = mc.ext.size();
+    for (int64_t done = 0, m = 0; done < timesteps; done += m)
+    {
+        m = std::min(cap, timesteps - done);
+        if (n_ext != 0) m = std::min<int64_t>(m, std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext)));
+        if (int rc = chip->queue_ext(m)) return rc;
+        DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &next)); // flushed: `next` is where this chunk starts
+        for (int64_t s = 0; s < m; s++)
+        {
+            DEV(sanafe_hip_step_neurons(chip->dev));
+            if (xc.kind == sanafe_amd::Exchange::Rccl_)
+            {
+                if (xc.gather_spikes_rccl(global_bits)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+                DEV(sanafe_hip_step_deliver_local(chip->dev));
+                if (xc.wait_gathered()) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+            }
+            else
+            {
+                DEV(sanafe_hip_export_spikes(chip->dev, h_local.data()));
+                if (xc.gather_spikes_host(h_local.data(), h_global.data())) return fail(SANAFE_HIP_ERR_INVALID, xc.error);
+                DEV(sanafe_hip_import_spikes(chip->dev, h_global.data()));
+                DEV(sanafe_hip_step_deliver_local(chip->dev));
+            }
+            DEV(sanafe_hip_step_deliver_remote(chip->dev, 1));
+        }
+        DEV(sanafe_hip_synchronize(chip->dev));
+        // this chunk's per-step maxima sit at [next, next + m) modulo cap: at most two pieces
+        for (int64_t at = 0; at < m;)
+        {
+            const int64_t first = (next + at) % cap, len = std::min(m - at, cap - first);
+            if (xc.kind == sanafe_amd::Exchange::Callback)
+            {
+                DEV(sanafe_hip_read_delay_log(chip->dev, first, len, maxima.data() + at));
+            }
+            if (xc.max_over_ranks(d_log + first, maxima.data() + at, static_cast<size_t>(len))) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+            at += len;
+        }
+        for (int64_t s = 0; s < m; s++) sim_time += maxima[s] + mc.sync_delay;
+        chip->total_timesteps += m;
+    }
+    sanafe_hip_totals mine{};
+    DEV(sanafe_hip_read_totals(chip->dev, &mine));
+    std::vector<sanafe_hip_totals> all;
+    if (xc.gather_totals(mine, sanafe_hip_run_totals_device(chip->dev), all)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+    run = sanafe_hip_totals{};
+    for (const sanafe_hip_totals &t : all) // rank order
+    {
+        run.spikes += t.spikes;
+        run.packets_sent += t.packets_sent;
+        run.neurons_updated += t.neurons_updated;
+        run.neurons_fired += t.neurons_fired;
+        run.total_hops += t.total_hops;
+        run.total_energy += t.total_energy;
+        run.synapse_energy += t.synapse_energy;
+        run.dendrite_energy += t.dendrite_energy;
+        run.soma_energy += t.soma_energy;
+        run.network_energy += t.network_energy;
+    }
+    run.sim_time = sim_time;
+    chip->total_messages_sent += run.packets_sent;
+    return 0;
+}
+
+extern "C" int sanafe_comm_unique_id(uint8_t id[SANAFE_COMM_ID_BYTES])
+{
+    if (!id) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (sanafe_amd::Exchange::unique_id(id) != 0)
+        return fail(SANAFE_HIP_ERR_HIP, "ncclGetUniqueId failed: " + sanafe_amd::Exchange::library_error());
+    return 0;
+}
+extern "C" int sanafe_chip_comm_init_rccl(sanafe_chip *chip, const uint8_t id[SANAFE_COMM_ID_BYTES])
+{
+    if (!chip || !id) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (!chip->dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "the chip has no device (mapped only)");
+    if (chip->xc.init_rccl(id, chip->device, sanafe_hip_stream(chip->dev))) return fail(SANAFE_HIP_ERR_HIP, chip->xc.error);
+    return 0;
+}
+extern "C" int sanafe_chip_comm_init_callback(sanafe_chip *chip, sanafe_allgather_fn fn, void *ctx)
+{
+    if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (chip->xc.init_callback(fn, ctx)) return fail(SANAFE_HIP_ERR_INVALID, chip->xc.error);
+    return 0;
+}
+
 extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *rd)
 {
     if (!chip || timesteps < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
@@ -853,7 +977,15 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_first_timestep = chip->total_timesteps + 1;
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty();
-    if (timing_model == SANAFE_TIMING_SIMPLE && !host_units)
+    // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
+    if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
+    {
+        if (timing_model != SANAFE_TIMING_SIMPLE || record || host_units)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a tile-sharded chip runs the simple timing model without traces or "
+                                                    "plugin units (detailed timing and traces need the whole chip in one process)");
+        if (int rc = sim_sharded(chip, timesteps, run)) return rc;
+    }
+    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units)
     {
         // Whole run stays on the device; nothing comes back per step unless recorded.  With external value
         // streams the run is cut into chunks whose stream rows fit a bounded upload (<= 64 MiB).

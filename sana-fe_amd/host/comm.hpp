@@ -1,0 +1,43 @@
+// comm.hpp -- the per-timestep spike exchange of a tile-sharded chip (see comm.cpp).
+#ifndef SANAFE_HOST_COMM_HPP
+#define SANAFE_HOST_COMM_HPP
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "../../include/sanafe_host.h"
+
+namespace sanafe_amd
+{
+struct Exchange
+{
+    enum Kind { None = 0, Rccl_ = 1, Callback = 2 };
+    Kind kind{None};
+    int n_ranks{1}, rank{0};
+    std::vector<uint32_t> slot_begin; // [n_ranks + 1] window of every rank in the global slot space
+    std::string error;
+
+    // RCCL (opaque here: ncclComm_t, hipStream_t, hipEvent_t)
+    void *comm{nullptr}, *comm_stream{nullptr}, *ev_neurons{nullptr}, *ev_gathered{nullptr}, *d_gather{nullptr};
+    void *stream{nullptr}; // the chip's compute stream
+    // host callback
+    sanafe_allgather_fn callback{nullptr};
+    void *callback_ctx{nullptr};
+    std::vector<unsigned char> h_send, h_recv;
+
+    ~Exchange();
+    static int unique_id(uint8_t *id);
+    static std::string library_error();
+    int init_rccl(const uint8_t *id, int device, void *compute_stream);
+    int init_callback(sanafe_allgather_fn fn, void *ctx);
+    void close();
+    int gather_spikes_rccl(void *global_bits);
+    int wait_gathered();
+    int gather_spikes_host(const uint32_t *local_bits, uint32_t *global_bits);
+    int gather_totals(const sanafe_hip_totals &mine, void *device_totals, std::vector<sanafe_hip_totals> &all);
+    int max_over_ranks(double *device_values, double *host_values, size_t count);
+    int set_error(const std::string &msg);
+};
+} // namespace sanafe_amd
+#endif

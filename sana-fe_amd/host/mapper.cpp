@@ -571,6 +571,20 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 : mc.slot_offset;
         mc.n_slots = std::max<uint32_t>(64, end_slot - mc.slot_offset);
         if (mc.last_core == mc.first_core) throw UnsupportedError("rank " + std::to_string(rank) + " owns no tiles");
+        // every rank's window of the global slot space (the spike exchange gathers these windows)
+        mc.rank_slot_begin.assign(n_ranks + 1, mc.n_global_slots);
+        for (int r = 0; r < n_ranks; r++)
+        {
+            const uint32_t r0 = std::min<uint32_t>(d.n_tiles, r * tpr);
+            uint32_t fc = d.n_cores;
+            for (int c = 0; c < d.n_cores; c++)
+                if (static_cast<uint32_t>(d.core_tile[c]) >= r0)
+                {
+                    fc = c;
+                    break;
+                }
+            mc.rank_slot_begin[r] = fc < static_cast<uint32_t>(d.n_cores) ? mc.core_nbase[fc] : mc.n_global_slots;
+        }
     }
     const uint32_t LC = mc.last_core - mc.first_core;
     const uint32_t LS = mc.n_slots, SO = mc.slot_offset;

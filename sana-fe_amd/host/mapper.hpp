@@ -75,6 +75,7 @@ struct MappedChip
     // ---- rank window ----
     uint32_t first_core{0}, last_core{0};              // [first, last) cores held by this rank
     uint32_t slot_offset{0}, n_slots{0};
+    std::vector<uint32_t> rank_slot_begin;             // [n_ranks + 1] first global slot of every rank's window
 
     // ---- image arrays (local to the rank) ----
     std::vector<uint32_t> l_core_nbase, l_core_ncount;

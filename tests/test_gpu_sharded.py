@@ -1,0 +1,163 @@
+"""Tile-sharded chips: the per-step spike exchange lives inside the product's sim().
+
+* a sharded chip refuses to simulate until an exchange is set up (it must never run without one);
+* two ranks -- two chips in this process, one thread each, both on device 0 -- through the host all-gather
+  callback reproduce the one-rank RunData and potentials exactly (integer weights: exact in any order);
+* the RCCL path runs with world size 1 (one process cannot hold two RCCL ranks on one device): the same loop
+  (neurons -> in-place all-gather on the communication stream || local delivery -> remaining delivery) against
+  the plain single-rank path;
+* config C4 at full size (1,048,576 TrueNorth neurons on one GPU): domain properties and determinism.
+"""
+import os
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nets  # noqa: E402
+
+INT_KEYS = ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops")
+DBL_KEYS = ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy", "network_energy", "sim_time")
+
+
+class ThreadGather:
+    """A blocking all-gather between the ranks' threads of this process."""
+
+    def __init__(self, n):
+        self.n, self.slots, self.barrier = n, [None] * n, threading.Barrier(n)
+
+    def for_rank(self, r):
+        def gather(send):
+            self.slots[r] = np.array(send, copy=True)
+            self.barrier.wait()
+            out = np.stack(self.slots)
+            self.barrier.wait()
+            return out
+        return gather
+
+
+def _one_rank(S, arch, net, steps):
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    return chip.run(steps, "simple"), chip.potentials(), chip
+
+
+def _sharded(S, arch, net, steps, n_ranks=2, calls=1):
+    tg = ThreadGather(n_ranks)
+    chips, results, errors = [], [None] * n_ranks, []
+    for r in range(n_ranks):
+        c = S.SpikingChip(arch, device=0, n_ranks=n_ranks, rank=r)
+        c.load(net)
+        c.comm_init_callback(tg.for_rank(r))
+        chips.append(c)
+
+    def work(r):
+        try:
+            out = [chips[r].run(steps, "simple") for _ in range(calls)]
+            results[r] = out
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            tg.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return chips, results
+
+
+def _assert_same(a, b):
+    for k in INT_KEYS:
+        assert a[k] == b[k], (k, a[k], b[k])
+    for k in DBL_KEYS:
+        assert a[k] == pytest.approx(b[k], rel=1e-12, abs=0), k
+
+
+def test_sharded_chip_needs_an_exchange(S):
+    arch, net = nets.truenorth_net(S, n_tiles=8)
+    chip = S.SpikingChip(arch, device=0, n_ranks=2, rank=1)
+    chip.load(net)
+    with pytest.raises(RuntimeError, match="exchange"):
+        chip.run(3, "simple")
+    chip.comm_init_callback(lambda send: np.stack([send, send]))
+    with pytest.raises(NotImplementedError):
+        chip.run(3, "detailed")  # the NoC schedule needs the whole chip in one process
+
+
+@pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_unequal"])
+def test_two_ranks_match_one(S, which):
+    if which == "truenorth":
+        arch, net = nets.truenorth_net(S, n_tiles=16)
+    elif which == "loihi_delays":
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=96, out_degree=48, delays=True, seed=5)
+    else:  # the ranks' slot windows differ in size: 5 tiles -> 3 + 2
+        arch, net = nets.random_loihi(S, n_tiles=5, neurons_per_core=70, out_degree=40, seed=6)
+    steps = 25
+    ref, v_ref, _ = _one_rank(S, arch, net, steps)
+    chips, results = _sharded(S, arch, net, steps)
+    assert ref["spikes"] > 0 and ref["neurons_fired"] > 0
+    for r in range(2):
+        _assert_same(results[r][0], ref)  # every rank reports the totals of the whole chip
+    # potentials: each rank holds its own neurons (others read 0)
+    info0, info1 = chips[0].info(), chips[1].info()
+    assert info0["n_slots"] + info1["n_slots"] == info0["n_global_slots"]
+    v = chips[0].potentials() + chips[1].potentials()
+    assert np.array_equal(v, v_ref)
+
+
+def test_sharded_sim_is_cumulative(S):
+    arch, net = nets.truenorth_net(S, n_tiles=8)
+    ref_chip = S.SpikingChip(arch)
+    ref_chip.load(net)
+    ref = [ref_chip.run(7, "simple") for _ in range(3)]
+    _, results = _sharded(S, arch, net, 7, calls=3)
+    for k in range(3):
+        _assert_same(results[0][k], ref[k])
+        _assert_same(results[1][k], ref[k])
+
+
+def test_rccl_exchange_world_size_one(S):
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=32, delays=True, seed=3)
+    ref, v_ref, _ = _one_rank(S, arch, net, 40)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    chip.comm_init_rccl(S.SpikingChip.comm_unique_id())  # ncclCommInitRank with one rank
+    got = chip.run(40, "simple")
+    _assert_same(got, ref)
+    assert np.array_equal(chip.potentials(), v_ref)
+    got2 = chip.run(5, "simple")  # the communicator stays usable
+    assert got2["neurons_updated"] == ref["neurons_updated"] // 40 * 5
+
+
+@pytest.mark.slow
+def test_c4_full_size_properties(S):
+    import bench
+    arch, net = bench.build_c4(S, 1, 0, 4096, 1)
+    steps = 12
+    runs = []
+    for _ in range(2):
+        chip = S.SpikingChip(arch)
+        chip.load(net)
+        tot = chip.run(steps, "simple", record=True)
+        recs = chip.step_totals(0, steps)
+        runs.append((tot, recs, chip.potentials()))
+        assert chip.info()["n_neurons"] == 1048576
+        del chip
+    tot, recs, v = runs[0]
+    assert np.all(recs["neurons_updated"] == 1048576)            # force_update: every neuron, every step
+    assert np.all(recs["spikes"] == recs["packets_sent"])        # one synapse behind every axon
+    assert np.all(recs["packets_sent"] == recs["neurons_fired"]) # one out-edge per neuron
+    assert recs["neurons_fired"][0] == 1048576                   # threshold 0, v = 0: every neuron fires in step 1
+    assert tot["neurons_fired"] == int(recs["neurons_fired"].sum())
+    assert np.all(recs["total_energy"] == 0.0)                   # arch/truenorth.yaml: all costs 0
+    # determinism: a second chip reproduces every record and every potential bit for bit
+    tot2, recs2, v2 = runs[1]
+    assert np.array_equal(v, v2)
+    for k in recs.dtype.names:
+        assert np.array_equal(recs[k], recs2[k]), k
