@@ -885,20 +885,25 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
         for (int64_t s = 0; s < m; s++)
         {
             DEV(sanafe_hip_step_neurons(chip->dev));
-            if (xc.kind == sanafe_amd::Exchange::Rccl_)
+            if (xc.kind == sanafe_amd::Exchange::Rccl_ && xc.overlap)
             {
                 if (xc.gather_spikes_rccl(global_bits)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
                 DEV(sanafe_hip_step_deliver_local(chip->dev));
                 if (xc.wait_gathered()) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+                DEV(sanafe_hip_step_deliver_remote(chip->dev, 1));
+                continue;
+            }
+            if (xc.kind == sanafe_amd::Exchange::Rccl_)
+            {
+                if (xc.gather_spikes_rccl(global_bits)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
             }
             else
             {
                 DEV(sanafe_hip_export_spikes(chip->dev, h_local.data()));
                 if (xc.gather_spikes_host(h_local.data(), h_global.data())) return fail(SANAFE_HIP_ERR_INVALID, xc.error);
                 DEV(sanafe_hip_import_spikes(chip->dev, h_global.data()));
-                DEV(sanafe_hip_step_deliver_local(chip->dev));
             }
-            DEV(sanafe_hip_step_deliver_remote(chip->dev, 1));
+            DEV(sanafe_hip_step_deliver(chip->dev, 1, 0));
         }
         DEV(sanafe_hip_synchronize(chip->dev));
         // this chunk's per-step maxima sit at [next, next + m) modulo cap: at most two pieces

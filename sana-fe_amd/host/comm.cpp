@@ -11,7 +11,7 @@
 //   callback  a caller-supplied host all-gather (tests on one GPU, MPI bindings): the windows go through
 //             host memory.
 //
-// Per step:  neurons -> [gather on the comm stream || delivery of the slices fed by local neurons only]
+// Per step:  neurons -> gather (in line; or on the comm stream beside the delivery of the slices fed by local neurons only)
 //            -> delivery of the remaining slices.
 #include <algorithm>
 #include <cstdio>
@@ -138,6 +138,7 @@ int Exchange::init_rccl(const uint8_t *id, int device, void *compute_stream)
     HIPCHK(hipMalloc(&p, static_cast<size_t>(n_ranks) * sizeof(sanafe_hip_totals)));
     d_gather = p;
     stream = compute_stream;
+    if (const char *env = std::getenv("SANAFE_COMM_OVERLAP")) overlap = std::atoi(env) != 0;
     kind = Rccl_;
     return 0;
 }
@@ -174,9 +175,12 @@ Exchange::~Exchange() { close(); }
 int Exchange::gather_spikes_rccl(void *global_bits)
 {
     Rccl &r = rccl();
-    hipStream_t s = static_cast<hipStream_t>(stream), cs = static_cast<hipStream_t>(comm_stream);
-    HIPCHK(hipEventRecord(static_cast<hipEvent_t>(ev_neurons), s));
-    HIPCHK(hipStreamWaitEvent(cs, static_cast<hipEvent_t>(ev_neurons), 0));
+    hipStream_t s = static_cast<hipStream_t>(stream), cs = overlap ? static_cast<hipStream_t>(comm_stream) : s;
+    if (overlap)
+    {
+        HIPCHK(hipEventRecord(static_cast<hipEvent_t>(ev_neurons), s));
+        HIPCHK(hipStreamWaitEvent(cs, static_cast<hipEvent_t>(ev_neurons), 0));
+    }
     char *base = static_cast<char *>(global_bits);
     bool equal = true;
     const uint32_t w0 = slot_begin[1] - slot_begin[0];
@@ -195,13 +199,13 @@ int Exchange::gather_spikes_rccl(void *global_bits)
         }
         NCCLCHK(r.group_end());
     }
-    HIPCHK(hipEventRecord(static_cast<hipEvent_t>(ev_gathered), cs));
+    if (overlap) HIPCHK(hipEventRecord(static_cast<hipEvent_t>(ev_gathered), cs));
     return 0;
 }
 
 int Exchange::wait_gathered()
 {
-    HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_gathered), 0));
+    if (overlap) HIPCHK(hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev_gathered), 0));
     return 0;
 }
 

@@ -21,6 +21,11 @@ struct Exchange
     // RCCL (opaque here: ncclComm_t, hipStream_t, hipEvent_t)
     void *comm{nullptr}, *comm_stream{nullptr}, *ev_neurons{nullptr}, *ev_gathered{nullptr}, *d_gather{nullptr};
     void *stream{nullptr}; // the chip's compute stream
+    // Gather in line on the compute stream (default), or on the communication stream beside the delivery of the
+    // slices fed by local neurons only (SANAFE_COMM_OVERLAP=1).  Measured on MI355X with a one-rank communicator:
+    // the two cross-stream dependencies of the overlapped form cost ~20 us per step, the in-line gather ~0.5-3 us;
+    // and with random connectivity nearly every slice has a remote source, so there is little to overlap with.
+    bool overlap{false};
     // host callback
     sanafe_allgather_fn callback{nullptr};
     void *callback_ctx{nullptr};
