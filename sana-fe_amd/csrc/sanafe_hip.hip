@@ -461,7 +461,20 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             while (seen < fmt && !need.compare_exchange_weak(seen, fmt)) {}
         });
         int fmt = need.load();
-        if (fmt == 0 && !small_cores) fmt = 1;
+        // format 0 addresses the LDS accumulators with 15 bits: (max delay + 1) rows of npad + 1 entries
+        uint32_t fmt0_rows = 1, fmt0_max_pad = 64;
+        {
+            std::atomic<uint32_t> md{0};
+            parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
+                uint32_t m = 0;
+                for (uint64_t k = lo; k < hi; k++) m = std::max(m, (h.syn_meta[k] >> 16) & 7u);
+                uint32_t seen = md.load();
+                while (seen < m && !md.compare_exchange_weak(seen, m)) {}
+            });
+            fmt0_rows = md.load() + 1;
+            for (uint32_t k = 0; k < h.n_cores; k++) fmt0_max_pad = std::max(fmt0_max_pad, (h.core_ncount[k] + 63u) & ~63u);
+        }
+        if (fmt == 0 && (!small_cores || (uint64_t) fmt0_rows * (fmt0_max_pad + 1u) > 32768ull)) fmt = 1;
         if (h.n_synapses == 0) fmt = 2;
         if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // experiments: force a wider format
             fmt = std::max(fmt, std::min(2, std::atoi(env)));
@@ -561,7 +574,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 if (stream_layout) // padding words of every chunk: weight 0 into the trash entry
                     for (uint64_t k = 0; k < nck; k++)
                         for (uint64_t q = chunk_pos[chunk0[sl] + k] + chunk_syn_count((uint32_t) sl, k); q < chunk_pos[chunk0[sl] + k + 1]; q++)
-                            meta[q] = trash_post | 0x8000u;
+                            meta[q] = trash_post << 8; // code 0, weight 0: adds nothing wherever it lands
                 for (uint64_t a = b0; a < e0; a++)
                 {
                     const uint64_t rel = a - b0;
@@ -585,7 +598,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[b0 + (rel / WAVE_CHUNK) * WAVE_CHUNK];
                     const uint64_t dpos = chunk_pos[chunk0[sl] + rel / WAVE_CHUNK] + (src - chunk_first);
-                    const uint32_t code = ((in_chunk & 3u) << 6) | (in_chunk >> 2);
+                    const uint32_t code = in_chunk; // index of the axon inside its 256-axon chunk
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t m = h.syn_meta[src + k];
@@ -593,8 +606,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                         if (c->syn_format == 0)
                         {
                             const bool drop = (m >> 19) & 1u;
-                            const uint32_t post = drop ? trash_post : (m & 0xfffu);
-                            meta[dpos + k] = post | (drop ? 0x8000u : (((m >> 16) & 7u) << 12)) | (code << 16) | ((uint32_t) (w & 0xff) << 24);
+                            const uint32_t idx = drop ? trash_post : ((m >> 16) & 7u) * (trash_post + 1u) + (m & 0xfffu);
+                            meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
                         }
                         else
                             meta[dpos + k] = (m & 0xfffffu) | ((uint32_t) (w & 0xfff) << 20);

@@ -100,10 +100,12 @@ struct DevImage
     const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
     const double *lat_class;      // [256] per-event latency of each class
     // Synapses, one of three formats (chip-wide):
-    //   0: 4 bytes      post (12b) | delay (3b) << 12 | drop << 15 | axon code (8b) << 16 | int8 weight << 24
-    //                   axon code = ((a & 3) << 6) | (a >> 2), a = index of the synapse's axon inside its 256-axon
-    //                   chunk: lets a chunk with many spikes be STREAMED (every synapse word read once, in order,
-    //                   fired or not decided from the word itself) instead of gathered
+    //   0: 4 bytes      axon code (8b) | accumulator index (15b) << 8 | int8 weight << 24
+    //                   axon code = index of the synapse's axon inside its 256-axon chunk: lets a chunk with many
+    //                   spikes be STREAMED (every synapse word read once, in order, fired or not decided from the
+    //                   word itself via a 256-byte table in LDS) instead of gathered;
+    //                   accumulator index = delay * (npad + 1) + post-neuron offset, i.e. the LDS entry the weight is
+    //                   added to; synapses whose charge is lost point at the trash entry `npad` of row 0
     //   1: 4 bytes      post (16b) | delay (3b) << 16 | drop << 19 | 12-bit signed weight << 20
     //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64
     const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
@@ -616,13 +618,13 @@ constexpr int WAVE_CHUNK = WAVE * AX_PER_THREAD; // axons one wave scans per ite
 constexpr int EXPAND_UNROLL = 4;
 constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bitmap
 #ifndef SANAFE_STREAM_DEPTH
-#define SANAFE_STREAM_DEPTH 3
+#define SANAFE_STREAM_DEPTH 4
 #endif
 #ifndef SANAFE_DELIVER_WAVES_PER_EU
 #define SANAFE_DELIVER_WAVES_PER_EU 5
 #endif
 constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
-constexpr uint32_t STREAM_MIN_ACTIVE = 16; // spiking axons in a 256-axon chunk from which streaming beats gathering
+constexpr uint32_t STREAM_MIN_ACTIVE_LANES = 8; // lanes (4 axons each) with a spiking axon from which streaming a chunk beats gathering
 constexpr unsigned long long ACC_UNTOUCHED = 0x8000000000000000ull; // -0.0: no sum of additions yields it
 
 // Inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips): Hillis-Steele inside each
@@ -649,6 +651,19 @@ __device__ __forceinline__ void wave_lds_fence()
 }
 
 extern __shared__ __align__(16) unsigned char deliver_lds[];
+
+// The synapse words are read exactly once per launch: non-temporal loads (global_load_dwordx4 ... nt) keep them from
+// displacing the spike bitmap and the axon records in the caches.
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_stream16(const uint4 *p)
+{
+#ifdef SANAFE_STREAM_PLAIN_LOADS
+    return *p;
+#else
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#endif
+}
 
 // LAST: the chip has cores whose time-step buffer sits before the dendrite unit (SANAFE_IN_LAST): for those cores the
 // workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
@@ -698,6 +713,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
 
     double proc = 0.0;
+    uint32_t stream_events = 0, stream_msgs = 0; // per lane: events / messages of the chunks this wave streamed
     const uint32_t *bits = st.bits_global;
     constexpr unsigned long long NONE = ~0ull; // wide record "past the end of the slice"
     // The 4 consecutive axon records of this lane.  Wide: two 16-byte loads (r[0..3]).  Compact: one 8-byte
@@ -745,7 +761,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         for (int u = 0; u < STREAM_DEPTH; u++)
         {
             const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
-            if (g < st_groups) sq[u] = st_src[g];
+            if (g < st_groups) sq[u] = load_stream16(st_src + g);
         }
     };
     // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
@@ -846,41 +862,27 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             // ---- STREAM: with many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
             //      so read them all once, in order (16 bytes per lane), and let each word say whether its axon
             //      spiked: no compaction, no ownership search, no per-event address arithmetic. ----
-            const unsigned long long b0 = __ballot(amask & 1u), b1 = __ballot(amask & 2u), b2 = __ballot(amask & 4u),
-                                     b3 = __ballot(amask & 8u);
-            const uint32_t n_act = (uint32_t) (__popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3));
-            if (n_act >= STREAM_MIN_ACTIVE)
+            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
+            if (n_act_lanes >= STREAM_MIN_ACTIVE_LANES)
             {
-                if (lane < 8)
-                {
-                    const unsigned long long b = (lane < 2) ? b0 : (lane < 4) ? b1 : (lane < 6) ? b2 : b3;
-                    w_pref[lane] = (uint32_t) (b >> ((lane & 1) * 32)); // word k*2 + (L >> 5), bit L & 31: axon 4L + k
-                }
+                // 256-byte table: byte a = "axon a of the chunk spiked"; lane L owns axons 4L..4L+3 = one dword
+                w_pref[lane] = (amask * 0x00204081u) & 0x01010101u;
                 wave_lds_fence();
                 if (!hot) stream_preload();
                 hot = true;
+                const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
                 auto add4 = [&](const uint4 &g, uint32_t pos0 /* position of g.x among the core's synapses */) {
                     const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
                     uint32_t fired[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                    {
-                        const uint32_t code = (w4[u] >> 16) & 0xffu;
-                        fired[u] = (w_pref[code >> 5] >> (code & 31u)) & 1u;
-                    }
+                    for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0xffu];
 #pragma unroll
                     for (int u = 0; u < 4; u++)
                         if (fired[u])
                         {
-                            if (LAST && last_mode)
-                            {
-                                atomicMax(&lastv[w4[u] & 0xfffu], pos0 + (uint32_t) u + 1u);
-                            }
-                            else
-                            {
-                                const uint32_t idx = (HAS_DELAY ? __umul24((w4[u] >> 12) & 7u, RS) : 0u) + (w4[u] & 0xfffu);
-                                atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
-                            }
+                            const uint32_t idx = (w4[u] >> 8) & 0x7fffu;
+                            if (LAST && last_mode) atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
+                            else atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
                         }
                 };
                 // rolling window: STREAM_DEPTH 16-byte groups per lane in flight while one is added
@@ -892,14 +894,14 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         // add, then refill the same registers (the other groups of the window are still in flight)
                         if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
                         const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
-                        if (nxt < st_groups) sq[u] = st_src[nxt];
+                        if (nxt < st_groups) sq[u] = load_stream16(st_src + nxt);
                     }
                 }
-                // processing delay of the chunk's messages: axon-in latency per message + per-event latency
-                uint32_t my_events = 0;
+                // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
+                // in integers here, priced once at the end of the slice
 #pragma unroll
-                for (int k = 0; k < AX_PER_THREAD; k++) my_events += (amask & (1u << k)) ? nsyn[k] : 0u;
-                proc += (double) my_events * slice_lat + (double) __popc(amask) * ain_lat;
+                for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
+                stream_msgs += (uint32_t) __popc(amask);
                 wave_lds_fence(); // w_pref is rewritten by the next chunk
                 continue;
             }
@@ -993,7 +995,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                             if (SYN_FMT == 0)
                             {
                                 const uint32_t m = im.syn_meta[s];
-                                meta[u] = (m & 0xfffu) | (((m >> 12) & 0xfu) << 16);
+                                meta[u] = (m >> 8) & 0x7fffu; // the accumulator index itself (trash entry when the charge is lost)
                                 wgt[u] = (double) ((int) m >> 24);
                             }
                             else if (SYN_FMT == 1)
@@ -1016,10 +1018,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     {
                         if (LAST && last_mode)
                         {
-                            atomicMax(&lastv[meta[u] & 0xffffu], spos[u] + 1u);
+                            atomicMax(&lastv[meta[u] & 0xffffu], spos[u] + 1u); // (format 0: the index; no delays in this mode)
                             continue;
                         }
-                        const uint32_t idx = (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
+                        const uint32_t idx = (SYN_FMT == 0) ? meta[u]
+                                                            : (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
                         atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
                         if (TOUCH_BYTES) touched[idx] = 1;
                     }
@@ -1029,6 +1032,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         wave_lds_fence(); // the lists are rewritten by the next chunk
     }
     // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
+    if (SYN_FMT == 0) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
     proc = wave_sum(proc);
     if (lane == 0) s_red[wave] = proc;
     __syncthreads();

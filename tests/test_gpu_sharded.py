@@ -122,7 +122,9 @@ def test_sharded_sim_is_cumulative(S):
         _assert_same(results[1][k], ref[k])
 
 
-def test_rccl_exchange_world_size_one(S):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_rccl_exchange_world_size_one(S, monkeypatch, overlap):
+    monkeypatch.setenv("SANAFE_COMM_OVERLAP", overlap)  # in-line gather / gather beside the local delivery
     arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=32, delays=True, seed=3)
     ref, v_ref, _ = _one_rank(S, arch, net, 40)
     chip = S.SpikingChip(arch)
