@@ -36,10 +36,11 @@ typedef struct sanafe_chip_info
 typedef struct sanafe_message
 {
     int64_t timestep, mid;
-    int64_t src_neuron;       /* global neuron id (desc order) */
+    int64_t src_neuron;       /* global neuron id (desc order): group + offset give src_neuron_group_id / _offset */
     int64_t src_tile, src_core_offset, src_core_id;
     int64_t dest_tile, dest_core_offset, dest_core_id, dest_axon_id;
     int64_t hops, spikes, placeholder;
+    int64_t src_x, src_y, dest_x, dest_y; /* NoC coordinates of the tiles (src/message.cpp:20-59) */
     double generation_delay, processing_delay, network_delay, blocking_delay,
             min_hop_delay, sent_timestamp, received_timestamp,
             processed_timestamp, messages_along_route;
@@ -57,7 +58,12 @@ int sanafe_chip_get_image(sanafe_chip *chip, sanafe_hip_image *out);
 int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron);
 
 /* SpikingChip::sim(timesteps, timing_model): returns the RunData of this call.
- * record != 0 keeps per-step totals / spike lists / (detailed) messages for the getters. */
+ * record bit 0 keeps per-step totals and spike lists for the getters, bit 2 (value 4) also the messages of every
+ * step (the message trace, src/chip.cpp:440-460) -- under `detailed` timing with the scheduled timestamps, under
+ * `simple` timing as schedule_messages_timestep_simple leaves them (network_delay = min_hop_delay, blocking_delay = 0,
+ * timestamps -inf; src/schedule.cpp:61-102). */
+#define SANAFE_RECORD_STEPS 1
+#define SANAFE_RECORD_MESSAGES 4
 int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *run_data);
 /* Number of host threads that run the detailed NoC schedule of finished timesteps while the GPU
  * simulates ahead (SpikingChip::sim `scheduler_threads`, src/chip.cpp:291-349; 0 = inline). */
@@ -121,6 +127,8 @@ int sanafe_chip_spike_buffers(sanafe_chip *chip, void **local_bits, uint64_t *lo
         uint64_t *global_bytes, uint64_t *local_offset_bytes);
 int sanafe_chip_synchronize(sanafe_chip *chip);
 int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out);
+/* SpikingChip::total_timesteps (src/chip.hpp:93): timesteps simulated since load(). */
+int64_t sanafe_chip_total_timesteps(sanafe_chip *chip);
 
 /* Synthetic random SNN edges for the benchmark configs: `out_degree` distinct
  * uniformly drawn targets per neuron, integer weights in {-8..8}\{0}; arrays hold

@@ -21,7 +21,8 @@ class OracleTs(C.Structure):
 
 
 MSG_INT = ("timestep", "mid", "src_neuron", "src_tile", "src_core_offset", "src_core_id", "dest_tile",
-           "dest_core_offset", "dest_core_id", "dest_axon_id", "hops", "spikes", "placeholder")
+           "dest_core_offset", "dest_core_id", "dest_axon_id", "hops", "spikes", "placeholder",
+           "src_x", "src_y", "dest_x", "dest_y")
 MSG_DBL = ("generation_delay", "processing_delay", "network_delay", "blocking_delay", "min_hop_delay",
            "sent_timestamp", "received_timestamp", "processed_timestamp", "messages_along_route")
 MSG_DTYPE = np.dtype([(n, np.int64) for n in MSG_INT] + [(n, np.float64) for n in MSG_DBL])

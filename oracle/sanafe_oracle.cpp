@@ -680,7 +680,6 @@ struct AxonOutUnit { long packets_out{0}; double energy{0}, energy_access{0}, la
 struct Message : oracle_msg
 {
     bool in_noc{false};
-    int64_t src_x{0}, src_y{0}, dest_x{0}, dest_y{0};
 };
 
 struct Core

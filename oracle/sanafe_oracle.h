@@ -40,6 +40,7 @@ typedef struct oracle_msg
     int64_t src_tile, src_core_offset, src_core_id;
     int64_t dest_tile, dest_core_offset, dest_core_id, dest_axon_id;
     int64_t hops, spikes, placeholder;
+    int64_t src_x, src_y, dest_x, dest_y; /* tile coordinates (src/message.cpp:20-59) */
     double generation_delay, processing_delay, network_delay, blocking_delay,
             min_hop_delay, sent_timestamp, received_timestamp,
             processed_timestamp, messages_along_route;

@@ -71,7 +71,8 @@ class ChipInfo(C.Structure):
 
 
 MSG_INT = ("timestep", "mid", "src_neuron", "src_tile", "src_core_offset", "src_core_id", "dest_tile",
-           "dest_core_offset", "dest_core_id", "dest_axon_id", "hops", "spikes", "placeholder")
+           "dest_core_offset", "dest_core_id", "dest_axon_id", "hops", "spikes", "placeholder",
+           "src_x", "src_y", "dest_x", "dest_y")
 MSG_DBL = ("generation_delay", "processing_delay", "network_delay", "blocking_delay", "min_hop_delay",
            "sent_timestamp", "received_timestamp", "processed_timestamp", "messages_along_route")
 MSG_DTYPE = np.dtype([(n, np.int64) for n in MSG_INT] + [(n, np.float64) for n in MSG_DBL])
@@ -123,6 +124,8 @@ def lib():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sanafe_chip_synchronize.argtypes = [C.c_void_p]
     L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
+    L.sanafe_chip_total_timesteps.argtypes = [C.c_void_p]
+    L.sanafe_chip_total_timesteps.restype = C.c_int64
     L.sanafe_comm_unique_id.argtypes = [C.c_void_p]
     L.sanafe_chip_comm_init_rccl.argtypes = [C.c_void_p, C.c_void_p]
     L.sanafe_chip_comm_init_callback.argtypes = [C.c_void_p, ALLGATHER_FN, C.c_void_p]
@@ -301,11 +304,17 @@ class SpikingChip:
             self._L.sanafe_chip_get_step_messages(self._h, index, out.ctypes.data, n)
         return out
 
-    def run(self, timesteps, timing_model="simple", record=False):
-        """One sanafe_chip_sim call; returns the raw totals dict."""
+    RECORD_STEPS, RECORD_MESSAGES = 1, 4  # include/sanafe_host.h
+
+    def run(self, timesteps, timing_model="simple", record=False, messages=False):
+        """One sanafe_chip_sim call; returns the raw totals dict.  ``record`` keeps the per-step totals and spike
+        lists, ``messages`` also every step's messages (step_messages)."""
         t = Totals()
-        self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], int(bool(record)), C.byref(t)))
-        self.total_timesteps += int(timesteps)
+        flags = (self.RECORD_STEPS if record or messages else 0) | (self.RECORD_MESSAGES if messages else 0)
+        try:
+            self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], flags, C.byref(t)))
+        finally:
+            self.total_timesteps = int(self._L.sanafe_chip_total_timesteps(self._h))  # the C side is the one counter
         return t.as_dict()
 
     # -- SpikingChip.sim (src/pymodule.cpp:549-706, 1198-1208) ---------------------------------
@@ -320,20 +329,20 @@ class SpikingChip:
         want_steps = any(t is not None and t is not False for t in (spike_trace, perf_trace, message_trace))
         want_state = any(t is not None and t is not False for t in (potential_trace, neuron_trace))
         spikes, pots, ntraces, perf, msgs = [], [], {}, None, []
+        if timing_model == "cycle":
+            raise NotImplementedError("UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope")
         if not want_state:
-            tot = self.run(timesteps, timing_model, record=want_steps)
+            tot = self.run(timesteps, timing_model, record=want_steps, messages=bool(message_trace))
             steps = self.step_totals(0, timesteps) if want_steps and timesteps > 0 else None
             fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
             if message_trace:
-                if timing_model != "detailed":
-                    raise NotImplementedError("message traces need timing_model='detailed' on the MI355X backend")
                 msgs = [self.step_messages(i) for i in range(timesteps)]
         else:
             # potentials / model traces are sampled after every step (src/pytrace.cpp:190-222)
             tot = None
             steps_l, fired = [], []
             for _ in range(timesteps):
-                r = self.run(1, timing_model, record=True)
+                r = self.run(1, timing_model, record=True, messages=bool(message_trace))
                 tot = r if tot is None else {k: tot[k] + r[k] for k in r}
                 steps_l.append(self.step_totals(0, 1)[0])
                 fired.append(self.step_fired(0))
@@ -373,12 +382,17 @@ class SpikingChip:
         result["potential_trace"] = pots if potential_trace else None
         result["neuron_trace"] = ntraces if neuron_trace else None
         result["perf_trace"] = perf
-        result["message_trace"] = [self._message_dicts(m) for m in msgs] if message_trace else None
+        result["message_trace"] = None
         for tr, key in ((spike_trace, "spike_trace"), (potential_trace, "potential_trace"), (perf_trace, "perf_trace"),
                         (message_trace, "message_trace")):
             if isinstance(tr, str) or hasattr(tr, "write"):
-                self._write_trace(tr, key, result[key], start, write_trace_headers)
+                self._write_trace(tr, key, msgs if key == "message_trace" else result[key], start, write_trace_headers)
                 result[key] = None
+            elif key == "message_trace" and tr:
+                result[key] = [self._message_dicts(m) for m in msgs]
+            elif key == "perf_trace" and result[key] is not None:
+                # the in-memory map has no "packets" entry (timestep_data_to_map, src/pytrace.cpp:55-74); the CSV has
+                result[key] = {k: v for k, v in result[key].items() if k != "packets"}
         return result
 
     def _labels(self):
@@ -389,18 +403,25 @@ class SpikingChip:
         return self._gid_label
 
     def _message_dicts(self, arr):
-        """Python in-memory message trace rows, sorted by mid: placeholders (-1) first (src/pytrace.hpp:336-339)."""
+        """In-memory message trace rows: exactly the 26 keys of message_to_dict (src/pytrace.cpp:17-53), sorted by
+        plain mid, so placeholders (mid -1) come first (src/pytrace.hpp:336-339)."""
         labels = self._labels()
         rows = []
         for m in np.sort(arr, order="mid", kind="stable"):
             g, o = labels.get(int(m["src_neuron"]), ("invalid", 0))
-            row = {"timestep": int(m["timestep"]), "mid": int(m["mid"]), "src_neuron": "%s.%d" % (g, o),
-                   "src_hw": "%d.%d" % (m["src_tile"], m["src_core_offset"]),
-                   "dest_hw": "x.x" if m["placeholder"] else "%d.%d" % (m["dest_tile"], m["dest_core_offset"]),
-                   "hops": int(m["hops"]), "spikes": int(m["spikes"])}
-            for k in MSG_DBL:
-                row[{"sent_timestamp": "send_timestamp"}.get(k, k)] = float(m[k])
-            rows.append(row)
+            rows.append({
+                "generation_delay": float(m["generation_delay"]), "network_delay": float(m["network_delay"]),
+                "processing_delay": float(m["processing_delay"]), "blocking_delay": float(m["blocking_delay"]),
+                "send_timestamp": float(m["sent_timestamp"]), "received_timestamp": float(m["received_timestamp"]),
+                "processed_timestamp": float(m["processed_timestamp"]),
+                "timestep": int(m["timestep"]), "mid": int(m["mid"]), "spikes": int(m["spikes"]), "hops": int(m["hops"]),
+                "src_neuron_offset": int(o), "src_neuron_group_id": g,
+                "src_x": int(m["src_x"]), "dest_x": int(m["dest_x"]), "src_y": int(m["src_y"]), "dest_y": int(m["dest_y"]),
+                "src_tile_id": int(m["src_tile"]), "src_core_id": int(m["src_core_id"]),
+                "src_core_offset": int(m["src_core_offset"]), "dest_tile_id": int(m["dest_tile"]),
+                "dest_core_id": int(m["dest_core_id"]), "dest_core_offset": int(m["dest_core_offset"]),
+                "dest_axon_hw": 0, "dest_axon_id": int(m["dest_axon_id"]), "placeholder": bool(m["placeholder"]),
+            })
         return rows
 
     def _write_trace(self, target, key, data, start, headers):
@@ -438,11 +459,19 @@ class SpikingChip:
                         "network_delay", "blocking_delay", "min_hop_delay", "messages_along_route"]
                 if headers:
                     f.write(",".join(cols) + "\n")
-                for step in data or []:
+                for step in data or []:  # raw records (MSG_DTYPE) of one timestep
                     # the CSV writer sorts by mid with placeholders LAST (src/message.cpp:70-91)
-                    rows = sorted(step, key=lambda r: (r["mid"] < 0, r["mid"]))
-                    for r in rows:
-                        f.write(",".join(("%g" % r[c]) if isinstance(r[c], float) else str(r[c]) for c in cols) + "\n")
+                    order = sorted(range(len(step)), key=lambda i: (step["mid"][i] < 0, step["mid"][i]))
+                    for i in order:
+                        m = step[i]
+                        g, o = names.get(int(m["src_neuron"]), ("invalid", 0))
+                        csv = {"timestep": int(m["timestep"]), "mid": int(m["mid"]), "src_neuron": "%s.%d" % (g, o),
+                               "src_hw": "%d.%d" % (m["src_tile"], m["src_core_offset"]),
+                               "dest_hw": "x.x" if m["placeholder"] else "%d.%d" % (m["dest_tile"], m["dest_core_offset"]),
+                               "hops": int(m["hops"]), "spikes": int(m["spikes"]), "send_timestamp": float(m["sent_timestamp"])}
+                        for k in MSG_DBL:
+                            csv.setdefault(k, float(m[k]))
+                        f.write(",".join(("%g" % csv[c]) if isinstance(csv[c], float) else str(csv[c]) for c in cols) + "\n")
         finally:
             if close:
                 f.close()

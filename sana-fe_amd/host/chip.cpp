@@ -187,7 +187,6 @@ struct ExtStreams
 struct Msg : sanafe_message
 {
     bool in_noc{false};
-    int64_t src_x{0}, src_y{0}, dest_x{0}, dest_y{0};
 };
 } // namespace
 
@@ -982,6 +981,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_first_timestep = chip->total_timesteps + 1;
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty();
+    const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
+    record = (record & (SANAFE_RECORD_STEPS | SANAFE_RECORD_MESSAGES)) ? 1 : 0;
     // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
     if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
     {
@@ -990,13 +991,15 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                                                     "plugin units (detailed timing and traces need the whole chip in one process)");
         if (int rc = sim_sharded(chip, timesteps, run)) return rc;
     }
-    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units)
+    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages)
     {
         // Whole run stays on the device; nothing comes back per step unless recorded.  With external value
         // streams the run is cut into chunks whose stream rows fit a bounded upload (<= 64 MiB).
         DEV(sanafe_hip_reset_totals(chip->dev));
         const size_t n_ext = mc.ext.size();
         int64_t chunk_cap = n_ext == 0 ? std::max<int64_t>(timesteps, 1) : std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext));
+        // recorded runs keep a spike bitmap and a totals record per step on the device: bounded chunks (<= 64 MiB)
+        if (record) chunk_cap = std::min<int64_t>(chunk_cap, std::max<int64_t>(1, (int64_t{64} << 20) / (mc.n_slots / 8 + 96)));
         if (const char *env = std::getenv("SANAFE_EXT_CHUNK_STEPS")) // tests: force several chunks
             if (n_ext != 0) chunk_cap = std::max<int64_t>(1, std::atol(env));
         for (int64_t done = 0, m = 0; done < timesteps; done += m)
@@ -1024,6 +1027,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             chip->rec_count = timesteps;
         }
         chip->total_timesteps += timesteps;
+        chip->total_messages_sent += run.packets_sent; // every message takes an id under any timing model, src/chip.cpp:811
     }
     else
     {
@@ -1031,7 +1035,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         // (serial by construction, src/schedule.cpp:234-281), one step at a time.
         // The same stepwise loop serves plugin (host-evaluated) soma units under either timing model.
         const bool detailed = (timing_model == SANAFE_TIMING_DETAILED);
-        if (detailed && mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing needs a single-rank chip");
+        if ((detailed || want_messages) && mc.out_ptr.empty())
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces need a single-rank chip");
         std::vector<uint8_t> status(mc.n_slots);
         struct Job
         {
@@ -1052,8 +1057,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             {
                 std::vector<std::vector<Msg>> per_core;
                 chip->build_messages(job.ts.timesteps, job.status, per_core, job.mid_base);
-                job.ts.sim_time = chip->schedule_detailed(per_core, record != 0);
-                if (record)
+                job.ts.sim_time = chip->schedule_detailed(per_core, want_messages);
+                if (want_messages)
                     for (auto &q : per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
             }
             catch (const std::exception &e)
@@ -1117,6 +1122,22 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 {
                     chip->rec_totals.push_back(ts);
                     chip->rec_messages.emplace_back();
+                    if (want_messages)
+                    {
+                        // schedule_messages_timestep_simple, src/schedule.cpp:61-102: the messages stay in their source
+                        // cores' FIFOs; no blocking is modelled and the network delay is the minimum hop delay
+                        std::vector<uint8_t> st_copy(st_bytes, st_bytes + mc.n_slots);
+                        std::vector<std::vector<Msg>> per_core;
+                        chip->build_messages(ts.timesteps, st_copy, per_core, mid_base);
+                        std::vector<Msg> &flat = chip->rec_messages.back();
+                        for (auto &q : per_core)
+                            for (Msg &m : q)
+                            {
+                                m.blocking_delay = 0.0;
+                                m.network_delay = m.min_hop_delay;
+                                flat.push_back(m);
+                            }
+                    }
                     chip->rec_spike_bits.push_back(std::move(bits));
                 }
                 return 0;
@@ -1166,7 +1187,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             {
                 const int64_t k_steps = std::min(k_cap, timesteps - s);
                 if (int rc = chip->queue_ext(k_steps)) return rc;
-                DEV(sanafe_hip_step(chip->dev, k_steps, 0, 3));
+                DEV(sanafe_hip_step(chip->dev, k_steps, detailed ? 0 : 1, 3));
                 DEV(sanafe_hip_synchronize(chip->dev));
                 tsv.resize(k_steps);
                 stv.resize(static_cast<size_t>(k_steps) * mc.n_slots);
@@ -1498,6 +1519,7 @@ extern "C" int sanafe_chip_synchronize(sanafe_chip *chip)
     DEV(sanafe_hip_synchronize(chip->dev));
     return 0;
 }
+extern "C" int64_t sanafe_chip_total_timesteps(sanafe_chip *chip) { return chip ? chip->total_timesteps : 0; }
 extern "C" int sanafe_chip_read_totals(sanafe_chip *chip, sanafe_hip_totals *out)
 {
     if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");

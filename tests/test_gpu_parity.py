@@ -89,7 +89,7 @@ def test_example_chip_detailed_messages(S):
     arch, net = nets.example(S)
     chip, orc = make(S, arch, net)
     for t in range(12):
-        a = chip.run(1, "detailed", record=True)
+        a = chip.run(1, "detailed", record=True, messages=True)
         b = orc.step("detailed")
         assert a["sim_time"] == b["sim_time"], t  # same serial algorithm on identical inputs: bit-exact
         ma, mb = chip.step_messages(0), orc.messages()
@@ -112,7 +112,7 @@ def test_random_loihi_detailed_messages(S):
     arch, net = nets.random_loihi(S, n_tiles=6, neurons_per_core=50, out_degree=16, arch_kind="loihi", seed=3)
     chip, orc = make(S, arch, net)
     for t in range(8):
-        a = chip.run(1, "detailed", record=True)
+        a = chip.run(1, "detailed", record=True, messages=True)
         b = orc.step("detailed")
         ma, mb = chip.step_messages(0), orc.messages()
         assert len(ma) == len(mb) > 0
@@ -127,7 +127,7 @@ def test_detailed_scheduler_many_messages_in_flight(S):
     arch, net = nets.random_loihi(S, n_tiles=16, neurons_per_core=40, out_degree=120, arch_kind="loihi", p_fire=0.3, seed=21)
     chip, orc = make(S, arch, net)
     for t in range(5):
-        a = chip.run(1, "detailed", record=True)
+        a = chip.run(1, "detailed", record=True, messages=True)
         b = orc.step("detailed")
         ma, mb = chip.step_messages(0), orc.messages()
         assert len(ma) == len(mb) > 1000
@@ -454,7 +454,7 @@ def test_cpp_frontend_yaml_on_gpu(S):
     orc = OracleChip(S.to_desc(t_arch, t_net))
     fired = 0
     for t in range(60):
-        a, b = chip.run(1, "detailed", record=True), orc.step("detailed")
+        a, b = chip.run(1, "detailed", record=True, messages=True), orc.step("detailed")
         for ka, kb in INT_KEYS:
             assert a[ka] == b[kb], (t, ka)
         for k in DBL_KEYS:

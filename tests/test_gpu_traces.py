@@ -1,0 +1,138 @@
+"""The trace side of the sim() boundary on the HIP path, against the oracle:
+message traces under `simple` timing, message ids across sim() calls of different timing models, the exact key
+set of the in-memory traces, `update_every_timestep` units (forced_updates, src/chip.cpp:975-1026)."""
+import io
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nets  # noqa: E402
+from oracle.oracle import OracleChip  # noqa: E402
+
+# message_to_dict, src/pytrace.cpp:17-53
+MESSAGE_KEYS = {"generation_delay", "network_delay", "processing_delay", "blocking_delay", "send_timestamp",
+                "received_timestamp", "processed_timestamp", "timestep", "mid", "spikes", "hops", "src_neuron_offset",
+                "src_neuron_group_id", "src_x", "dest_x", "src_y", "dest_y", "src_tile_id", "src_core_id",
+                "src_core_offset", "dest_tile_id", "dest_core_id", "dest_core_offset", "dest_axon_hw", "dest_axon_id",
+                "placeholder"}
+# timestep_data_to_map, src/pytrace.cpp:55-74 (no "packets": that column exists in the CSV only, src/chip.cpp:1704-1729)
+PERF_KEYS = {"timestep", "fired", "updated", "hops", "spikes", "sim_time", "synapse_energy", "dendrite_energy",
+             "soma_energy", "network_energy", "total_energy"}
+
+
+def make(S, arch, net):
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    return chip, OracleChip(S.to_desc(arch, net))
+
+
+def same_messages(ma, mb, where):
+    assert len(ma) == len(mb), where
+    for name in ma.dtype.names:
+        assert np.array_equal(ma[name], mb[name]), (where, name)
+
+
+def test_message_trace_under_simple_timing(S):
+    """schedule_messages_timestep_simple (src/schedule.cpp:61-102) leaves network_delay = min_hop_delay,
+    blocking_delay = 0 and the timestamps at -inf; the messages stay in their source cores' FIFOs."""
+    arch, net = nets.random_loihi(S, n_tiles=6, neurons_per_core=50, out_degree=16, arch_kind="loihi", seed=3)
+    chip, orc = make(S, arch, net)
+    total = 0
+    for t in range(10):
+        a = chip.run(1, "simple", record=True, messages=True)
+        b = orc.step("simple")
+        ma, mb = chip.step_messages(0), orc.messages()
+        same_messages(ma, mb, t)
+        real = ma[ma["placeholder"] == 0]
+        assert np.array_equal(real["network_delay"], real["min_hop_delay"]) and not real["blocking_delay"].any()
+        assert np.all(np.isneginf(ma["sent_timestamp"]))
+        assert a["sim_time"] == pytest.approx(b["sim_time"], rel=1e-12)
+        total += len(real)
+    assert total > 100
+
+
+def test_message_ids_continue_across_timing_models(S):
+    """Every message takes an id under any timing model (src/chip.cpp:811): ids after an untraced `simple` run
+    continue where it stopped."""
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+    chip, orc = make(S, arch, net)
+    chip.run(9, "simple")
+    for _ in range(9):
+        orc.step("simple")
+    for t in range(4):
+        chip.run(1, "detailed", record=True, messages=True)
+        orc.step("detailed")
+        same_messages(chip.step_messages(0), orc.messages(), t)
+    assert chip.step_messages(0)["mid"].max() > 50
+
+
+def test_in_memory_trace_keys_and_csv(S, tmp_path):
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+    chip, _ = make(S, arch, net)
+    r = chip.sim(6, timing_model="simple", message_trace=True, perf_trace=True)
+    assert set(r["perf_trace"].keys()) == PERF_KEYS
+    assert len(r["message_trace"]) == 6 and sum(len(s) for s in r["message_trace"]) > 20
+    for step in r["message_trace"]:
+        mids = [m["mid"] for m in step]
+        assert mids == sorted(mids)  # plain mid order: placeholders (-1) first (src/pytrace.hpp:336-339)
+        for m in step:
+            assert set(m.keys()) == MESSAGE_KEYS
+            assert isinstance(m["src_neuron_group_id"], str) and isinstance(m["placeholder"], bool)
+    # the same run as CSV files: reference column layout, placeholders last (src/message.cpp:70-91)
+    chip2, _ = make(S, arch, net)
+    buf = io.StringIO()
+    perf = str(tmp_path / "perf.csv")
+    r2 = chip2.sim(6, timing_model="simple", message_trace=buf, perf_trace=perf)
+    assert r2["message_trace"] is None and r2["perf_trace"] is None
+    lines = buf.getvalue().splitlines()
+    assert lines[0] == ("timestep,mid,src_neuron,src_hw,dest_hw,hops,spikes,send_timestamp,received_timestamp,"
+                        "processed_timestamp,generation_delay,processing_delay,network_delay,blocking_delay,"
+                        "min_hop_delay,messages_along_route")
+    assert len(lines) - 1 == sum(len(s) for s in r["message_trace"])
+    assert open(perf).readline().strip().startswith("timestep,fired,updated,packets,hops,spikes,sim_time")
+
+
+def test_sim_rejects_before_running(S):
+    """An unsupported request must not advance the chip (the checks come before the first timestep)."""
+    arch, net = nets.example(S)
+    chip, _ = make(S, arch, net)
+    with pytest.raises(NotImplementedError):
+        chip.sim(5, timing_model="cycle")
+    assert chip.total_timesteps == 0
+    r = chip.sim(3, timing_model="simple")
+    assert r["timestep_start"] == 1 and chip.total_timesteps == 3
+
+
+@pytest.mark.parametrize("kind", ["delay_line", "taps"])
+def test_update_every_timestep_units(S, kind):
+    """forced_updates (src/chip.cpp:975-1026) calls `update` of flagged synapse / dendrite units once per step with no
+    input and keeps only an energy the MODEL returns.  The built-in units return none and catch their state up
+    lazily with the same operations, so the flag changes nothing observable -- checked against the oracle, which
+    performs the forced updates."""
+    if kind == "delay_line":
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=24, arch_kind="large", delays=True, seed=11)
+    else:
+        arch, net = nets.taps_dendrites(S)
+    flagged = 0
+    seen = set()
+    for core in arch.cores():
+        for u in core.units:  # cores replicated from one entry share their template's unit objects
+            if id(u) not in seen and (u.implements & (S.description.IMPL_SYNAPSE | S.description.IMPL_DENDRITE)) \
+                    and not (u.implements & S.description.IMPL_SOMA):
+                seen.add(id(u))
+                u.update_every_timestep = True
+                flagged += 1
+    assert flagged > 0
+    chip, orc = make(S, arch, net)
+    for t in range(30):
+        a = chip.run(1, "simple")
+        b = orc.step("simple")
+        assert a["neurons_fired"] == b["neurons_fired"] and a["spikes"] == b["spike_count"], t
+        assert a["total_energy"] == pytest.approx(b["total_energy"], rel=1e-12, abs=1e-30), t
+        assert np.array_equal(chip.status(), orc.status()), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
