@@ -93,6 +93,12 @@ int sanafe_chip_get_status(sanafe_chip *chip, uint8_t *out);      /* [n_neurons]
 int sanafe_chip_get_potentials(sanafe_chip *chip, double *out);   /* [n_neurons] */
 int sanafe_chip_get_input_current(sanafe_chip *chip, double *out);/* [n_neurons] LIF trace "u" */
 int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int64_t count, sanafe_hip_totals *out);
+/* Optional perf-trace columns (sim_trace_get_optional_traces, src/chip.cpp:1541-1579): `<tile>.energy`,
+ * `<tile>.<core>.energy`, `<tile>.<core>.<unit>.energy` / `.latency` for every tile / core / unit whose description
+ * sets log_energy / log_latency, in lexicographic order.  _perf_columns writes the NUL-separated names and returns
+ * the column count; _get_step_optional copies out[count][columns] of the recorded steps (sim with record). */
+int64_t sanafe_chip_perf_columns(sanafe_chip *chip, char *names, int64_t cap);
+int sanafe_chip_get_step_optional(sanafe_chip *chip, int64_t first, int64_t count, double *out);
 /* fired flag per neuron (desc order) of recorded step `index` of the last sim */
 int sanafe_chip_get_step_fired(sanafe_chip *chip, int64_t index, uint8_t *out);
 /* messages of recorded step `index` (detailed timing + record only), per-source-core order */

@@ -104,6 +104,18 @@ class OracleChip:
             lib().oracle_get_messages(self._h, out.ctypes.data, n)
         return out
 
+    def optional_traces(self):
+        """{column name: value} of the optional perf-trace columns of the last step."""
+        L = lib()
+        L.oracle_optional_traces.restype = C.c_int64
+        L.oracle_optional_traces.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+        n = L.oracle_optional_traces(self._h, None, 0, None, 0)
+        names = C.create_string_buffer(256 * max(1, n))
+        vals = np.zeros(max(1, n), dtype=np.float64)
+        L.oracle_optional_traces(self._h, names, len(names), vals.ctypes.data, n)
+        keys = names.raw.split(b"\0")[:n]
+        return {k.decode(): float(v) for k, v in zip(keys, vals[:n])}
+
     def reset(self):
         lib().oracle_reset(self._h)
 

@@ -1720,6 +1720,48 @@ extern "C" int64_t oracle_get_messages(const oracle_chip *chip, oracle_msg *out,
     return k;
 }
 
+// sim_trace_get_optional_traces, src/chip.cpp:1541-1579: the per-tile / per-core / per-unit columns of the perf
+// trace, in std::map (lexicographic) order; values are those of the timestep just simulated.  Names are written
+// NUL-separated into `names`; returns the number of columns.
+extern "C" int64_t oracle_optional_traces(const oracle_chip *chip, char *names, int64_t names_cap, double *values, int64_t cap)
+{
+    std::map<std::string, double> opt;
+    const sanafe_desc &d = *chip->desc;
+    for (const Tile &t : chip->tiles)
+    {
+        const std::string tn = chip->str(d.tile_name[t.id]);
+        if (d.tile_log_energy[t.id]) opt[tn + ".energy"] = t.energy;
+        for (size_t cid : t.cores)
+        {
+            const Core &c = chip->cores[cid];
+            const std::string cn = chip->str(d.core_name[cid]);
+            if (d.core_log_energy[cid]) opt[tn + "." + cn + ".energy"] = c.energy;
+            // every unit of the core exists in the reference from construction on (src/chip.cpp:83-87); this oracle
+            // instantiates on first use, so a unit nothing was mapped to is listed from the description, at 0.0
+            for (size_t slot = 0; slot < c.pipeline_hw.size(); slot++)
+            {
+                const int u = d.tmpl_unit_ptr[c.tmpl] + static_cast<int>(slot);
+                const Unit *hw = c.pipeline_hw[slot].get();
+                const std::string base = tn + "." + cn + "." + chip->str(d.unit_name[u]);
+                if (d.unit_flags[u] & SANAFE_UNIT_LOG_ENERGY) opt[base + ".energy"] = hw ? hw->energy : 0.0;
+                if (d.unit_flags[u] & SANAFE_UNIT_LOG_LATENCY) opt[base + ".latency"] = hw ? hw->latency : 0.0;
+            }
+        }
+    }
+    int64_t k = 0, pos = 0;
+    for (const auto &kv : opt)
+    {
+        if (values && k < cap) values[k] = kv.second;
+        if (names && pos + static_cast<int64_t>(kv.first.size()) + 1 <= names_cap)
+        {
+            std::memcpy(names + pos, kv.first.c_str(), kv.first.size() + 1);
+            pos += static_cast<int64_t>(kv.first.size()) + 1;
+        }
+        k++;
+    }
+    return k;
+}
+
 extern "C" void oracle_reset(oracle_chip *chip) // src/chip.cpp:576-600
 {
     for (Core &c : chip->cores)

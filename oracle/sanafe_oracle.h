@@ -60,6 +60,9 @@ void oracle_get_potentials(const oracle_chip *chip, double *out);
 /* named neuron trace (e.g. "u"), NaN where the neuron has no such trace. */
 void oracle_get_trace(const oracle_chip *chip, const char *name, double *out);
 /* Messages of the last step in per-source-core order; returns count. */
+/* Optional perf-trace columns of the last step (sim_trace_get_optional_traces, src/chip.cpp:1541-1579):
+ * NUL-separated names in lexicographic order + their values; returns the column count. */
+int64_t oracle_optional_traces(const oracle_chip *chip, char *names, int64_t names_cap, double *values, int64_t cap);
 int64_t oracle_get_messages(const oracle_chip *chip, oracle_msg *out,
         int64_t cap);
 void oracle_reset(oracle_chip *chip);

@@ -124,6 +124,9 @@ def lib():
                                             C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.sanafe_chip_synchronize.argtypes = [C.c_void_p]
     L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
+    L.sanafe_chip_perf_columns.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.sanafe_chip_perf_columns.restype = C.c_int64
+    L.sanafe_chip_get_step_optional.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.sanafe_chip_total_timesteps.argtypes = [C.c_void_p]
     L.sanafe_chip_total_timesteps.restype = C.c_int64
     L.sanafe_comm_unique_id.argtypes = [C.c_void_p]
@@ -290,6 +293,22 @@ class SpikingChip:
         self._check(self._L.sanafe_chip_get_step_totals(self._h, first, count, out.ctypes.data))
         return out
 
+    def perf_columns(self):
+        """Names of the optional perf-trace columns (tiles / cores / units with log_energy / log_latency)."""
+        n = self._L.sanafe_chip_perf_columns(self._h, None, 0)
+        if n <= 0:
+            return []
+        buf = C.create_string_buffer(512 * n)
+        self._L.sanafe_chip_perf_columns(self._h, buf, len(buf))
+        return [b.decode() for b in buf.raw.split(b"\0")[:n]]
+
+    def step_optional(self, first, count):
+        """[count, len(perf_columns())] values of the optional perf-trace columns of recorded steps."""
+        out = np.zeros((count, len(self.perf_columns())), dtype=np.float64)
+        if out.size:
+            self._check(self._L.sanafe_chip_get_step_optional(self._h, first, count, out.ctypes.data))
+        return out
+
     def step_fired(self, index):
         out = np.zeros(self.n_neurons, dtype=np.uint8)
         self._check(self._L.sanafe_chip_get_step_fired(self._h, index, out.ctypes.data))
@@ -329,11 +348,15 @@ class SpikingChip:
         want_steps = any(t is not None and t is not False for t in (spike_trace, perf_trace, message_trace))
         want_state = any(t is not None and t is not False for t in (potential_trace, neuron_trace))
         spikes, pots, ntraces, perf, msgs = [], [], {}, None, []
+        opt_names = self.perf_columns() if perf_trace else []
+        opt_rows = []
         if timing_model == "cycle":
             raise NotImplementedError("UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope")
         if not want_state:
             tot = self.run(timesteps, timing_model, record=want_steps, messages=bool(message_trace))
             steps = self.step_totals(0, timesteps) if want_steps and timesteps > 0 else None
+            if opt_names and timesteps > 0:
+                opt_rows = list(self.step_optional(0, timesteps))
             fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
             if message_trace:
                 msgs = [self.step_messages(i) for i in range(timesteps)]
@@ -345,6 +368,8 @@ class SpikingChip:
                 r = self.run(1, timing_model, record=True, messages=bool(message_trace))
                 tot = r if tot is None else {k: tot[k] + r[k] for k in r}
                 steps_l.append(self.step_totals(0, 1)[0])
+                if opt_names:
+                    opt_rows.append(self.step_optional(0, 1)[0])
                 fired.append(self.step_fired(0))
                 if message_trace:
                     msgs.append(self.step_messages(0))
@@ -378,6 +403,9 @@ class SpikingChip:
                     "synapse_energy": steps["synapse_energy"].tolist(), "dendrite_energy": steps["dendrite_energy"].tolist(),
                     "soma_energy": steps["soma_energy"].tolist(), "network_energy": steps["network_energy"].tolist(),
                     "total_energy": steps["total_energy"].tolist()}
+            # optional columns, in the reference's std::map order (src/chip.cpp:1541-1579, src/pytrace.hpp:249-258)
+            for k, name in enumerate(opt_names):
+                perf[name] = [float(row[k]) for row in opt_rows]
         result["spike_trace"] = spikes if spike_trace else None
         result["potential_trace"] = pots if potential_trace else None
         result["neuron_trace"] = ntraces if neuron_trace else None
@@ -448,7 +476,7 @@ class SpikingChip:
                         f.write("%d," % (start + i) + "".join("%g," % v for v in row) + "\n")
             elif key == "perf_trace":
                 cols = ["timestep", "fired", "updated", "packets", "hops", "spikes", "sim_time", "synapse_energy",
-                        "dendrite_energy", "soma_energy", "network_energy", "total_energy"]
+                        "dendrite_energy", "soma_energy", "network_energy", "total_energy"] + self.perf_columns()
                 if headers:
                     f.write(",".join(cols) + "\n")
                 for i in range(len(data["timestep"]) if data else 0):

@@ -320,6 +320,7 @@ struct sanafe_chip
     std::vector<sanafe_hip_totals> rec_totals;
     std::vector<std::vector<Msg>> rec_messages; // per recorded step, per-source-core order
     std::vector<std::vector<uint32_t>> rec_spike_bits;
+    std::vector<std::vector<double>> rec_optional; // per recorded step: the optional perf-trace columns (mc.log)
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
 
@@ -529,6 +530,73 @@ struct sanafe_chip
                 per_core[c].push_back(m);
             }
         }
+    }
+
+    // ------------------------------------------------------------------------------
+    // Optional perf-trace columns of one timestep (sim_trace_get_optional_traces, src/chip.cpp:1541-1579) from the
+    // status of every slot.  Per-unit energy is accumulated by the reference one pipeline call at a time
+    // (PipelineUnit::process, src/pipeline.cpp:87-105): first every neuron of every core in order, then every
+    // message in (source core, neuron, destination core) order with its synapses in connection order -- the same
+    // sequence of additions is replayed here.  unit.latency accumulates ENERGY (src/pipeline.cpp:102), so a
+    // `.latency` column repeats the `.energy` value.  Core and tile energies follow sim_calculate_core_energy /
+    // _tile_energy (src/chip.cpp:1188-1261); a tile's hop energy is summed per message here (per direction there).
+    // ------------------------------------------------------------------------------
+    std::vector<double> optional_columns(const uint8_t *status) const
+    {
+        const MappedChip::LogPlan &lg = mc.log;
+        std::vector<double> unit_e(lg.unit_used.size(), 0.0), tile_hop(mc.n_tiles, 0.0);
+        std::vector<int64_t> msgs_in(mc.n_cores, 0), packets_out(mc.n_cores, 0);
+        for (uint32_t c = 0; c < mc.n_cores; c++) // neuron processing
+            for (uint32_t k = 0; k < mc.core_ncount[c]; k++)
+            {
+                const uint32_t s = mc.core_nbase[c] + k;
+                const uint8_t stt = status[s];
+                if (stt == 0) continue;
+                const sanafe_hip_cost_class &cc = mc.cost_classes[(mc.slot_cls[s] >> 6) & 1023u];
+                if (lg.core_bp[c] <= SANAFE_BUF_INSIDE_DENDRITE) unit_e[lg.core_unit_beg[c] + lg.slot_dend_unit[s]] += cc.dendrite_energy;
+                unit_e[lg.core_unit_beg[c] + lg.slot_soma_unit[s]] += cc.soma_energy[stt - 1];
+            }
+        for (uint32_t c = 0; c < mc.n_cores; c++) // message processing
+            for (uint32_t k = 0; k < mc.core_ncount[c]; k++)
+            {
+                const uint32_t s = mc.core_nbase[c] + k;
+                if (status[s] != 3) continue;
+                for (uint64_t o = mc.out_ptr[s]; o < mc.out_ptr[s + 1]; o++)
+                {
+                    const uint64_t a = mc.out_axon[o];
+                    const uint32_t dc = mc.ax_dest_core[a];
+                    packets_out[c]++;
+                    msgs_in[dc]++;
+                    tile_hop[mc.core_tile[dc]] += lg.ax_e_hop[a];
+                    const uint64_t s0 = mc.core_syn_base[dc] + mc.ax_syn_beg[a];
+                    for (uint32_t q = 0; q < mc.ax_nsyn[a]; q++)
+                    {
+                        const uint16_t pair = lg.syn_units[s0 + q];
+                        unit_e[lg.core_unit_beg[dc] + (pair & 0xffu)] += lg.unit_e_spike[lg.core_unit_beg[dc] + (pair & 0xffu)];
+                        if (lg.core_bp[dc] > SANAFE_BUF_BEFORE_DENDRITE)
+                            unit_e[lg.core_unit_beg[dc] + (pair >> 8)] += lg.unit_e_update[lg.core_unit_beg[dc] + (pair >> 8)];
+                    }
+                }
+            }
+        std::vector<double> core_e(mc.n_cores, 0.0), tile_e(tile_hop);
+        for (uint32_t c = 0; c < mc.n_cores; c++)
+        {
+            double e = static_cast<double>(msgs_in[c]) * lg.core_e_ain[c], pipeline = 0.0;
+            for (uint32_t u = lg.core_unit_beg[c]; u < lg.core_unit_beg[c + 1]; u++)
+                if (lg.unit_used[u]) pipeline += unit_e[u];
+            e += pipeline;
+            // AxonOutUnit::energy accumulates energy_access once per packet, src/chip.cpp:826-829
+            double aout = 0.0;
+            for (int64_t p = 0; p < packets_out[c]; p++) aout += lg.core_e_aout[c];
+            e += aout;
+            core_e[c] = e;
+            tile_e[mc.core_tile[c]] += e;
+        }
+        std::vector<double> out;
+        out.reserve(lg.columns.size());
+        for (const MappedChip::LogPlan::Column &col : lg.columns)
+            out.push_back(col.kind == 0 ? tile_e[col.tile] : col.kind == 1 ? core_e[col.core] : unit_e[lg.core_unit_beg[col.core] + col.unit]);
+        return out;
     }
 
     // ---- detailed timing model: src/schedule.cpp:208-620 ----
@@ -978,6 +1046,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_totals.clear();
     chip->rec_messages.clear();
     chip->rec_spike_bits.clear();
+    chip->rec_optional.clear();
     chip->rec_first_timestep = chip->total_timesteps + 1;
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty();
@@ -991,7 +1060,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                                                     "plugin units (detailed timing and traces need the whole chip in one process)");
         if (int rc = sim_sharded(chip, timesteps, run)) return rc;
     }
-    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages)
+    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages && !(record && chip->mc.log.any))
     {
         // Whole run stays on the device; nothing comes back per step unless recorded.  With external value
         // streams the run is cut into chunks whose stream rows fit a bounded upload (<= 64 MiB).
@@ -1114,6 +1183,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 bits.assign(mc.n_slots / 32, 0);
                 for (uint32_t k = 0; k < mc.n_slots; k++)
                     if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
+                if (mc.log.any) chip->rec_optional.push_back(chip->optional_columns(st_bytes));
             }
             if (!detailed)
             {
@@ -1340,6 +1410,27 @@ extern "C" int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int
     if (!chip || !out || !chip->have_records || first < 0 || count < 0 || first + count > chip->rec_count)
         return fail(SANAFE_HIP_ERR_INVALID, "step records not available (sim with record=1)");
     std::copy(chip->rec_totals.begin() + first, chip->rec_totals.begin() + first + count, out);
+    return 0;
+}
+
+extern "C" int64_t sanafe_chip_perf_columns(sanafe_chip *chip, char *names, int64_t cap)
+{
+    if (!chip) return -1;
+    int64_t pos = 0;
+    for (const MappedChip::LogPlan::Column &col : chip->mc.log.columns)
+    {
+        const int64_t n = static_cast<int64_t>(col.name.size()) + 1;
+        if (names && pos + n <= cap) std::memcpy(names + pos, col.name.c_str(), static_cast<size_t>(n));
+        pos += n;
+    }
+    return static_cast<int64_t>(chip->mc.log.columns.size());
+}
+extern "C" int sanafe_chip_get_step_optional(sanafe_chip *chip, int64_t first, int64_t count, double *out)
+{
+    if (!chip || !out || !chip->have_records || first < 0 || count < 0 || first + count > static_cast<int64_t>(chip->rec_optional.size()))
+        return fail(SANAFE_HIP_ERR_INVALID, "optional perf columns not recorded (sim with record=1 on an architecture with log flags)");
+    const size_t n = chip->mc.log.columns.size();
+    for (int64_t k = 0; k < count; k++) std::copy(chip->rec_optional[first + k].begin(), chip->rec_optional[first + k].end(), out + k * n);
     return 0;
 }
 

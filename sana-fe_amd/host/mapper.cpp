@@ -150,7 +150,7 @@ struct UnitInfo // one pipeline unit of a core template
     std::string name;
     Model model{M_PLUGIN};
     bool syn{false}, dend{false}, soma{false};
-    bool update_every_timestep{false}, log{false};
+    bool update_every_timestep{false}, log{false}, log_energy{false}, log_latency{false};
     std::optional<double> e_spike, l_spike, e_update, l_update;
     bool has_soma_e{false}, has_soma_l{false};
     double se[3]{}, sl[3]{}; // access, update, spike_out
@@ -191,6 +191,8 @@ Template read_template(const sanafe_desc &d, int tm)
         ui.soma = d.unit_implements[u] & SANAFE_IMPL_SOMA;
         ui.update_every_timestep = d.unit_flags[u] & SANAFE_UNIT_UPDATE_EVERY_TIMESTEP;
         ui.log = d.unit_flags[u] & (SANAFE_UNIT_LOG_ENERGY | SANAFE_UNIT_LOG_LATENCY);
+        ui.log_energy = d.unit_flags[u] & SANAFE_UNIT_LOG_ENERGY;
+        ui.log_latency = d.unit_flags[u] & SANAFE_UNIT_LOG_LATENCY;
         bool want_syn = false, want_dend = false, want_soma = false;
         if (d.unit_plugin[u] >= 0) ui.model = M_PLUGIN;
         else if (model == "current_based") ui.model = M_CURRENT_BASED, want_syn = true;
@@ -743,6 +745,66 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
         }
     }
+    // ---- optional perf-trace columns (MappedChip::LogPlan) ----
+    {
+        MappedChip::LogPlan &lg = mc.log;
+        for (int t = 0; t < d.n_tiles; t++) lg.any = lg.any || d.tile_log_energy[t];
+        for (int c = 0; c < d.n_cores; c++)
+        {
+            lg.any = lg.any || d.core_log_energy[c];
+            for (const UnitInfo &u : tmpl_of(c).units) lg.any = lg.any || u.log;
+        }
+        if (lg.any)
+        {
+            if (n_ranks != 1) throw UnsupportedError("log_energy / log_latency columns need the whole chip in one process");
+            lg.core_unit_beg.assign(d.n_cores + 1, 0);
+            for (int c = 0; c < d.n_cores; c++) lg.core_unit_beg[c + 1] = lg.core_unit_beg[c] + static_cast<uint32_t>(tmpl_of(c).units.size());
+            const size_t nu = lg.core_unit_beg[d.n_cores];
+            lg.unit_e_spike.assign(nu, 0.0);
+            lg.unit_e_update.assign(nu, 0.0);
+            lg.unit_used.assign(nu, 0);
+            lg.slot_soma_unit.assign(LS, 0);
+            lg.slot_dend_unit.assign(LS, 0);
+            lg.core_e_ain.assign(d.n_cores, 0.0);
+            lg.core_e_aout.assign(d.n_cores, 0.0);
+            lg.core_bp.assign(d.n_cores, 0);
+            std::map<std::string, MappedChip::LogPlan::Column> cols;
+            for (int c = 0; c < d.n_cores; c++)
+            {
+                const Template &t = tmpl_of(c);
+                const uint32_t tile = d.core_tile[c];
+                const std::string tn = S(d, d.tile_name[tile]), cn = S(d, d.core_name[c]);
+                lg.core_bp[c] = d.core_buffer_pos[c];
+                lg.core_e_ain[c] = t.ain_e.size() == 1 ? t.ain_e[0] : 0.0;   // counters on unit 0, energy read from the LAST
+                lg.core_e_aout[c] = t.aout_e.size() == 1 ? t.aout_e[0] : 0.0; // unit (src/chip.cpp:1215-1221, 1248-1253)
+                if (d.tile_log_energy[tile]) cols[tn + ".energy"] = {tn + ".energy", 0, tile, 0, 0};
+                if (d.core_log_energy[c]) cols[tn + "." + cn + ".energy"] = {tn + "." + cn + ".energy", 1, tile, static_cast<uint32_t>(c), 0};
+                for (size_t u = 0; u < t.units.size(); u++)
+                {
+                    const UnitInfo &ui = t.units[u];
+                    const size_t k = lg.core_unit_beg[c] + u;
+                    if (ui.e_spike) lg.unit_e_spike[k] = *ui.e_spike;
+                    if (ui.e_update) lg.unit_e_update[k] = *ui.e_update;
+                    const std::string base = tn + "." + cn + "." + ui.name;
+                    if (ui.log_energy)
+                        cols[base + ".energy"] = {base + ".energy", 2, tile, static_cast<uint32_t>(c), static_cast<uint32_t>(u)};
+                    if (ui.log_latency)
+                        cols[base + ".latency"] = {base + ".latency", 3, tile, static_cast<uint32_t>(c), static_cast<uint32_t>(u)};
+                }
+            }
+            for (auto &kv : cols) lg.columns.push_back(kv.second);
+            for (int64_t gid = 0; gid < N; gid++)
+            {
+                const int32_t c = d.neuron_core[gid];
+                lg.unit_used[lg.core_unit_beg[c] + soma_unit[gid]] = 1;
+                lg.unit_used[lg.core_unit_beg[c] + dend_unit[gid]] = 1;
+                const uint32_t s = mc.slot_of_gid[gid];
+                if (s < SO || s >= SO + LS) continue;
+                lg.slot_soma_unit[s - SO] = static_cast<uint8_t>(soma_unit[gid]);
+                lg.slot_dend_unit[s - SO] = static_cast<uint8_t>(dend_unit[gid]);
+            }
+        }
+    }
     std::vector<uint32_t> rand_slots; // global slots of all TrueNorth neurons with random_mask != 0
     std::map<std::pair<int32_t, int>, uint32_t> noise_stream_ids; // (core, unit) -> stream
     for (int64_t gid = 0; gid < N; gid++)
@@ -759,7 +821,6 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             throw UnsupportedError("dendrite model of unit '" + du.name + "' is not implemented on the MI355X backend");
         if (du.model == M_TAPS && bp != SANAFE_BUF_BEFORE_SOMA)
             throw UnsupportedError("`taps` dendrites are implemented for `buffer_position: soma` (outside the unit) only");
-        if (du.log || su.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
         uint8_t kind = SANAFE_IN_BUFFERED;
         if (bp == SANAFE_BUF_INSIDE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_ZERO, neuron_dend_kind[gid] = 1;
         if (bp == SANAFE_BUF_BEFORE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_LAST;
@@ -1046,7 +1107,6 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const int su = memo_unit;
             const UnitInfo &u = tp.units[su];
             if (u.model != M_CURRENT_BASED) throw UnsupportedError("synapse unit '" + u.name + "' (plugin) is not implemented on the MI355X backend");
-            if (u.log) throw UnsupportedError("per-unit log_energy/log_latency is not implemented on the MI355X backend");
             if (!u.e_spike) throw std::runtime_error("Synapse unit does not simulate energy or provide a default energy cost in the architecture description.");
             if (!u.l_spike) throw std::runtime_error("Synapse unit does not simulate latency or provide a default latency cost in the architecture description.");
             edge_syn_unit[e] = su;
@@ -1146,6 +1206,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     const int64_t local_beg = first_at_or_after(mc.first_core), local_end = first_at_or_after(mc.last_core);
     mc.syn_meta.resize(static_cast<size_t>(local_end - local_beg));
     mc.syn_weight.resize(static_cast<size_t>(local_end - local_beg));
+    if (mc.log.any) mc.log.syn_units.resize(static_cast<size_t>(local_end - local_beg));
 
     // Pass 1 (threads, blocks of whole axons): everything about an axon that depends only on its own
     // edges.  Pass 2 (serial, below) numbers the axons and accumulates the per-neuron aggregates in
@@ -1154,7 +1215,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     {
         std::vector<uint32_t> pre, nsyn, hops, dc;
         std::vector<uint8_t> uniform;
-        std::vector<double> proc, first_lat, min_hop, e_net, e_syn, e_dend;
+        std::vector<double> proc, first_lat, min_hop, e_net, e_syn, e_dend, e_hop;
     };
     const int T = block_count(n_threads, static_cast<uint64_t>(E));
     std::vector<AxonBlock> blocks(T);
@@ -1217,6 +1278,12 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
                     mc.syn_meta[static_cast<size_t>(k - local_beg)] = meta;
                     mc.syn_weight[static_cast<size_t>(k - local_beg)] = d.edge_weight[e];
+                    if (mc.log.any)
+                    {
+                        mc.log.syn_units[static_cast<size_t>(k - local_beg)] =
+                                static_cast<uint16_t>(static_cast<uint32_t>(edge_syn_unit[e]) | (static_cast<uint32_t>(dend_unit[dst]) << 8));
+                        mc.log.unit_used[mc.log.core_unit_beg[dc] + edge_syn_unit[e]] = 1; // (benign race: every writer stores 1)
+                    }
                 }
             }
             // network costs: sim_estimate_network_costs, src/chip.cpp:1127-1169
@@ -1259,6 +1326,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             B.first_lat.push_back(first_lat);
             B.min_hop.push_back(min_hop);
             B.e_net.push_back((e_aout + e_hop) + e_ain);
+            if (mc.log.any) B.e_hop.push_back(e_hop);
             B.e_syn.push_back(e_syn);
             B.e_dend.push_back(e_dend);
             i = j;
@@ -1321,6 +1389,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 if (q < 255) cls = static_cast<uint8_t>(q);
             }
             mc.ax_lat_class.push_back(cls);
+            if (mc.log.any) mc.log.ax_e_hop.push_back(B.e_hop[a]);
             if (keep_out_tables)
             {
                 mc.ax_dest_core.push_back(dc);

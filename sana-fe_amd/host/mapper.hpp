@@ -155,6 +155,29 @@ struct MappedChip
     std::vector<HostUnit> host_units;
     std::vector<HostNeuron> host_neurons;
 
+    // ---- optional perf-trace columns: tiles / cores with log_energy, units with log_energy / log_latency
+    //      (sim_trace_get_optional_traces, src/chip.cpp:1541-1579).  Filled only when some flag is set. ----
+    struct LogPlan
+    {
+        bool any{false};
+        struct Column
+        {
+            std::string name;
+            uint8_t kind{0}; // 0 tile energy, 1 core energy, 2 unit energy, 3 unit latency
+            uint32_t tile{0}, core{0}, unit{0};
+        };
+        std::vector<Column> columns;               // std::map order (lexicographic by name)
+        std::vector<uint32_t> core_unit_beg;       // [n_cores + 1] first entry of each core in the unit_* arrays
+        std::vector<double> unit_e_spike, unit_e_update; // per (core, unit): energy per synaptic event / per dendrite update
+        std::vector<uint8_t> unit_used;            // PipelineUnit::is_used
+        std::vector<uint8_t> slot_soma_unit, slot_dend_unit; // per local slot: unit index inside its core
+        std::vector<uint16_t> syn_units;           // per local synapse: synapse unit | dendrite unit << 8
+        std::vector<double> ax_e_hop;              // per local axon: hop energy charged to the destination tile
+        std::vector<double> core_e_ain, core_e_aout; // per core: energy per message in / out (0 unless exactly one axon unit)
+        std::vector<int> core_bp;                  // buffer position of each core
+    };
+    LogPlan log;
+
     // neuron groups (for trace ordering: lexicographic group name, offset)
     std::vector<std::string> group_names;
     std::vector<int64_t> group_ptr;

@@ -136,3 +136,38 @@ def test_update_every_timestep_units(S, kind):
         assert a["total_energy"] == pytest.approx(b["total_energy"], rel=1e-12, abs=1e-30), t
         assert np.array_equal(chip.status(), orc.status()), t
         assert np.array_equal(chip.potentials(), orc.potentials()), t
+
+
+def test_optional_perf_columns(S):
+    """Tiles / cores with log_energy and units with log_energy / log_latency add columns to the perf trace
+    (sim_trace_get_optional_traces, src/chip.cpp:1541-1579); `unit.latency` accumulates ENERGY (src/pipeline.cpp:102)."""
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+    arch.tiles[1].log_energy = True
+    cores = arch.cores()
+    cores[2].log_energy = True
+    cores[5].log_energy = True
+    seen = set()
+    for core in cores:
+        for u in core.units:
+            if id(u) not in seen:
+                seen.add(id(u))
+                u.log_energy = True
+                u.log_latency = bool(u.implements & S.description.IMPL_SOMA)
+    chip, orc = make(S, arch, net)
+    names = chip.perf_columns()
+    assert names == sorted(names) and any(n.endswith(".latency") for n in names)
+    steps = 12
+    r = chip.sim(steps, timing_model="simple", perf_trace=True)
+    nonzero = 0
+    for t in range(steps):
+        orc.step("simple")
+        want = orc.optional_traces()
+        assert sorted(want) == names
+        for n in names:
+            assert r["perf_trace"][n][t] == pytest.approx(want[n], rel=1e-12, abs=1e-30), (t, n)
+            nonzero += want[n] != 0.0
+        for n in names:  # quirk 5
+            if n.endswith(".latency"):
+                assert r["perf_trace"][n][t] == r["perf_trace"][n[:-len(".latency")] + ".energy"][t]
+    assert nonzero > steps
+    assert set(r["perf_trace"]) == PERF_KEYS | set(names)
