@@ -202,11 +202,17 @@ int sanafe_hip_chip_create(const sanafe_hip_image *image, int device, sanafe_hip
 void sanafe_hip_chip_destroy(sanafe_hip_chip *chip);
 
 /* Runs `n_steps` timesteps back to back on the chip's stream (asynchronous).
- * `record` bit 0 keeps a per-step record (totals + spike bitmap) for sanafe_hip_read_step_*, bit 1 additionally the
+ * `record` bit 0 keeps a per-step record (totals + spike bitmap) for sanafe_hip_read_step_*, bit 3 the logged state
+ * (sanafe_hip_set_state_log), bit 1 additionally the
  * NeuronStatus of every slot (sanafe_hip_read_step_status; what the host needs to rebuild a step's messages for the
  * detailed timing model without a round trip per step); `simple_timing` != 0 evaluates the simple timing
  * model on the device (src/schedule.cpp:61-102). */
 int sanafe_hip_step(sanafe_hip_chip *chip, int64_t n_steps, int simple_timing, int record);
+/* Device-side compaction of the logged neurons (potential trace, src/chip.cpp:1786-1805; neuron traces :1807-1831):
+ * with `record` bit 3 (value 8) every recorded step keeps the potentials of the n_v listed slots followed by the LIF
+ * input currents of the n_u listed slots -- sanafe_hip_read_step_state copies out[count][n_v + n_u] rows. */
+int sanafe_hip_set_state_log(sanafe_hip_chip *chip, uint32_t n_v, const uint32_t *slots_v, uint32_t n_u, const uint32_t *slots_u);
+int sanafe_hip_read_step_state(sanafe_hip_chip *chip, int64_t first, int64_t count, double *out);
 /* Queues the external stream values of the next n_steps timesteps: values[step][column], int32:
  * input model 1 = "poisson_probability > U(0,1)" held, TrueNorth `rand() & mask`, LIF the sign-extended
  * noise value.  Every step of a chip with n_ext > 0 consumes one row; stepping past the queued rows

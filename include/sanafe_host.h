@@ -64,6 +64,7 @@ int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron);
  * timestamps -inf; src/schedule.cpp:61-102). */
 #define SANAFE_RECORD_STEPS 1
 #define SANAFE_RECORD_MESSAGES 4
+#define SANAFE_RECORD_STATE 8 /* potentials / input currents of the neurons listed with sanafe_chip_set_state_log */
 int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_model, int record, sanafe_hip_totals *run_data);
 /* Number of host threads that run the detailed NoC schedule of finished timesteps while the GPU
  * simulates ahead (SpikingChip::sim `scheduler_threads`, src/chip.cpp:291-349; 0 = inline). */
@@ -99,6 +100,11 @@ int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int64_t count,
  * the column count; _get_step_optional copies out[count][columns] of the recorded steps (sim with record). */
 int64_t sanafe_chip_perf_columns(sanafe_chip *chip, char *names, int64_t cap);
 int sanafe_chip_get_step_optional(sanafe_chip *chip, int64_t first, int64_t count, double *out);
+/* Potential and neuron traces (src/chip.cpp:1786-1831): the neurons whose potential (n_v) and LIF input current `u`
+ * (n_u) every recorded step keeps, sampled on the device right after the neuron update (no per-step host round trip);
+ * _get_step_state copies out[count][n_v + n_u] rows of a sim() run with SANAFE_RECORD_STATE. */
+int sanafe_chip_set_state_log(sanafe_chip *chip, int64_t n_v, const int64_t *neurons_v, int64_t n_u, const int64_t *neurons_u);
+int sanafe_chip_get_step_state(sanafe_chip *chip, int64_t first, int64_t count, double *out);
 /* fired flag per neuron (desc order) of recorded step `index` of the last sim */
 int sanafe_chip_get_step_fired(sanafe_chip *chip, int64_t index, uint8_t *out);
 /* messages of recorded step `index` (detailed timing + record only), per-source-core order */

@@ -127,6 +127,8 @@ def lib():
     L.sanafe_chip_perf_columns.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.sanafe_chip_perf_columns.restype = C.c_int64
     L.sanafe_chip_get_step_optional.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
+    L.sanafe_chip_set_state_log.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
+    L.sanafe_chip_get_step_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.sanafe_chip_total_timesteps.argtypes = [C.c_void_p]
     L.sanafe_chip_total_timesteps.restype = C.c_int64
     L.sanafe_comm_unique_id.argtypes = [C.c_void_p]
@@ -201,14 +203,29 @@ class SpikingChip:
         self._device, self._n_ranks, self._rank = device, n_ranks, rank
         self._h = None
         self._net = None
+        self._nets = []
         self._built = None
         self.total_timesteps = 0
 
     # -- SpikingChip::load (src/chip.cpp:129-138); Python default overwrite=False ---------------
     def load(self, net: D.Network, overwrite=False):
+        """SpikingChip::load (src/chip.cpp:129-138).  ``overwrite=False`` on a programmed chip ADDS the network: its
+        groups are mapped after the ones already there (neuron ids, mapping order and per-core offsets continue).
+        The chip is re-lowered from the combined description, so this is supported until the first timestep has
+        been simulated (the reference would also carry the running state of the first network over)."""
         if self._h is not None and not overwrite:
-            raise NotImplementedError("loading a second network into a programmed chip is not supported; "
-                                      "use load(net, overwrite=True)")
+            if self.total_timesteps > 0:
+                raise NotImplementedError("UnsupportedError: load(net, overwrite=False) after timesteps have been simulated "
+                                          "(the state of the programmed network cannot be carried into the re-lowered chip)")
+            if cpp is None or not isinstance(net, cpp.Network) or not all(isinstance(n, cpp.Network) for n in self._nets):
+                raise NotImplementedError("UnsupportedError: adding a network to a programmed chip needs sanafecpp_amd networks")
+            merged = cpp.Network(self._nets[0].name)
+            for n in self._nets + [net]:
+                merged.absorb(n)
+            self._nets.append(net)
+            net = merged
+        else:
+            self._nets = [net]
         self._free()
         self._net = net
         self._built = _Lowered(self.arch, net)
@@ -323,13 +340,29 @@ class SpikingChip:
             self._L.sanafe_chip_get_step_messages(self._h, index, out.ctypes.data, n)
         return out
 
-    RECORD_STEPS, RECORD_MESSAGES = 1, 4  # include/sanafe_host.h
+    RECORD_STEPS, RECORD_MESSAGES, RECORD_STATE = 1, 4, 8  # include/sanafe_host.h
 
-    def run(self, timesteps, timing_model="simple", record=False, messages=False):
+    def set_state_log(self, potential_gids, current_gids=()):
+        """Neurons whose potential / LIF input current every recorded step keeps (sampled on the device)."""
+        pv = np.ascontiguousarray(potential_gids, dtype=np.int64)
+        pu = np.ascontiguousarray(current_gids, dtype=np.int64)
+        self._check(self._L.sanafe_chip_set_state_log(self._h, len(pv), pv.ctypes.data if len(pv) else None, len(pu),
+                                                      pu.ctypes.data if len(pu) else None))
+        self._state_row = len(pv) + len(pu)
+
+    def step_state(self, first, count):
+        out = np.zeros((count, self._state_row), dtype=np.float64)
+        if out.size:
+            self._check(self._L.sanafe_chip_get_step_state(self._h, first, count, out.ctypes.data))
+        return out
+
+    def run(self, timesteps, timing_model="simple", record=False, messages=False, state=False):
         """One sanafe_chip_sim call; returns the raw totals dict.  ``record`` keeps the per-step totals and spike
-        lists, ``messages`` also every step's messages (step_messages)."""
+        lists, ``messages`` also every step's messages (step_messages), ``state`` the potentials / currents of the
+        neurons given to set_state_log (step_state)."""
         t = Totals()
-        flags = (self.RECORD_STEPS if record or messages else 0) | (self.RECORD_MESSAGES if messages else 0)
+        flags = (self.RECORD_STEPS if record or messages or state else 0) | (self.RECORD_MESSAGES if messages else 0) | \
+                (self.RECORD_STATE if state else 0)
         try:
             self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], flags, C.byref(t)))
         finally:
@@ -352,37 +385,26 @@ class SpikingChip:
         opt_rows = []
         if timing_model == "cycle":
             raise NotImplementedError("UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope")
-        if not want_state:
-            tot = self.run(timesteps, timing_model, record=want_steps, messages=bool(message_trace))
-            steps = self.step_totals(0, timesteps) if want_steps and timesteps > 0 else None
-            if opt_names and timesteps > 0:
-                opt_rows = list(self.step_optional(0, timesteps))
-            fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
-            if message_trace:
-                msgs = [self.step_messages(i) for i in range(timesteps)]
-        else:
-            # potentials / model traces are sampled after every step (src/pytrace.cpp:190-222)
-            tot = None
-            steps_l, fired = [], []
-            for _ in range(timesteps):
-                r = self.run(1, timing_model, record=True, messages=bool(message_trace))
-                tot = r if tot is None else {k: tot[k] + r[k] for k in r}
-                steps_l.append(self.step_totals(0, 1)[0])
-                if opt_names:
-                    opt_rows.append(self.step_optional(0, 1)[0])
-                fired.append(self.step_fired(0))
-                if message_trace:
-                    msgs.append(self.step_messages(0))
-                if potential_trace:
-                    v = self.potentials()
-                    sel = self._trace_order[self._log_potential[self._trace_order]]
-                    pots.append([float(x) for x in v[sel]])
-                if neuron_trace:
-                    u = self.input_currents()
-                    ntraces.setdefault("u", []).append([float(x) for x in u[self._trace_order]])
-            steps = np.array(steps_l, dtype=TOTALS_DTYPE) if steps_l else None
-            if tot is None:
-                tot = Totals().as_dict()
+        # One sanafe_chip_sim call whatever is traced: potentials and model traces are sampled on the device right after
+        # each neuron update (src/pytrace.cpp:190-222 samples them per step) and fetched in bulk afterwards.
+        pot_gids = self._trace_order[self._log_potential[self._trace_order]] if potential_trace else np.zeros(0, np.int64)
+        cur_gids = self._trace_order if neuron_trace else np.zeros(0, np.int64)
+        want_state = want_state and (len(pot_gids) + len(cur_gids)) > 0
+        if want_state:
+            self.set_state_log(pot_gids, cur_gids)
+        tot = self.run(timesteps, timing_model, record=want_steps or want_state, messages=bool(message_trace), state=want_state)
+        steps = self.step_totals(0, timesteps) if (want_steps or want_state) and timesteps > 0 else None
+        if opt_names and timesteps > 0:
+            opt_rows = list(self.step_optional(0, timesteps))
+        fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
+        if message_trace:
+            msgs = [self.step_messages(i) for i in range(timesteps)]
+        if potential_trace or neuron_trace:
+            state = self.step_state(0, timesteps) if want_state else np.zeros((timesteps, 0))
+            if potential_trace:
+                pots = state[:, :len(pot_gids)].tolist()
+            if neuron_trace:
+                ntraces["u"] = state[:, len(pot_gids):].tolist()
         result = {
             "timestep_start": start, "timesteps_executed": timesteps,
             "energy": {"total": tot["total_energy"], "synapse": tot["synapse_energy"], "dendrite": tot["dendrite_energy"],

@@ -88,6 +88,11 @@ struct sanafe_hip_chip
     std::vector<uint32_t> h_core_wg_beg, h_core_slice_beg; // host copies for sanafe_hip_read_core_delays
     std::vector<double> h_core_out_lat;
     uint64_t layout_bytes[SANAFE_HIP_LAYOUT_FIELDS]{};
+    // state log (record bit 3): potentials / input currents of listed slots, one row per recorded step
+    uint32_t *d_log_slots_v{nullptr}, *d_log_slots_u{nullptr};
+    uint32_t n_log_v{0}, n_log_u{0};
+    double *d_state_log{nullptr}; // [state_log_cap][n_log_v + n_log_u]
+    long long state_log_cap{0};
     uint32_t n_local_slices{0}; // leading slice descriptors whose axons all start on this chip
     int neuron_model{0};      // soma model every live slot runs (SANAFE_SOMA_LIF / _TRUENORTH), 0 when they differ
     bool uni{false};          // every live slot carries the class word us.cls (UniformSoma)
@@ -802,6 +807,8 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     if (c->st.status_log) (void) hipFree(c->st.status_log);
     if (c->st.delay_log) (void) hipFree(c->st.delay_log);
+    for (void *p : {(void *) c->d_log_slots_v, (void *) c->d_log_slots_u, (void *) c->d_state_log})
+        if (p) (void) hipFree(p);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
                  (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
@@ -829,6 +836,72 @@ static int ensure_log(sanafe_hip_chip *c, long long steps, bool with_status)
         HIPCHK(hipMemset(c->st.status_log, 0, (size_t) steps * c->im.n_slots)); // padding slots stay 0
     }
     c->st.log_cap = steps;
+    return 0;
+}
+
+static int ensure_state_log(sanafe_hip_chip *c, long long steps)
+{
+    const size_t row = (size_t) c->n_log_v + c->n_log_u;
+    if (row == 0) return fail(SANAFE_HIP_ERR_INVALID, "record bit 3 needs the slots to log (sanafe_hip_set_state_log)");
+    if (c->d_state_log && c->state_log_cap >= steps) return 0;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->d_state_log) HIPCHK(hipFree(c->d_state_log));
+    c->d_state_log = nullptr;
+    c->state_log_cap = 0;
+    HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_state_log), (size_t) steps * row * sizeof(double)));
+    c->state_log_cap = steps;
+    return 0;
+}
+static int launch_state_log(sanafe_hip_chip *c, long long rec_index)
+{
+    const uint32_t n = c->n_log_v + c->n_log_u;
+    double *row = c->d_state_log + (size_t) (rec_index % c->state_log_cap) * n;
+    hipLaunchKernelGGL(state_log_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, c->st.v, c->st.icur, c->d_log_slots_v, c->n_log_v,
+            c->d_log_slots_u, c->n_log_u, row, row + c->n_log_v);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sanafe_hip_set_state_log(sanafe_hip_chip *c, uint32_t n_v, const uint32_t *slots_v, uint32_t n_u, const uint32_t *slots_u)
+{
+    if (!c || (n_v > 0 && !slots_v) || (n_u > 0 && !slots_u)) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    for (uint32_t i = 0; i < n_v; i++)
+        if (slots_v[i] >= c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "logged slot %u out of range", i);
+    for (uint32_t i = 0; i < n_u; i++)
+        if (slots_u[i] >= c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "logged slot %u out of range", i);
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    for (uint32_t **p : {&c->d_log_slots_v, &c->d_log_slots_u})
+    {
+        if (*p) HIPCHK(hipFree(*p));
+        *p = nullptr;
+    }
+    if (c->d_state_log) HIPCHK(hipFree(c->d_state_log));
+    c->d_state_log = nullptr;
+    c->state_log_cap = 0;
+    c->n_log_v = c->n_log_u = 0;
+    if (n_v > 0)
+    {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_log_slots_v), (size_t) n_v * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_log_slots_v, slots_v, (size_t) n_v * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (n_u > 0)
+    {
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_log_slots_u), (size_t) n_u * sizeof(uint32_t)));
+        HIPCHK(hipMemcpy(c->d_log_slots_u, slots_u, (size_t) n_u * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    c->n_log_v = n_v;
+    c->n_log_u = n_u;
+    return 0;
+}
+extern "C" int sanafe_hip_read_step_state(sanafe_hip_chip *c, int64_t first, int64_t count, double *out)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->state_log_cap || !c->d_state_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "state records [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    const size_t row = (size_t) c->n_log_v + c->n_log_u;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(out, c->d_state_log + (size_t) first * row, (size_t) count * row * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
 
@@ -927,6 +1000,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
     {
         TRY(flush_pending(c)); // an earlier step's record must not land in the resized log
         TRY(ensure_log(c, n_steps, (record & 2) != 0));
+        if (record & 8) TRY(ensure_state_log(c, n_steps));
         HIPCHK(hipMemsetAsync(c->st.rec, 0, sizeof(long long), c->stream));
     }
     if (!c->timing)
@@ -934,6 +1008,7 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         for (int64_t s = 0; s < n_steps; s++)
         {
             TRY(launch_neurons(c, record, s));
+            if (record & 8) TRY(launch_state_log(c, s));
             TRY(launch_deliver(c, 0, c->im.n_slices));
             TRY(launch_taps(c));
             finish_step(c, simple_timing, record, s);

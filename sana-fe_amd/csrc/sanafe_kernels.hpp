@@ -1242,6 +1242,17 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
     }
 }
 
+// Device-side compaction of the logged neurons (potential / neuron traces, src/chip.cpp:1766-1831): after the
+// neuron launch of a recorded step, the potentials of the `n_v` listed slots and the input currents of the `n_u`
+// listed slots go into one row each of the state log -- no per-step host round trip, no full-state copy.
+__global__ void state_log_kernel(const double *v, const double *icur, const uint32_t *slots_v, uint32_t n_v, const uint32_t *slots_u,
+        uint32_t n_u, double *row_v, double *row_u)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_v) row_v[i] = v[slots_v[i]];
+    else if (i - n_v < n_u) row_u[i - n_v] = icur[slots_u[i - n_v]];
+}
+
 // Flushes pending reductions when no further neuron launch follows: grid = n_reduce_wgs (or 1 for level 2 only).
 __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PendStep l1, PendStep l2)
 {

@@ -321,6 +321,9 @@ struct sanafe_chip
     std::vector<std::vector<Msg>> rec_messages; // per recorded step, per-source-core order
     std::vector<std::vector<uint32_t>> rec_spike_bits;
     std::vector<std::vector<double>> rec_optional; // per recorded step: the optional perf-trace columns (mc.log)
+    // state log (potential / neuron traces): neurons whose potential / input current every recorded step keeps
+    std::vector<int64_t> log_v_gids, log_u_gids;
+    std::vector<double> rec_state; // [recorded steps][log_v_gids + log_u_gids]
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
 
@@ -1051,7 +1054,12 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty();
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
-    record = (record & (SANAFE_RECORD_STEPS | SANAFE_RECORD_MESSAGES)) ? 1 : 0;
+    const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
+    if (want_state && chip->log_v_gids.empty() && chip->log_u_gids.empty())
+        return fail(SANAFE_HIP_ERR_INVALID, "SANAFE_RECORD_STATE needs the neurons to log (sanafe_chip_set_state_log)");
+    record = (record & (SANAFE_RECORD_STEPS | SANAFE_RECORD_MESSAGES | SANAFE_RECORD_STATE)) ? 1 : 0;
+    const size_t state_row = chip->log_v_gids.size() + chip->log_u_gids.size();
+    chip->rec_state.clear();
     // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
     if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
     {
@@ -1068,15 +1076,20 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         const size_t n_ext = mc.ext.size();
         int64_t chunk_cap = n_ext == 0 ? std::max<int64_t>(timesteps, 1) : std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext));
         // recorded runs keep a spike bitmap and a totals record per step on the device: bounded chunks (<= 64 MiB)
-        if (record) chunk_cap = std::min<int64_t>(chunk_cap, std::max<int64_t>(1, (int64_t{64} << 20) / (mc.n_slots / 8 + 96)));
+        if (record) chunk_cap = std::min<int64_t>(chunk_cap, std::max<int64_t>(1, (int64_t{64} << 20) / static_cast<int64_t>(mc.n_slots / 8 + 96 + (want_state ? state_row * 8 : 0))));
         if (const char *env = std::getenv("SANAFE_EXT_CHUNK_STEPS")) // tests: force several chunks
             if (n_ext != 0) chunk_cap = std::max<int64_t>(1, std::atol(env));
         for (int64_t done = 0, m = 0; done < timesteps; done += m)
         {
             m = std::min(chunk_cap, timesteps - done);
             if (int rc = chip->queue_ext(m)) return rc;
-            DEV(sanafe_hip_step(chip->dev, m, 1, record));
+            DEV(sanafe_hip_step(chip->dev, m, 1, record | (want_state ? 8 : 0)));
             DEV(sanafe_hip_synchronize(chip->dev));
+            if (want_state && m > 0)
+            {
+                chip->rec_state.resize(static_cast<size_t>(done + m) * state_row);
+                DEV(sanafe_hip_read_step_state(chip->dev, 0, m, chip->rec_state.data() + static_cast<size_t>(done) * state_row));
+            }
             if (record && m > 0)
             {
                 chip->rec_totals.resize(done + m);
@@ -1257,8 +1270,13 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             {
                 const int64_t k_steps = std::min(k_cap, timesteps - s);
                 if (int rc = chip->queue_ext(k_steps)) return rc;
-                DEV(sanafe_hip_step(chip->dev, k_steps, detailed ? 0 : 1, 3));
+                DEV(sanafe_hip_step(chip->dev, k_steps, detailed ? 0 : 1, 3 | (want_state ? 8 : 0)));
                 DEV(sanafe_hip_synchronize(chip->dev));
+                if (want_state)
+                {
+                    chip->rec_state.resize(static_cast<size_t>(s + k_steps) * state_row);
+                    DEV(sanafe_hip_read_step_state(chip->dev, 0, k_steps, chip->rec_state.data() + static_cast<size_t>(s) * state_row));
+                }
                 tsv.resize(k_steps);
                 stv.resize(static_cast<size_t>(k_steps) * mc.n_slots);
                 DEV(sanafe_hip_read_step_totals(chip->dev, 0, k_steps, tsv.data()));
@@ -1292,6 +1310,15 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             sanafe_hip_totals ts{};
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
             DEV(sanafe_hip_read_status(chip->dev, status.data()));
+            if (want_state) // plugin somas keep their own potentials: sampled on the host
+            {
+                std::vector<double> v(static_cast<size_t>(chip->n_neurons)), u(static_cast<size_t>(chip->n_neurons));
+                if (int rc = sanafe_chip_get_potentials(chip, v.data())) return rc;
+                if (!chip->log_u_gids.empty())
+                    if (int rc = sanafe_chip_get_input_current(chip, u.data())) return rc;
+                for (int64_t g : chip->log_v_gids) chip->rec_state.push_back(v[g]);
+                for (int64_t g : chip->log_u_gids) chip->rec_state.push_back(u[g]);
+            }
             if (int rc = process_step(ts, status.data())) return rc;
         }
         if (detailed)
@@ -1410,6 +1437,38 @@ extern "C" int sanafe_chip_get_step_totals(sanafe_chip *chip, int64_t first, int
     if (!chip || !out || !chip->have_records || first < 0 || count < 0 || first + count > chip->rec_count)
         return fail(SANAFE_HIP_ERR_INVALID, "step records not available (sim with record=1)");
     std::copy(chip->rec_totals.begin() + first, chip->rec_totals.begin() + first + count, out);
+    return 0;
+}
+
+extern "C" int sanafe_chip_set_state_log(sanafe_chip *chip, int64_t n_v, const int64_t *neurons_v, int64_t n_u, const int64_t *neurons_u)
+{
+    if (!chip || n_v < 0 || n_u < 0 || (n_v > 0 && !neurons_v) || (n_u > 0 && !neurons_u)) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    if (!chip->dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "the chip has no device (mapped only)");
+    const MappedChip &mc = chip->mc;
+    std::vector<uint32_t> sv, su;
+    auto to_slots = [&](const int64_t *g, int64_t n, std::vector<uint32_t> &out) {
+        for (int64_t i = 0; i < n; i++)
+        {
+            if (g[i] < 0 || g[i] >= chip->n_neurons) return false;
+            const uint32_t s = mc.slot_of_gid[g[i]];
+            if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots) return false; // another rank's neuron
+            out.push_back(s - mc.slot_offset);
+        }
+        return true;
+    };
+    if (!to_slots(neurons_v, n_v, sv) || !to_slots(neurons_u, n_u, su))
+        return fail(SANAFE_HIP_ERR_INVALID, "logged neuron id out of range (or held by another rank)");
+    DEV(sanafe_hip_set_state_log(chip->dev, static_cast<uint32_t>(sv.size()), sv.data(), static_cast<uint32_t>(su.size()), su.data()));
+    chip->log_v_gids.assign(neurons_v, neurons_v + n_v);
+    chip->log_u_gids.assign(neurons_u, neurons_u + n_u);
+    return 0;
+}
+extern "C" int sanafe_chip_get_step_state(sanafe_chip *chip, int64_t first, int64_t count, double *out)
+{
+    const size_t row = chip ? chip->log_v_gids.size() + chip->log_u_gids.size() : 0;
+    if (!chip || !out || first < 0 || count < 0 || row == 0 || static_cast<size_t>(first + count) * row > chip->rec_state.size())
+        return fail(SANAFE_HIP_ERR_INVALID, "state records not available (sim with SANAFE_RECORD_STATE)");
+    std::copy(chip->rec_state.begin() + first * row, chip->rec_state.begin() + (first + count) * row, out);
     return 0;
 }
 

@@ -264,6 +264,49 @@ void SpikingNetwork::add_edges(const int64_t *s, const int64_t *d, const double 
     else if (!edge_delay.empty()) edge_delay.insert(edge_delay.end(), n, -1);
 }
 
+void SpikingNetwork::absorb(const SpikingNetwork &other)
+{
+    auto re = [&](int32_t id) { return id < 0 ? -1 : intern(other.strings[id]); };
+    for (const auto &gp : other.order)
+        if (groups.count(gp->name))
+            throw std::invalid_argument("Group: " + gp->name + " already exists on the chip (load(net, overwrite=False) adds the "
+                                        "network's groups to the programmed ones).");
+    const int64_t gid0 = neuron_count, map0 = mapping_count;
+    for (const auto &gp : other.order)
+    {
+        const NeuronGroup &o = *gp;
+        order.push_back(std::make_unique<NeuronGroup>(this, o.name, o.count, gid0 + o.base));
+        NeuronGroup &g = *order.back();
+        groups[g.name] = &g;
+        g.core = o.core;
+        g.log_spikes = o.log_spikes;
+        g.log_potential = o.log_potential;
+        for (int64_t i = 0; i < o.count; i++)
+        {
+            g.soma_hw[i] = re(o.soma_hw[i]);
+            g.dendrite_hw[i] = re(o.dendrite_hw[i]);
+            g.synapse_hw[i] = re(o.synapse_hw[i]);
+            g.map_order[i] = o.map_order[i] + map0;
+        }
+        g.columns = o.columns;
+        for (auto &kv : g.columns)
+            for (int32_t &sid : kv.second.str) sid = re(sid);
+        g.list_values = o.list_values;
+    }
+    neuron_count += other.neuron_count;
+    mapping_count += other.mapping_count;
+    const size_t e0 = edge_src.size(), n = other.edge_src.size();
+    if (!other.edge_delay.empty() && edge_delay.empty()) edge_delay.assign(e0, -1);
+    for (size_t i = 0; i < n; i++)
+    {
+        edge_src.push_back(other.edge_src[i] + gid0);
+        edge_dst.push_back(other.edge_dst[i] + gid0);
+        edge_weight.push_back(other.edge_weight[i]);
+        edge_synapse_hw.push_back(re(other.edge_synapse_hw[i]));
+        if (!edge_delay.empty() || !other.edge_delay.empty()) edge_delay.push_back(i < other.edge_delay.size() ? other.edge_delay[i] : int8_t{-1});
+    }
+}
+
 NeuronGroup &SpikingNetwork::create_neuron_group(const std::string &group_name, int64_t n,
         const std::map<std::string, std::pair<AttrValue, int>> &attributes, const std::string &syn, const std::string &dend, bool lp,
         bool ls, const std::string &soma)

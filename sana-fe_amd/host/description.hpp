@@ -202,6 +202,9 @@ public:
     void add_edges(const int64_t *src, const int64_t *dst, const double *weight, const int8_t *delay, int32_t synapse_hw,
             int64_t n);
     int64_t edge_count() const { return static_cast<int64_t>(edge_src.size()); }
+    // Appends a copy of every group, mapping and edge of `other` (neuron ids and mapping order continue after this
+    // network's): what a chip holds after SpikingChip::load(other, overwrite = false), src/chip.cpp:129-138.
+    void absorb(const SpikingNetwork &other);
 };
 
 // Owns every buffer behind a sanafe_desc.

@@ -325,6 +325,8 @@ PYBIND11_MODULE(sanafecpp_amd, m)
             .def(py::init<std::string>(), py::arg("name") = "")
             .def_readonly("name", &SpikingNetwork::name)
             .def_readonly("neuron_count", &SpikingNetwork::neuron_count)
+            .def("absorb", &SpikingNetwork::absorb, py::arg("other"),
+                    "Append a copy of every group, mapping and edge of `other` (SpikingChip.load(net, overwrite=False)).")
             .def_property_readonly("edge_count", &SpikingNetwork::edge_count)
             .def(
                     "create_neuron_group",

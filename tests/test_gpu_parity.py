@@ -313,10 +313,30 @@ def test_tutorial5_dvs_golden_on_gpu(S):
 
 @pytest.mark.slow
 def test_dvs_yaml_c2_spike_trace(S):
-    """Config C2: loihi + dvs.yaml, spike trace bit-exact vs the oracle, potentials of group 1 equal."""
+    """Config C2 at its full length: loihi + dvs.yaml, 1000 timesteps through SpikingChip.sim() with the spike trace of
+    all 18,678 neurons (log_spikes) and the potential trace of group 1 (log_potential, 3,600 neurons) -- the spike
+    trace bit-exact against the oracle step by step, every per-step potential of group 1 equal (integer weights and
+    thresholds: exact; BASELINE asks for <= 1e-6 relative)."""
     arch, net = nets.dvs_yaml(S)
-    chip, orc, tot = check_batched(S, arch, net, steps=300)
-    assert tot["neurons_fired"] > 0
+    chip, orc = make(S, arch, net)
+    steps = 1000
+    r = chip.sim(steps, timing_model="simple", spike_trace=True, potential_trace=True, perf_trace=True)
+    logged = chip._trace_order[chip._log_potential[chip._trace_order]]
+    assert len(logged) == 3600 and len(r["spike_trace"]) == steps and len(r["potential_trace"]) == steps
+    labels = chip._labels()
+    order = chip._trace_order
+    fired_total = 0
+    for t in range(steps):
+        b = orc.step("simple")
+        st = orc.status()
+        want = [labels[int(g)] for g in order[(st[order] == 3) & chip._log_spikes[order]]]
+        assert r["spike_trace"][t] == want, t
+        assert np.array_equal(np.asarray(r["potential_trace"][t]), orc.potentials()[logged]), t
+        assert r["perf_trace"]["fired"][t] == b["neurons_fired"] and r["perf_trace"]["spikes"][t] == b["spike_count"], t
+        assert r["perf_trace"]["total_energy"][t] == pytest.approx(b["total_energy"], rel=REL), t
+        assert r["perf_trace"]["sim_time"][t] == pytest.approx(b["sim_time"], rel=REL), t
+        fired_total += b["neurons_fired"]
+    assert r["neurons_fired"] == fired_total > 10000
 
 
 def test_set_bias_between_sims(S):

@@ -171,3 +171,50 @@ def test_optional_perf_columns(S):
                 assert r["perf_trace"][n][t] == r["perf_trace"][n[:-len(".latency")] + ".energy"][t]
     assert nonzero > steps
     assert set(r["perf_trace"]) == PERF_KEYS | set(names)
+
+
+def test_second_load_adds_a_network(S):
+    """SpikingChip::load(net, overwrite=False) on a programmed chip maps the new groups after the programmed ones
+    (src/chip.cpp:129-138; the Python default is overwrite=False, src/pymodule.cpp:1195-1197)."""
+    def arch_():
+        return S.presets.loihi(n_inputs=4)
+
+    def add_group(net, name, n, core, seed):
+        rng = np.random.default_rng(seed)
+        g = net.create_neuron_group(name, n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
+                                    "loihi_dendrites", False, True, "loihi_lif")
+        g.set_attribute_column("bias", np.where(rng.random(n) < 0.3, 128.0, 0.0), integer=True)
+        g.map_to_core(core, 0, n)
+        return g, rng
+
+    def wire(net, g, n, rng, base=0):
+        src = np.repeat(np.arange(n, dtype=np.int64), 8) + base
+        dst = rng.integers(0, n, size=8 * n).astype(np.int64) + base
+        net.add_edges(src, dst, rng.integers(1, 9, size=8 * n).astype(np.float64), "loihi_sparse_synapse")
+
+    arch = arch_()
+    cores = arch.cores()
+    net_a, net_b, both = S.Network("a"), S.Network("b"), S.Network("ab")
+    ga, ra = add_group(net_a, "first", 96, cores[0], 1)
+    wire(net_a, ga, 96, ra)
+    gb, rb = add_group(net_b, "second", 80, cores[5], 2)
+    wire(net_b, gb, 80, rb)
+    g1, r1 = add_group(both, "first", 96, cores[0], 1)
+    wire(both, g1, 96, r1)
+    g2, r2 = add_group(both, "second", 80, cores[5], 2)
+    wire(both, g2, 80, r2, base=96)
+
+    chip = S.SpikingChip(arch)
+    chip.load(net_a)
+    chip.load(net_b)  # overwrite=False: both networks are on the chip now
+    ref = S.SpikingChip(arch)
+    ref.load(both)
+    assert chip.n_neurons == ref.n_neurons == 176 and set(chip.mapped_neuron_groups) == {"first", "second"}
+    a, b = chip.sim(25, timing_model="simple", spike_trace=True), ref.sim(25, timing_model="simple", spike_trace=True)
+    assert a["neurons_fired"] == b["neurons_fired"] > 0 and a["spikes"] == b["spikes"] > 0
+    assert a["spike_trace"] == b["spike_trace"] and a["energy"] == b["energy"] and a["sim_time"] == b["sim_time"]
+    assert np.array_equal(chip.potentials(), ref.potentials())
+    with pytest.raises(NotImplementedError):
+        chip.load(net_b)  # timesteps have been simulated
+    chip.load(net_b, overwrite=True)  # clear_hw + load: only the new network remains
+    assert chip.n_neurons == 80 and chip.total_timesteps == 0
