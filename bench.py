@@ -29,7 +29,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0):
+def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0, weights="int8"):
     """Built through the product front-end (C++17 / PyBind11 description objects)."""
     n_tiles = max(1024, (cores_per_gpu * n_gpus + 3) // 4) if cores_per_gpu * n_gpus > 4096 else 1024
     arch = S.presets.loihi_large(n_tiles=n_tiles, n_inputs=4)
@@ -45,6 +45,10 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
     # a rank only needs the edges that start or end in its own shard of the neurons
     shard = None if n_gpus == 1 else (rank * n_per_gpu, (rank + 1) * n_per_gpu)
     src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard)
+    if weights == "int12":    # integers beyond int8: the 12-bit-weight synapse word (format 3)
+        w *= 100.0
+    elif weights == "float":  # not representable as integers: fp64 weights beside the synapse words (format 4)
+        w *= 0.7310585786300049
     net.add_edges(src, dst, w, "loihi_sparse_synapse")
     del src, dst, w
     for r in range(n_gpus):
@@ -198,6 +202,8 @@ def main():
     ap.add_argument("--neurons-per-core", type=int, default=512)
     ap.add_argument("--out-degree", type=int, default=2621)
     ap.add_argument("--p-fire", type=float, default=0.1)
+    ap.add_argument("--weights", choices=("int8", "int12", "float"), default="int8",
+                    help="c3: synaptic weights -- integers in +-8 (default, SURVEY 8d), integers in +-800, or non-integers")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -243,11 +249,13 @@ def main():
                     "one out-edge per neuron, 80%% remote" % (n_total, args.tiles_per_gpu))
     else:
         arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire,
-                                   args.seed, rank)
+                                   args.seed, rank, args.weights)
         n_total = args.cores_per_gpu * args.neurons_per_core * world
         workload = ("arch/loihi_large.yaml + synthetic random SNN (BASELINE configs[2]): %d LIF neurons (%d cores x %d per "
                     "GPU), out-degree %d, %.0f%% biased to fire every step, loihi_dendrites_delay"
                     % (n_total, args.cores_per_gpu, args.neurons_per_core, args.out_degree, 100 * args.p_fire))
+        if args.weights != "int8":
+            workload += ", %s weights" % args.weights
     workload += ", %s timing" % args.timing
     t_net = time.perf_counter() - t_setup
     chip = S.SpikingChip(arch, device=0 if args.same_device else local_rank, n_ranks=world, rank=rank)

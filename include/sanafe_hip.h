@@ -219,9 +219,10 @@ int sanafe_hip_read_step_state(sanafe_hip_chip *chip, int64_t first, int64_t cou
  * fails with SANAFE_HIP_ERR_INVALID (no default values are invented). */
 int sanafe_hip_write_ext(sanafe_hip_chip *chip, int64_t n_steps, const int32_t *values);
 int sanafe_hip_synchronize(sanafe_hip_chip *chip);
-/* How the image was packed for the device (diagnostics, tests): synapse format 0 = 2+1 bytes (12-bit post,
- * int8 weight), 1 = 4 bytes (12-bit integer weight), 2 = 4+8 bytes (fp64 weight); number of delivery slices
- * whose axon records use the 2-byte delta form instead of the 8-byte form. */
+/* How the image was packed for the device (diagnostics, tests): synapse format 0 = 4 bytes (axon code, accumulator
+ * index, int8 weight), 3 = 4 bytes (12-bit integer weight), 4 = 4 + 8 bytes (fp64 weight) -- the streamable layouts --
+ * or the gather-only fall-backs 1 = 4 bytes (12-bit weight), 2 = 4 + 8 bytes for cores with too many accumulators;
+ * number of delivery slices whose axon records use the 2-byte delta form instead of the 8-byte form. */
 int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_compact_slices);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.

@@ -98,7 +98,7 @@ struct sanafe_hip_chip
     bool uni{false};          // every live slot carries the class word us.cls (UniformSoma)
     UniformSoma us{};
     std::vector<sanafe_hip_soma_class> h_soma_classes; // host copy of the class table the device uses
-    int syn_format{2};        // 0: 2+1 B, 1: 4 B, 2: 4+8 B per synapse (DevImage)
+    int syn_format{2};        // 0..4, see DevImage
     uint32_t n_compact_slices{0};
     DevImage im{};
     DevState st{};
@@ -447,12 +447,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     im.n_ext = h.n_ext;
     im.slot_ext = nullptr;
     if (h.n_ext > 0) TRYC(upload(c, h.slot_ext, h.n_slots, &im.slot_ext));
-    // ---- synapse format: the narrowest of the three that holds every weight exactly (see DevImage) ----
-    //   0: post < 4096 and int8 weights; 1: 12-bit integer weights; 2: fp64 weights
+    // ---- synapse format: the narrowest that holds every weight exactly and every accumulator index (see DevImage) ----
+    //   streamable: 0 int8 weights, 3 12-bit integer weights, 4 fp64 weights; gather-only fall-backs: 1 (12-bit), 2 (fp64)
     {
         std::atomic<int> need{0};
-        bool small_cores = true;
-        for (uint32_t k = 0; k < h.n_cores; k++) small_cores = small_cores && h.core_ncount[k] <= 4032u; // post and trash index in 12 bits
         parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
             int fmt = 0;
             for (uint64_t k = lo; k < hi && fmt < 2; k++)
@@ -479,13 +477,24 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             fmt0_rows = md.load() + 1;
             for (uint32_t k = 0; k < h.n_cores; k++) fmt0_max_pad = std::max(fmt0_max_pad, (h.core_ncount[k] + 63u) & ~63u);
         }
-        if (fmt == 0 && (!small_cores || (uint64_t) fmt0_rows * (fmt0_max_pad + 1u) > 32768ull)) fmt = 1;
+        // the index-coded words address (max delay + 1) rows of npad + 1 accumulators: 15 bits (12 with 12-bit weights)
+        const uint64_t n_acc = (uint64_t) fmt0_rows * (fmt0_max_pad + 1u);
+        const int weights = fmt; // 0 int8, 1 12-bit integers, 2 fp64
+        if (weights == 0) fmt = n_acc <= 32768ull ? 0 : 1;
+        else if (weights == 1) fmt = n_acc <= 4096ull ? 3 : 1;
+        else fmt = n_acc <= 32768ull ? 4 : 2;
         if (h.n_synapses == 0) fmt = 2;
-        if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // experiments: force a wider format
-            fmt = std::max(fmt, std::min(2, std::atoi(env)));
+        if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // tests / experiments: 1 or 2 force the gather-only
+        {                                                       // layouts, 3 / 4 the wider streamable ones
+            const int want = std::atoi(env);
+            if (want == 1) fmt = weights <= 1 ? 1 : 2;
+            else if (want == 2) fmt = 2;
+            else if (want == 3 && weights <= 1 && n_acc <= 4096ull) fmt = 3;
+            else if (want == 4 && n_acc <= 32768ull) fmt = 4;
+        }
         c->syn_format = fmt;
     }
-    const bool stream_layout = (c->syn_format == 0);
+    const bool stream_layout = (c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4);
     {
         // ---- axon records: per slice, compact (2 B/axon) when its axons allow it, else wide (8 B/axon) ----
         std::vector<unsigned long long> rec_off(h.n_slices, 0);
@@ -565,8 +574,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<unsigned char> bytes(n_bytes + 16, 0);
         std::vector<uint32_t> csyn(n_chunks, 0), cpre(n_chunks, 0);
         std::vector<uint8_t> exact(h.n_slices, 0);
-        std::vector<uint32_t> meta; // device synapse words of formats 0 and 1
+        std::vector<uint32_t> meta; // device synapse words (all formats but 2, which keeps the image's arrays)
+        std::vector<double> wdev;   // format 4: the fp64 weights at the device positions of their words
         if (c->syn_format != 2) meta.assign(n_dev_syn + 256, 0u);
+        if (c->syn_format == 4) wdev.assign(n_dev_syn + 256, 0.0);
         parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t sl = lo; sl < hi; sl++)
             {
@@ -608,11 +619,17 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                     {
                         const uint32_t m = h.syn_meta[src + k];
                         const int w = (int) h.syn_weight[src + k];
-                        if (c->syn_format == 0)
+                        if (stream_layout)
                         {
                             const bool drop = (m >> 19) & 1u;
-                            const uint32_t idx = drop ? trash_post : ((m >> 16) & 7u) * (trash_post + 1u) + (m & 0xfffu);
-                            meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
+                            const uint32_t idx = drop ? trash_post : ((m >> 16) & 7u) * (trash_post + 1u) + (m & 0xffffu);
+                            if (c->syn_format == 0) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
+                            else if (c->syn_format == 3) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xfff) << 20);
+                            else
+                            {
+                                meta[dpos + k] = code | (idx << 8);
+                                wdev[dpos + k] = h.syn_weight[src + k];
+                            }
                         }
                         else
                             meta[dpos + k] = (m & 0xfffffu) | ((uint32_t) (w & 0xfff) << 20);
@@ -672,7 +689,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
         for (uint8_t m : mode) c->n_compact_slices += m;
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
-        c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * 4ull;
+        c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : 4ull);
         c->layout_bytes[1] = n_bytes;
         c->layout_bytes[2] = n_chunks * 8ull;
         c->layout_bytes[3] = (uint64_t) h.n_slices * sizeof(SliceDesc);
@@ -687,6 +704,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         else
         {
             TRYC(upload(c, meta.data(), meta.size(), &im.syn_meta));
+            if (c->syn_format == 4) TRYC(upload(c, wdev.data(), wdev.size(), &im.syn_weight));
         }
     }
     {
@@ -784,6 +802,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     SANAFE_SET_LDS_LAST(0);
     SANAFE_SET_LDS_LAST(1);
     SANAFE_SET_LDS_LAST(2);
+    SANAFE_SET_LDS_LAST(3);
+    SANAFE_SET_LDS_LAST(4);
 #undef SANAFE_SET_LDS_LAST
     SANAFE_SET_LDS(0, true);
     SANAFE_SET_LDS(0, false);
@@ -791,6 +811,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     SANAFE_SET_LDS(1, false);
     SANAFE_SET_LDS(2, true);
     SANAFE_SET_LDS(2, false);
+    SANAFE_SET_LDS(3, true);
+    SANAFE_SET_LDS(3, false);
+    SANAFE_SET_LDS(4, true);
+    SANAFE_SET_LDS(4, false);
 #undef SANAFE_SET_LDS
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -947,15 +971,19 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
     hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
 #define SANAFE_LAUNCH_DELIVER_LAST(F) \
     hipLaunchKernelGGL((deliver_kernel<F, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
-        if (c->im.has_last && c->syn_format == 0) SANAFE_LAUNCH_DELIVER_LAST(0);
-        else if (c->im.has_last && c->syn_format == 1) SANAFE_LAUNCH_DELIVER_LAST(1);
-        else if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(2);
-        else if (c->syn_format == 0 && c->has_delay) SANAFE_LAUNCH_DELIVER(0, true);
-        else if (c->syn_format == 0) SANAFE_LAUNCH_DELIVER(0, false);
-        else if (c->syn_format == 1 && c->has_delay) SANAFE_LAUNCH_DELIVER(1, true);
-        else if (c->syn_format == 1) SANAFE_LAUNCH_DELIVER(1, false);
-        else if (c->has_delay) SANAFE_LAUNCH_DELIVER(2, true);
-        else SANAFE_LAUNCH_DELIVER(2, false);
+#define SANAFE_LAUNCH_FORMAT(F)                                      \
+    if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(F);               \
+    else if (c->has_delay) SANAFE_LAUNCH_DELIVER(F, true);           \
+    else SANAFE_LAUNCH_DELIVER(F, false)
+        switch (c->syn_format)
+        {
+        case 0: SANAFE_LAUNCH_FORMAT(0); break;
+        case 1: SANAFE_LAUNCH_FORMAT(1); break;
+        case 3: SANAFE_LAUNCH_FORMAT(3); break;
+        case 4: SANAFE_LAUNCH_FORMAT(4); break;
+        default: SANAFE_LAUNCH_FORMAT(2); break;
+        }
+#undef SANAFE_LAUNCH_FORMAT
 #undef SANAFE_LAUNCH_DELIVER
 #undef SANAFE_LAUNCH_DELIVER_LAST
         HIPCHK(hipGetLastError());

@@ -106,11 +106,15 @@ struct DevImage
     //                   word itself via a 256-byte table in LDS) instead of gathered;
     //                   accumulator index = delay * (npad + 1) + post-neuron offset, i.e. the LDS entry the weight is
     //                   added to; synapses whose charge is lost point at the trash entry `npad` of row 0
-    //   1: 4 bytes      post (16b) | delay (3b) << 16 | drop << 19 | 12-bit signed weight << 20
-    //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64
+    //   1: 4 bytes      post (16b) | delay (3b) << 16 | drop << 19 | 12-bit signed weight << 20   (gather only)
+    //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64                    (gather only)
+    //   3: 4 bytes      axon code (8b) | accumulator index (12b) << 8 | 12-bit signed weight << 20: the streamable
+    //                   form of 1, for chips whose cores need at most 4096 accumulators
+    //   4: 4 + 8 bytes  axon code (8b) | accumulator index (15b) << 8, syn_weight = fp64: the streamable form of 2
+    // Formats 0, 3 and 4 give every 256-axon chunk a 16-byte aligned, padded run of words (stream layout).
     const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
     const double *syn_weight;
-    int syn_format;               // 0 / 1 / 2 as above
+    int syn_format;               // 0 .. 4 as above
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
 };
 
@@ -379,7 +383,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 {
                     const uint32_t cr = (core != 0xffffffffu) ? core : im.wg_desc[wg].core;
                     const unsigned long long pos = im.core_syn_base[cr] + (last - 1u);
-                    const double w = (im.syn_format == 2) ? im.syn_weight[pos]
+                    const double w = (im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
                                                           : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
                     cur = 0.0 + w;
                     st.ring_last[c0 + lane] = 0u;
@@ -689,7 +693,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const uint32_t D = HAS_DELAY ? im.delay_slots : 1u; // LDS holds one accumulator row per delay value in use
     // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
     // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
-    const uint32_t RS = (SYN_FMT == 0) ? npad + 1u : npad;
+    constexpr bool STREAMABLE = (SYN_FMT == 0 || SYN_FMT == 3 || SYN_FMT == 4); // stream layout, index-coded words
+    constexpr bool FP_WEIGHTS = (SYN_FMT == 2 || SYN_FMT == 4);
+    constexpr int SDEPTH = (SYN_FMT == 4) ? 2 : STREAM_DEPTH; // fp64 weights triple the registers of a group in flight
+    const uint32_t RS = STREAMABLE ? npad + 1u : npad;
     const long long t = done + 1;
     const unsigned long long a_beg = sd.a_beg;
     const uint32_t n_ax = sd.n_ax; // slices hold < 2^32 axons
@@ -704,7 +711,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     // Which accumulators received a synaptic event (the buffer holds a value, even a zero one: src/chip.cpp:759)?
     // Integer-weight formats start every accumulator at -0.0, which no addition of weights can produce again;
     // fp64 weights (format 2) could be -0.0 themselves and keep a byte per accumulator instead.
-    constexpr bool TOUCH_BYTES = (SYN_FMT == 2);
+    constexpr bool TOUCH_BYTES = FP_WEIGHTS;
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
     const uint32_t core_inkind = sd.inkind;  // the buffer position belongs to the core
@@ -746,8 +753,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.  A wave whose
     // previous chunk streamed ("hot") starts the loads of the next chunk before it knows which axons spiked.
     bool hot = false;
-    uint4 sq[STREAM_DEPTH];
+    uint4 sq[SDEPTH];
+    double2 sw[FP_WEIGHTS ? SDEPTH : 1][2]; // the four fp64 weights of each group (format 4)
     const uint4 *st_src = nullptr;
+    const double2 *st_wsrc = nullptr;
     uint32_t st_groups = 0, st_pos0 = 0;
     constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
     uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // axon offset of the chunk inside the slice
@@ -757,11 +766,20 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         st_pos0 = s0;
         st_groups = (chunk_syn0[ci + 1] - s0) >> 2; // chunks are 16-byte aligned and padded (format 0)
         st_src = reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
+        if (SYN_FMT == 4) st_wsrc = reinterpret_cast<const double2 *>(im.syn_weight + (syn_base + s0));
 #pragma unroll
-        for (int u = 0; u < STREAM_DEPTH; u++)
+        for (int u = 0; u < SDEPTH; u++)
         {
             const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
-            if (g < st_groups) sq[u] = load_stream16(st_src + g);
+            if (g < st_groups)
+            {
+                sq[u] = load_stream16(st_src + g);
+                if (SYN_FMT == 4)
+                {
+                    sw[u][0] = st_wsrc[2 * g];
+                    sw[u][1] = st_wsrc[2 * g + 1];
+                }
+            }
         }
     };
     // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
@@ -835,7 +853,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     __syncthreads();
     for (; c0 < n_ax; c0 += stride)
     {
-        if (SYN_FMT == 0 && hot) stream_preload();
+        if (STREAMABLE && hot) stream_preload();
         // ---- this chunk: take over what the previous iteration decoded and probed ----
         const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
         uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
@@ -857,7 +875,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             hot = false;
             continue; // wave-uniform
         }
-        if (SYN_FMT == 0 && compact)
+        if (STREAMABLE && compact)
         {
             // ---- STREAM: with many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
             //      so read them all once, in order (16 bytes per lane), and let each word say whether its axon
@@ -871,8 +889,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 if (!hot) stream_preload();
                 hot = true;
                 const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
-                auto add4 = [&](const uint4 &g, uint32_t pos0 /* position of g.x among the core's synapses */) {
+                auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
                     const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
+                    const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
                     uint32_t fired[4];
 #pragma unroll
                     for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0xffu];
@@ -880,21 +899,35 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     for (int u = 0; u < 4; u++)
                         if (fired[u])
                         {
-                            const uint32_t idx = (w4[u] >> 8) & 0x7fffu;
-                            if (LAST && last_mode) atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
-                            else atomicAdd(&acc[idx], (double) ((int) w4[u] >> 24)); // ds_add_f64 (lost charge lands in the trash entry)
+                            const uint32_t idx = (w4[u] >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu);
+                            if (LAST && last_mode)
+                            {
+                                atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
+                                continue;
+                            }
+                            // ds_add_f64 (lost charge lands in the trash entry)
+                            atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
+                            if (TOUCH_BYTES) touched[idx] = 1;
                         }
                 };
-                // rolling window: STREAM_DEPTH 16-byte groups per lane in flight while one is added
-                for (uint32_t g = (uint32_t) lane; g < st_groups; g += WAVE * STREAM_DEPTH)
+                // rolling window: SDEPTH 16-byte groups per lane in flight while one is added
+                for (uint32_t g = (uint32_t) lane; g < st_groups; g += WAVE * SDEPTH)
                 {
 #pragma unroll
-                    for (int u = 0; u < STREAM_DEPTH; u++)
+                    for (int u = 0; u < SDEPTH; u++)
                     {
                         // add, then refill the same registers (the other groups of the window are still in flight)
-                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
-                        const uint32_t nxt = g + (uint32_t) (STREAM_DEPTH + u) * WAVE;
-                        if (nxt < st_groups) sq[u] = load_stream16(st_src + nxt);
+                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
+                        const uint32_t nxt = g + (uint32_t) (SDEPTH + u) * WAVE;
+                        if (nxt < st_groups)
+                        {
+                            sq[u] = load_stream16(st_src + nxt);
+                            if (SYN_FMT == 4)
+                            {
+                                sw[u][0] = st_wsrc[2 * nxt];
+                                sw[u][1] = st_wsrc[2 * nxt + 1];
+                            }
+                        }
                     }
                 }
                 // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
@@ -992,11 +1025,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         {
                             spos[u] = (uint32_t) (w_beg[owner] + e);
                             const unsigned long long s = syn_base + spos[u];
-                            if (SYN_FMT == 0)
+                            if (STREAMABLE)
                             {
                                 const uint32_t m = im.syn_meta[s];
-                                meta[u] = (m >> 8) & 0x7fffu; // the accumulator index itself (trash entry when the charge is lost)
-                                wgt[u] = (double) ((int) m >> 24);
+                                meta[u] = (m >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu); // the accumulator index itself (trash entry when the charge is lost)
+                                wgt[u] = SYN_FMT == 4 ? im.syn_weight[s] : (double) ((int) m >> (SYN_FMT == 0 ? 24 : 20));
                             }
                             else if (SYN_FMT == 1)
                             {
@@ -1021,7 +1054,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                             atomicMax(&lastv[meta[u] & 0xffffu], spos[u] + 1u); // (format 0: the index; no delays in this mode)
                             continue;
                         }
-                        const uint32_t idx = (SYN_FMT == 0) ? meta[u]
+                        const uint32_t idx = STREAMABLE ? meta[u]
                                                             : (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
                         atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
                         if (TOUCH_BYTES) touched[idx] = 1;
@@ -1032,7 +1065,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         wave_lds_fence(); // the lists are rewritten by the next chunk
     }
     // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
-    if (SYN_FMT == 0) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
+    if (STREAMABLE) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
     proc = wave_sum(proc);
     if (lane == 0) s_red[wave] = proc;
     __syncthreads();
@@ -1348,7 +1381,8 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
             uint32_t core = 0; // the slot's core: cores are few, slots of a core contiguous
             while (core + 1 < im.n_cores && im.core_nbase[core + 1] <= g) core++;
             const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
-            c = 0.0 + ((im.syn_format == 2) ? im.syn_weight[pos] : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20)));
+            c = 0.0 + ((im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
+                                                                   : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20)));
             st.ring_last[g] = 0u;
         }
         cur[i] = c;

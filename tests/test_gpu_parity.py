@@ -212,7 +212,7 @@ def test_random_configurations(S, seed, monkeypatch):
         monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
     arch, net = _random_configuration(S, seed)
     chip, orc = make(S, arch, net)
-    exact = chip.device_layout()["syn_format"] != 2
+    exact = chip.device_layout()["syn_format"] not in (2, 4)  # fp64 weights: sums in a different order
     tot = chip.run(14, "simple", record=True)
     recs = chip.step_totals(0, 14)
     for t in range(14):
@@ -257,16 +257,35 @@ def test_truenorth(S):
     check_stepwise(S, *nets.truenorth_net(S, n_tiles=16, neurons_per_core=256), steps=20)
 
 
-def test_float_weights(S):
-    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=16, arch_kind="loihi", weights="float")
+@pytest.mark.parametrize("force,fmt", [(None, 4), ("2", 2)])
+def test_float_weights(S, monkeypatch, force, fmt):
+    """fp64 weights: 4 + 8 bytes per synapse, in the streamable layout (index-coded words, format 4) and in the
+    gather-only fall-back (format 2); p_fire 0.5 makes whole chunks stream."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=48, arch_kind="loihi", weights="float", p_fire=0.5)
     chip, _ = check_stepwise(S, arch, net, steps=20, exact_v=False)
-    assert chip.device_layout()["syn_format"] == 2  # 4 + 8 bytes per synapse
+    assert chip.device_layout()["syn_format"] == fmt
 
 
-def test_twelve_bit_integer_weights(S):
-    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=16, arch_kind="loihi", weights="int12")
+@pytest.mark.parametrize("force,fmt", [(None, 3), ("1", 1)])
+def test_twelve_bit_integer_weights(S, monkeypatch, force, fmt):
+    """12-bit integer weights: 4 bytes per synapse, streamable (format 3) or gather-only (format 1)."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=48, arch_kind="loihi", weights="int12", p_fire=0.5)
     chip, _ = check_stepwise(S, arch, net, steps=20)
-    assert chip.device_layout()["syn_format"] == 1  # 4 bytes per synapse
+    assert chip.device_layout()["syn_format"] == fmt
+
+
+@pytest.mark.parametrize("weights,fmt", [("int12", 3), ("float", 4)])
+def test_streamed_delay_lines_other_formats(S, weights, fmt):
+    """The stream path of formats 3 / 4 with synaptic delays (several accumulator rows) on dense cores."""
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=200, arch_kind="large", delays=True,
+                                  weights=weights, p_fire=0.4, seed=13)
+    chip, _ = check_stepwise(S, arch, net, steps=10, exact_v=(weights != "float"))
+    lay = chip.device_layout()
+    assert lay["syn_format"] == fmt and lay["n_compact_slices"] > 0
 
 
 def test_mixed_axon_record_modes(S):
