@@ -162,99 +162,75 @@ def hip_lib():
 TIMING = {"simple": 0, "detailed": 1, "cycle": 2}
 
 
-class MappedNeuronRef:
-    """``chip.mapped_neuron_groups[name][i]`` (src/pymodule.cpp:1174-1192)."""
-
-    def __init__(self, chip, gid):
-        self._chip, self._gid = chip, gid
-
-    def set_model_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None):
-        """Older spelling some scripts use (scripts/computer2026/combined.py:297)."""
-        return self.set_attributes(model_attributes, soma_attributes, dendrite_attributes)
-
-    def set_attributes(self, model_attributes=None, soma_attributes=None, dendrite_attributes=None, log_spikes=None):
-        """MappedNeuron::set_attributes (src/mapped.cpp:113-166): every attribute goes to the neuron's soma unit as at
-        load().  The accumulator dendrites have no per-neuron attributes, so ``dendrite_attributes`` and the dendrite
-        copy of ``model_attributes`` change nothing there, as in the reference; the constants of a `taps` dendrite
-        cannot be changed after load() on this backend."""
-        frozen = {"taps", "time_constants", "space_constants"}
-        hit = frozen & (set(model_attributes or {}) | set(dendrite_attributes or {}))
-        if hit:
-            raise NotImplementedError("`taps` dendrite attributes cannot change after load() on the MI355X backend: %s"
-                                      % sorted(hit))
-        attrs = dict(model_attributes or {})
-        attrs.update(soma_attributes or {})
-        for key, value in attrs.items():
-            t, num, sval, lst = D.py_to_attr(value)
-            if t == D.ATTR_LIST:
-                self._chip._set_attribute_list(self._gid, key, lst)
-            else:
-                self._chip._set_attribute(self._gid, key, t, num, sval)
-        if log_spikes is not None:
-            self._chip._log_spikes[self._gid] = bool(log_spikes)
+class _GroupsView(dict):
+    """{group name: (first neuron id, count)} of the programmed chip (kept for tests and helpers)."""
 
 
-class SpikingChip:
-    """Drop-in for ``sanafe.SpikingChip`` on one MI355X (or one rank of a tile-sharded run)."""
+_Base = cpp.SpikingChip if cpp is not None else object
 
-    def __init__(self, arch: D.Architecture, device=0, n_ranks=1, rank=0):
+
+class SpikingChip(_Base):
+    """Drop-in for ``sanafe.SpikingChip`` on one MI355X (or one rank of a tile-sharded run).
+
+    The class itself is compiled C++ (PyBind11, host/pychip.cpp): ``load``, ``sim`` (GIL released, Ctrl-C polled
+    between chunks, traces streamed), ``reset``, ``get_power``, ``mapped_neuron_groups[...][i].set_attributes``.
+    This Python subclass only adds the diagnostics the tests and bench.py use (raw step records, state dumps, the
+    exchange set-up) through the C API of libsanafe_host.so on the same chip handle, and the loader for networks
+    built with the pure-Python twin of the description layer."""
+
+    def __init__(self, arch, device=0, n_ranks=1, rank=0):
+        if cpp is None:
+            raise BackendMissingError("sanafecpp_amd is missing: build it with `make -C sana-fe_amd`")
         self._L = lib()
-        self.arch = arch
+        super().__init__(arch, device, n_ranks, rank)
         self._device, self._n_ranks, self._rank = device, n_ranks, rank
-        self._h = None
-        self._net = None
-        self._nets = []
-        self._built = None
-        self.total_timesteps = 0
-
-    # -- SpikingChip::load (src/chip.cpp:129-138); Python default overwrite=False ---------------
-    def load(self, net: D.Network, overwrite=False):
-        """SpikingChip::load (src/chip.cpp:129-138).  ``overwrite=False`` on a programmed chip ADDS the network: its
-        groups are mapped after the ones already there (neuron ids, mapping order and per-core offsets continue).
-        The chip is re-lowered from the combined description, so this is supported until the first timestep has
-        been simulated (the reference would also carry the running state of the first network over)."""
-        if self._h is not None and not overwrite:
-            if self.total_timesteps > 0:
-                raise NotImplementedError("UnsupportedError: load(net, overwrite=False) after timesteps have been simulated "
-                                          "(the state of the programmed network cannot be carried into the re-lowered chip)")
-            if cpp is None or not isinstance(net, cpp.Network) or not all(isinstance(n, cpp.Network) for n in self._nets):
-                raise NotImplementedError("UnsupportedError: adding a network to a programmed chip needs sanafecpp_amd networks")
-            merged = cpp.Network(self._nets[0].name)
-            for n in self._nets + [net]:
-                merged.absorb(n)
-            self._nets.append(net)
-            net = merged
-        else:
-            self._nets = [net]
-        self._free()
-        self._net = net
-        self._built = _Lowered(self.arch, net)
-        h = C.c_void_p()
-        rc = self._L.sanafe_chip_create(self._built.address, self._device, self._n_ranks, self._rank, C.byref(h))
-        if rc != 0:
-            msg = self._L.sanafe_last_error().decode()
-            if msg.startswith("HardwareMappingError"):
-                raise D.HardwareMappingError(msg)
-            if msg.startswith("UnsupportedError"):
-                raise NotImplementedError(msg)
-            raise RuntimeError(msg)
-        self._h = h
-        self.n_neurons = self._built.n_neurons
-        self._log_spikes = self._built.log_spikes.copy()
-        self._log_potential = self._built.log_potential.copy()
-        # trace order: groups lexicographically by name, neurons by offset (std::map, src/chip.cpp:1616-1629)
-        order = []
-        for name in sorted(self._built.groups):
-            base, count = self._built.groups[name]
-            order.append(np.arange(base, base + count))
-        self._trace_order = np.concatenate(order) if order else np.zeros(0, np.int64)
-        self._gid_label = {}
-        self.total_timesteps = 0
+        self._state_row = 0
 
     @property
-    def mapped_neuron_groups(self):
-        return {name: [MappedNeuronRef(self, base + i) for i in range(count)]
-                for name, (base, count) in self._built.groups.items()}
+    def _h(self):
+        return C.c_void_p(self.handle) if self.handle else None
+
+    # -- SpikingChip::load (src/chip.cpp:129-138); Python default overwrite=False ---------------
+    def load(self, net, overwrite=False):
+        if isinstance(net, cpp.Network):
+            return super().load(net, overwrite)
+        # a network built with the Python twin (tests): lower it there and hand the flat description over
+        if self.handle and not overwrite:
+            raise NotImplementedError("UnsupportedError: adding a network to a programmed chip needs sanafecpp_amd networks")
+        built = D.to_desc(self.arch, net)
+        groups = [(g.name, int(g.base), int(g.count)) for g in net._order]
+        cat = lambda name: (np.concatenate([getattr(g, name) for g in net._order]).astype(np.uint8)  # noqa: E731
+                            if net._order else np.zeros(0, np.uint8))
+        try:
+            self.load_lowered(C.addressof(built.desc), groups, cat("log_spikes"), cat("log_potential"), (built, net, self.arch))
+        except RuntimeError as e:
+            if str(e).startswith("HardwareMappingError"):
+                raise D.HardwareMappingError(str(e))
+            raise
+
+    # -- views the tests use -----------------------------------------------------------------------
+    @property
+    def _built(self):
+        class _B:
+            pass
+        b = _B()
+        b.groups = self.group_table()
+        return b
+
+    @property
+    def _trace_order(self):
+        return np.asarray(self.trace_order())
+
+    @property
+    def _log_spikes(self):
+        return np.asarray(self.log_flags()[0]).astype(bool)
+
+    @property
+    def _log_potential(self):
+        return np.asarray(self.log_flags()[1]).astype(bool)
+
+    def _labels(self):
+        return {base + i: (name, i) for name, (base, count) in self.group_table().items() for i in range(count)}
 
     def info(self):
         i = ChipInfo()
@@ -268,17 +244,6 @@ class SpikingChip:
                 raise NotImplementedError(msg)
             raise RuntimeError(msg)
 
-    def _free(self):
-        if self._h is not None:
-            self._L.sanafe_chip_destroy(self._h)
-            self._h = None
-
-    def __del__(self):
-        try:
-            self._free()
-        except Exception:
-            pass
-
     def _set_bias(self, gids, values):
         g = np.ascontiguousarray(gids, dtype=np.int64)
         v = np.ascontiguousarray(values, dtype=np.float64)
@@ -286,7 +251,7 @@ class SpikingChip:
 
     def set_bias(self, group, values):
         """Vectorised MappedNeuron.set_attributes(model_attributes={'bias': b}) for a whole group (DVS frames)."""
-        base, count = self._built.groups[str(group)]
+        base, count = self.group_table()[str(group)]
         self._set_bias(np.arange(base, base + count), np.asarray(values, dtype=np.float64))
 
     # -- raw accessors (desc order) ------------------------------------------------------------
@@ -363,174 +328,8 @@ class SpikingChip:
         t = Totals()
         flags = (self.RECORD_STEPS if record or messages or state else 0) | (self.RECORD_MESSAGES if messages else 0) | \
                 (self.RECORD_STATE if state else 0)
-        try:
-            self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], flags, C.byref(t)))
-        finally:
-            self.total_timesteps = int(self._L.sanafe_chip_total_timesteps(self._h))  # the C side is the one counter
+        self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], flags, C.byref(t)))
         return t.as_dict()
-
-    # -- SpikingChip.sim (src/pymodule.cpp:549-706, 1198-1208) ---------------------------------
-    def sim(self, timesteps=1, timing_model="detailed", processing_threads=0, scheduler_threads=0, spike_trace=None,
-            potential_trace=None, neuron_trace=None, perf_trace=None, message_trace=None, write_trace_headers=True):
-        if self._h is None:
-            raise RuntimeError("no network loaded")
-        if timing_model not in TIMING:
-            timing_model = "detailed"  # parse_timing_model falls back to detailed, src/chip.cpp:1833-1858
-        self._check(self._L.sanafe_chip_set_scheduler_threads(self._h, int(scheduler_threads)))
-        start = self.total_timesteps + 1
-        want_steps = any(t is not None and t is not False for t in (spike_trace, perf_trace, message_trace))
-        want_state = any(t is not None and t is not False for t in (potential_trace, neuron_trace))
-        spikes, pots, ntraces, perf, msgs = [], [], {}, None, []
-        opt_names = self.perf_columns() if perf_trace else []
-        opt_rows = []
-        if timing_model == "cycle":
-            raise NotImplementedError("UnsupportedError: the cycle-accurate (Booksim2) timing model is out of scope")
-        # One sanafe_chip_sim call whatever is traced: potentials and model traces are sampled on the device right after
-        # each neuron update (src/pytrace.cpp:190-222 samples them per step) and fetched in bulk afterwards.
-        pot_gids = self._trace_order[self._log_potential[self._trace_order]] if potential_trace else np.zeros(0, np.int64)
-        cur_gids = self._trace_order if neuron_trace else np.zeros(0, np.int64)
-        want_state = want_state and (len(pot_gids) + len(cur_gids)) > 0
-        if want_state:
-            self.set_state_log(pot_gids, cur_gids)
-        tot = self.run(timesteps, timing_model, record=want_steps or want_state, messages=bool(message_trace), state=want_state)
-        steps = self.step_totals(0, timesteps) if (want_steps or want_state) and timesteps > 0 else None
-        if opt_names and timesteps > 0:
-            opt_rows = list(self.step_optional(0, timesteps))
-        fired = [self.step_fired(i) for i in range(timesteps)] if spike_trace else []
-        if message_trace:
-            msgs = [self.step_messages(i) for i in range(timesteps)]
-        if potential_trace or neuron_trace:
-            state = self.step_state(0, timesteps) if want_state else np.zeros((timesteps, 0))
-            if potential_trace:
-                pots = state[:, :len(pot_gids)].tolist()
-            if neuron_trace:
-                ntraces["u"] = state[:, len(pot_gids):].tolist()
-        result = {
-            "timestep_start": start, "timesteps_executed": timesteps,
-            "energy": {"total": tot["total_energy"], "synapse": tot["synapse_energy"], "dendrite": tot["dendrite_energy"],
-                       "soma": tot["soma_energy"], "network": tot["network_energy"]},
-            "sim_time": tot["sim_time"], "spikes": tot["spikes"], "packets_sent": tot["packets_sent"],
-            "neurons_updated": tot["neurons_updated"], "neurons_fired": tot["neurons_fired"],
-        }
-        if spike_trace:
-            names = self._labels()
-            for f in fired:
-                sel = self._trace_order[(f[self._trace_order] != 0) & self._log_spikes[self._trace_order]]
-                spikes.append([names[int(g)] for g in sel])
-        if perf_trace and steps is not None:
-            perf = {"timestep": [int(start + i) for i in range(timesteps)],
-                    "fired": steps["neurons_fired"].tolist(), "updated": steps["neurons_updated"].tolist(),
-                    "packets": steps["packets_sent"].tolist(), "hops": steps["total_hops"].tolist(),
-                    "spikes": steps["spikes"].tolist(), "sim_time": steps["sim_time"].tolist(),
-                    "synapse_energy": steps["synapse_energy"].tolist(), "dendrite_energy": steps["dendrite_energy"].tolist(),
-                    "soma_energy": steps["soma_energy"].tolist(), "network_energy": steps["network_energy"].tolist(),
-                    "total_energy": steps["total_energy"].tolist()}
-            # optional columns, in the reference's std::map order (src/chip.cpp:1541-1579, src/pytrace.hpp:249-258)
-            for k, name in enumerate(opt_names):
-                perf[name] = [float(row[k]) for row in opt_rows]
-        result["spike_trace"] = spikes if spike_trace else None
-        result["potential_trace"] = pots if potential_trace else None
-        result["neuron_trace"] = ntraces if neuron_trace else None
-        result["perf_trace"] = perf
-        result["message_trace"] = None
-        for tr, key in ((spike_trace, "spike_trace"), (potential_trace, "potential_trace"), (perf_trace, "perf_trace"),
-                        (message_trace, "message_trace")):
-            if isinstance(tr, str) or hasattr(tr, "write"):
-                self._write_trace(tr, key, msgs if key == "message_trace" else result[key], start, write_trace_headers)
-                result[key] = None
-            elif key == "message_trace" and tr:
-                result[key] = [self._message_dicts(m) for m in msgs]
-            elif key == "perf_trace" and result[key] is not None:
-                # the in-memory map has no "packets" entry (timestep_data_to_map, src/pytrace.cpp:55-74); the CSV has
-                result[key] = {k: v for k, v in result[key].items() if k != "packets"}
-        return result
-
-    def _labels(self):
-        if not self._gid_label:
-            for name, (base, count) in self._built.groups.items():
-                for i in range(count):
-                    self._gid_label[base + i] = (name, i)  # NeuronAddress(group_name, neuron_offset)
-        return self._gid_label
-
-    def _message_dicts(self, arr):
-        """In-memory message trace rows: exactly the 26 keys of message_to_dict (src/pytrace.cpp:17-53), sorted by
-        plain mid, so placeholders (mid -1) come first (src/pytrace.hpp:336-339)."""
-        labels = self._labels()
-        rows = []
-        for m in np.sort(arr, order="mid", kind="stable"):
-            g, o = labels.get(int(m["src_neuron"]), ("invalid", 0))
-            rows.append({
-                "generation_delay": float(m["generation_delay"]), "network_delay": float(m["network_delay"]),
-                "processing_delay": float(m["processing_delay"]), "blocking_delay": float(m["blocking_delay"]),
-                "send_timestamp": float(m["sent_timestamp"]), "received_timestamp": float(m["received_timestamp"]),
-                "processed_timestamp": float(m["processed_timestamp"]),
-                "timestep": int(m["timestep"]), "mid": int(m["mid"]), "spikes": int(m["spikes"]), "hops": int(m["hops"]),
-                "src_neuron_offset": int(o), "src_neuron_group_id": g,
-                "src_x": int(m["src_x"]), "dest_x": int(m["dest_x"]), "src_y": int(m["src_y"]), "dest_y": int(m["dest_y"]),
-                "src_tile_id": int(m["src_tile"]), "src_core_id": int(m["src_core_id"]),
-                "src_core_offset": int(m["src_core_offset"]), "dest_tile_id": int(m["dest_tile"]),
-                "dest_core_id": int(m["dest_core_id"]), "dest_core_offset": int(m["dest_core_offset"]),
-                "dest_axon_hw": 0, "dest_axon_id": int(m["dest_axon_id"]), "placeholder": bool(m["placeholder"]),
-            })
-        return rows
-
-    def _write_trace(self, target, key, data, start, headers):
-        """CSV traces with the reference's column layout (src/chip.cpp:1447-1764)."""
-        close = False
-        f = target
-        if isinstance(target, str):
-            f = open(target, "w" if headers else "a")
-            close = True
-        try:
-            names = self._labels()
-            if key == "spike_trace":
-                if headers:
-                    f.write("neuron,timestep\n")
-                for i, row in enumerate(data or []):
-                    for (g, o) in row:
-                        f.write("%s.%d,%d\n" % (g, o, start + i))
-            elif key == "potential_trace":
-                sel = self._trace_order[self._log_potential[self._trace_order]]
-                if headers:
-                    f.write("timestep," + "".join("neuron %s.%d," % names[int(g)] for g in sel) + "\n")
-                for i, row in enumerate(data or []):
-                    if row:
-                        f.write("%d," % (start + i) + "".join("%g," % v for v in row) + "\n")
-            elif key == "perf_trace":
-                cols = ["timestep", "fired", "updated", "packets", "hops", "spikes", "sim_time", "synapse_energy",
-                        "dendrite_energy", "soma_energy", "network_energy", "total_energy"] + self.perf_columns()
-                if headers:
-                    f.write(",".join(cols) + "\n")
-                for i in range(len(data["timestep"]) if data else 0):
-                    f.write(",".join(("%d" % data[c][i]) if c in cols[:6] else ("%e" % data[c][i]) for c in cols) + "\n")
-            elif key == "message_trace":
-                cols = ["timestep", "mid", "src_neuron", "src_hw", "dest_hw", "hops", "spikes", "send_timestamp",
-                        "received_timestamp", "processed_timestamp", "generation_delay", "processing_delay",
-                        "network_delay", "blocking_delay", "min_hop_delay", "messages_along_route"]
-                if headers:
-                    f.write(",".join(cols) + "\n")
-                for step in data or []:  # raw records (MSG_DTYPE) of one timestep
-                    # the CSV writer sorts by mid with placeholders LAST (src/message.cpp:70-91)
-                    order = sorted(range(len(step)), key=lambda i: (step["mid"][i] < 0, step["mid"][i]))
-                    for i in order:
-                        m = step[i]
-                        g, o = names.get(int(m["src_neuron"]), ("invalid", 0))
-                        csv = {"timestep": int(m["timestep"]), "mid": int(m["mid"]), "src_neuron": "%s.%d" % (g, o),
-                               "src_hw": "%d.%d" % (m["src_tile"], m["src_core_offset"]),
-                               "dest_hw": "x.x" if m["placeholder"] else "%d.%d" % (m["dest_tile"], m["dest_core_offset"]),
-                               "hops": int(m["hops"]), "spikes": int(m["spikes"]), "send_timestamp": float(m["sent_timestamp"])}
-                        for k in MSG_DBL:
-                            csv.setdefault(k, float(m[k]))
-                        f.write(",".join(("%g" % csv[c]) if isinstance(csv[c], float) else str(csv[c]) for c in cols) + "\n")
-        finally:
-            if close:
-                f.close()
-
-    def reset(self):
-        self._check(self._L.sanafe_chip_reset(self._h))
-
-    def get_power(self):
-        return self._L.sanafe_chip_get_power(self._h)
 
     # -- tile-sharded chips: the per-step spike exchange lives in the host library (host/comm.cpp) ----------
     @staticmethod
@@ -611,7 +410,6 @@ class SpikingChip:
 
     def step_deliver(self, timing_model="simple"):
         self._check(self._L.sanafe_chip_step_deliver(self._h, TIMING[timing_model]))
-        self.total_timesteps += 1
 
     def spike_buffers(self):
         lp, gp = C.c_void_p(), C.c_void_p()

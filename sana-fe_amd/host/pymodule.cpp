@@ -14,12 +14,11 @@
 #include <string>
 
 #include "description.hpp"
+#include "pyconv.hpp"
 
 namespace py = pybind11;
 using namespace sanafe_amd;
 
-namespace
-{
 AttrValue py_to_attr(const py::handle &v, bool narrow)
 {
     if (py::isinstance<py::str>(v)) return AttrValue::String(v.cast<std::string>());
@@ -48,6 +47,8 @@ AttrValue py_to_attr(const py::handle &v, bool narrow)
     }
     throw std::invalid_argument("Error: dict has unsupported type");
 }
+namespace
+{
 std::map<std::string, std::pair<AttrValue, int>> dict_attrs(const py::dict &d, int fwd, bool narrow = true)
 {
     std::map<std::string, std::pair<AttrValue, int>> out;
@@ -396,6 +397,7 @@ PYBIND11_MODULE(sanafecpp_amd, m)
                 return h;
             },
             py::arg("arch"), py::arg("net"));
+    bind_spiking_chip(m); // SpikingChip, MappedNeuron (pychip.cpp)
     m.def("load_arch", &load_arch, py::arg("path"));
     m.def(
             "load_net",

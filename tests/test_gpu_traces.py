@@ -218,3 +218,40 @@ def test_second_load_adds_a_network(S):
         chip.load(net_b)  # timesteps have been simulated
     chip.load(net_b, overwrite=True)  # clear_hw + load: only the new network remains
     assert chip.n_neurons == 80 and chip.total_timesteps == 0
+
+
+def test_sim_releases_the_gil_and_polls_signals(S):
+    """pysim releases the GIL around the simulation and polls PyErr_CheckSignals (src/pymodule.cpp:628-666): other
+    Python threads run during sim(), and Ctrl-C interrupts it between chunks."""
+    import signal
+    import threading
+    import time
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=64, out_degree=16, arch_kind="loihi", seed=2)
+    chip, _ = make(S, arch, net)
+    ticks, stop = [0], [False]
+
+    def spin():
+        while not stop[0]:
+            ticks[0] += 1
+            time.sleep(0.001)
+
+    th = threading.Thread(target=spin)
+    th.start()
+    t0 = time.perf_counter()
+    chip.sim(30000, timing_model="simple")
+    dt = time.perf_counter() - t0
+    stop[0] = True
+    th.join()
+    assert ticks[0] > 20 * dt  # ~1000 ticks/s when the GIL is free; a sim holding it would leave a handful
+    signal.setitimer(signal.ITIMER_REAL, 0.3)
+    old = signal.signal(signal.SIGALRM, lambda *_: (_ for _ in ()).throw(KeyboardInterrupt()))
+    try:
+        with pytest.raises(KeyboardInterrupt):
+            chip.sim(50_000_000, timing_model="simple")  # hours of work: only the signal ends it
+    finally:
+        signal.setitimer(signal.ITIMER_REAL, 0)
+        signal.signal(signal.SIGALRM, old)
+    done = chip.total_timesteps
+    assert 30000 < done < 50_030_000
+    r = chip.sim(3, timing_model="simple")  # the chip stays usable; sim() is cumulative
+    assert r["timestep_start"] == done + 1
