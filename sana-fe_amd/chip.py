@@ -12,13 +12,16 @@ import os
 
 import numpy as np
 
-from . import description as D
-
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-try:  # C++17 / PyBind11 description objects (the product front-end); built by `make -C sana-fe_amd`
+
+class HardwareMappingError(RuntimeError):
+    """The reference's exception for networks that do not fit the hardware (src/mapped.hpp:30-38)."""
+
+
+try:  # C++17 / PyBind11 module: description objects + the compiled SpikingChip; built by `make -C sana-fe_amd`
     from . import sanafecpp_amd as cpp
-except ImportError:  # pragma: no cover - the Python twin in description.py still works for tests
+except ImportError:  # pragma: no cover
     cpp = None
 
 
@@ -36,13 +39,12 @@ class _Lowered:
             ls, lp = net.log_flags()
             self.log_spikes, self.log_potential = np.asarray(ls).astype(bool), np.asarray(lp).astype(bool)
         else:
-            self.handle = D.to_desc(arch, net)
-            self.address = C.addressof(self.handle.desc)
-            self.n_neurons = int(self.handle.desc.n_neurons)
-            self.groups = {g.name: (g.base, g.count) for g in net._order}
-            cat = lambda name: (np.concatenate([getattr(g, name) for g in net._order]).astype(bool)  # noqa: E731
-                                if net._order else np.zeros(0, bool))
-            self.log_spikes, self.log_potential = cat("log_spikes"), cat("log_potential")
+            # any other front-end (the tests' pure-Python twin) lowers itself: lower_for_chip(arch) ->
+            # (address of a sanafe_desc, [(group, base, count)], log_spikes, log_potential, keep-alive object)
+            self.address, groups, ls, lp, self.handle = net.lower_for_chip(arch)
+            self.n_neurons = int(len(ls))
+            self.groups = {name: (int(base), int(count)) for name, base, count in groups}
+            self.log_spikes, self.log_potential = np.asarray(ls).astype(bool), np.asarray(lp).astype(bool)
 
 
 class Totals(C.Structure):
@@ -194,19 +196,12 @@ class SpikingChip(_Base):
     def load(self, net, overwrite=False):
         if isinstance(net, cpp.Network):
             return super().load(net, overwrite)
-        # a network built with the Python twin (tests): lower it there and hand the flat description over
+        # a network from another front-end (the tests' pure-Python twin) lowers itself and hands the flat description over
         if self.handle and not overwrite:
             raise NotImplementedError("UnsupportedError: adding a network to a programmed chip needs sanafecpp_amd networks")
-        built = D.to_desc(self.arch, net)
-        groups = [(g.name, int(g.base), int(g.count)) for g in net._order]
-        cat = lambda name: (np.concatenate([getattr(g, name) for g in net._order]).astype(np.uint8)  # noqa: E731
-                            if net._order else np.zeros(0, np.uint8))
-        try:
-            self.load_lowered(C.addressof(built.desc), groups, cat("log_spikes"), cat("log_potential"), (built, net, self.arch))
-        except RuntimeError as e:
-            if str(e).startswith("HardwareMappingError"):
-                raise D.HardwareMappingError(str(e))
-            raise
+        address, groups, ls, lp, keep = net.lower_for_chip(self.arch)
+        self.load_lowered(address, [(str(n), int(b), int(c)) for n, b, c in groups], np.asarray(ls, dtype=np.uint8),
+                          np.asarray(lp, dtype=np.uint8), (keep, net, self.arch))
 
     # -- views the tests use -----------------------------------------------------------------------
     @property
@@ -487,7 +482,7 @@ def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
     if L.sanafe_chip_create(built.address, -1, n_ranks, rank, C.byref(h)) != 0:
         msg = L.sanafe_last_error().decode()
         if msg.startswith("HardwareMappingError"):
-            raise D.HardwareMappingError(msg)
+            raise HardwareMappingError(msg)
         if msg.startswith("UnsupportedError"):
             raise NotImplementedError(msg)
         raise RuntimeError(msg)

@@ -44,7 +44,7 @@ namespace
     }
     if (msg.rfind("HardwareMappingError", 0) == 0)
     {
-        py::object cls = py::module_::import("sanafe_amd.description").attr("HardwareMappingError");
+        py::object cls = py::module_::import("sanafe_amd.chip").attr("HardwareMappingError");
         PyErr_SetString(cls.ptr(), msg.c_str());
         throw py::error_already_set();
     }

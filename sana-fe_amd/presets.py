@@ -6,15 +6,16 @@ numeric constants are the ones the reference's architecture descriptions give
 (cited per preset); tests/test_presets.py checks each preset against the
 reference YAML whenever the reference is present.
 """
-from . import description as D
 
 
 def _api(api):
-    """The description API to build with: the C++/PyBind11 module by default, or the Python twin."""
+    """The description API to build with: the C++/PyBind11 module by default (tests pass their Python twin)."""
     if api is not None:
         return api
     from .chip import cpp
-    return cpp if cpp is not None else D
+    if cpp is None:
+        raise ImportError("sanafecpp_amd is missing: build it with `make -C sana-fe_amd`")
+    return cpp
 
 # arch/loihi.yaml:19-27, arch/loihi_large.yaml:12-20 -- Loihi hop costs (Davies et al. 2018)
 _LOIHI_TILE = dict(energy_north_hop=4.2e-12, latency_north_hop=6.5e-9, energy_east_hop=3.0e-12, latency_east_hop=4.1e-9,
@@ -132,29 +133,6 @@ def example_chip(api=None):
                                 latency_update_neuron=0.0, energy_spike_out=0.0, latency_spike_out=0.0))
             core.create_axon_out("demo_out", 100.0e-12, 5.0e-9)
     return arch
-
-
-def example_snn(arch):
-    """snn/example_snn.yaml restated with the Python twin's typed setters, so that the description is
-    identical to what the YAML front-end reads (4 neurons, 5 synapses)."""
-    net = D.Network("example_snn")
-    gin = net.create_neuron_group("in", 2, log_spikes=True)
-    gin.apply_config(0, 1, log_spikes=False)
-    gin.set_attribute("spikes", (D.ATTR_LIST, 0.0, None, [1, 0, 1]), D.FWD_ALL, 1, 2)
-    gout = net.create_neuron_group("out", 2)
-    gout.apply_config(0, 2, log_potential=True,
-                      attrs={"threshold": ((D.ATTR_INT, 2.0, None, None), D.FWD_SOMA),
-                             "log_u": ((D.ATTR_BOOL, 1.0, None, None), D.FWD_ALL)})
-    import numpy as np
-    net._add_edges(np.array([gout.base + 1]), np.array([gout.base + 1]), np.array([-4.0]))
-    gin.connect_neurons_dense(gout, {"weight": np.array([-1.0, 2.0, 1.0, 3.0])}, narrow_float=False)
-    cores = arch.tile_cores(0)
-    gin.apply_config(0, 1, soma_hw_name="demo_input")
-    gin.map_to_core(cores[0], 0, 1)
-    gin.apply_config(1, 2, soma_hw_name="demo_input")
-    gin.map_to_core(cores[1], 1, 2)
-    gout.map_to_core(cores[0])
-    return net
 
 
 def loihi_with_plugin_somas(k, plugin_path, model="hodgkin_huxley", n_inputs=4, api=None):

@@ -14,7 +14,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def example(S):
     """Config C1: arch/example_chip.yaml + snn/example_snn.yaml."""
     arch = S.presets.example_chip(api=S.description)
-    return arch, S.presets.example_snn(arch)
+    return arch, example_snn(S, arch)
 
 
 def tutorial5_dvs(S, core_counts=(1, 4, 16, 16, 4, 1)):
@@ -307,8 +307,7 @@ def shared_input_units(S, seed=8):
 
 
 def hh_plugin_path():
-    return os.path.join(os.path.dirname(GOLDEN.rstrip("/")).rsplit("/tests", 1)[0], "sana-fe_amd", "plugins",
-                        "libhodgkin_huxley.so")
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", "libhodgkin_huxley.so")
 
 
 def hodgkin_huxley(S, k=12, lif=24, seed=4):
@@ -336,3 +335,27 @@ def hodgkin_huxley(S, k=12, lif=24, seed=4):
     out.map_to_core(cores[5], 0, lif // 2)
     out.map_to_core(cores[0], lif // 2, lif)
     return arch, net
+
+
+def example_snn(S, arch):
+    """snn/example_snn.yaml restated with the Python twin's typed setters, so that the description is
+    identical to what the YAML front-end reads (4 neurons, 5 synapses)."""
+    D = S.description
+    net = D.Network("example_snn")
+    gin = net.create_neuron_group("in", 2, log_spikes=True)
+    gin.apply_config(0, 1, log_spikes=False)
+    gin.set_attribute("spikes", (D.ATTR_LIST, 0.0, None, [1, 0, 1]), D.FWD_ALL, 1, 2)
+    gout = net.create_neuron_group("out", 2)
+    gout.apply_config(0, 2, log_potential=True,
+                      attrs={"threshold": ((D.ATTR_INT, 2.0, None, None), D.FWD_SOMA),
+                             "log_u": ((D.ATTR_BOOL, 1.0, None, None), D.FWD_ALL)})
+    import numpy as np
+    net._add_edges(np.array([gout.base + 1]), np.array([gout.base + 1]), np.array([-4.0]))
+    gin.connect_neurons_dense(gout, {"weight": np.array([-1.0, 2.0, 1.0, 3.0])}, narrow_float=False)
+    cores = arch.tile_cores(0)
+    gin.apply_config(0, 1, soma_hw_name="demo_input")
+    gin.map_to_core(cores[0], 0, 1)
+    gin.apply_config(1, 2, soma_hw_name="demo_input")
+    gin.map_to_core(cores[1], 1, 2)
+    gout.map_to_core(cores[0])
+    return net

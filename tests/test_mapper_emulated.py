@@ -124,7 +124,7 @@ def test_unsupported_configs_fail_loudly(S):
     arch = S.presets.example_chip(api=S.description)
     for c in arch.cores():
         c.buffer_position = S.description.BUF_INSIDE_SOMA  # the soma would run once per synaptic event
-    net = S.presets.example_snn(arch)
+    net = nets.example_snn(S, arch)
     with pytest.raises(NotImplementedError, match="buffer position"):
         S.map_only(arch, net)
 

@@ -19,7 +19,7 @@ def test_reference_plugin_recompiles_unchanged(tmp_path):
 
 
 def test_in_tree_plugin_exports_factory():
-    so = os.path.join(ROOT, "sana-fe_amd", "plugins", "libhodgkin_huxley.so")
+    so = os.path.join(ROOT, "tests", "plugins", "libhodgkin_huxley.so")
     assert os.path.exists(so), "run `make -C sana-fe_amd`"
     assert " T create_hodgkin_huxley" in subprocess.check_output(["nm", "-D", so]).decode()
 

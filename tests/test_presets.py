@@ -1,5 +1,6 @@
 """The programmatic presets must equal what the YAML front-end reads from the reference's
 architecture / SNN descriptions (checked only where /root/reference is present)."""
+import nets  # noqa: E402
 import pytest
 
 from conftest import REFERENCE, have_reference
@@ -44,7 +45,7 @@ def test_loihi_large_preset_sample(S):
 
 def test_example_snn_preset(S):
     arch = S.presets.example_chip(api=S.description)
-    a = S.description.describe(S.to_desc(arch, S.presets.example_snn(arch)))
+    a = S.description.describe(S.to_desc(arch, nets.example_snn(S, arch)))
     arch2 = S.yaml_io.load_arch(REFERENCE + "/arch/example_chip.yaml")
     b = S.description.describe(S.to_desc(arch2, S.yaml_io.load_net(REFERENCE + "/snn/example_snn.yaml", arch2)))
     assert a["groups"] == b["groups"]

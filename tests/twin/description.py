@@ -35,8 +35,7 @@ RESERVED_NEURON_ATTRIBUTES = {"soma_hw_name", "default_synapse_hw_name", "dendri
                               "log_spikes", "log_potential", "log_v"}
 
 
-class HardwareMappingError(RuntimeError):
-    """Mirror of sanafe::HardwareMappingError (src/mapped.hpp:30-38)."""
+from sanafe_amd.chip import HardwareMappingError  # noqa: E402,F401  (the product's exception class)
 
 
 # --------------------------------------------------------------------------
@@ -575,6 +574,15 @@ class Network:
         self._mapping_count = 0
         self._edge_blocks = []
         self._n_edges = 0
+
+    def lower_for_chip(self, arch):
+        """What SpikingChip.load() needs from a front-end other than sanafecpp_amd: (address of the sanafe_desc,
+        [(group, first neuron id, count)], log_spikes, log_potential, object that keeps the buffers alive)."""
+        built = to_desc(arch, self)
+        cat = lambda name: (np.concatenate([getattr(g, name) for g in self._order]).astype(np.uint8)  # noqa: E731
+                            if self._order else np.zeros(0, np.uint8))
+        return (C.addressof(built.desc), [(g.name, int(g.base), int(g.count)) for g in self._order], cat("log_spikes"),
+                cat("log_potential"), built)
 
     def __getitem__(self, name):
         return self.groups[str(name)]
