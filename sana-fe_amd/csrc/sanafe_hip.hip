@@ -789,6 +789,15 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (max_delay >= h.ring_slots) return bail(fail(SANAFE_HIP_ERR_INVALID, "synaptic delay %u needs more than %u ring slots", max_delay, h.ring_slots));
         im.delay_slots = max_delay + 1;
     }
+    {
+        // a gated delay line matures one slot later than a plain one: writes go to slot (t + 1 + d + 1) % R
+        bool gated = false;
+        for (uint32_t g = 0; g < h.n_slots && !gated; g++)
+            gated = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_GATED;
+        if (gated && im.delay_slots + 1 > h.ring_slots)
+            return bail(fail(SANAFE_HIP_ERR_INVALID, "SANAFE_IN_GATED neurons with synaptic delay %u need %u ring slots (have %u)",
+                    im.delay_slots - 1, im.delay_slots + 1, h.ring_slots));
+    }
     c->deliver_lds = (size_t) im.delay_slots * (max_pad + 1) * (sizeof(double) + 1);
     c->has_delay = im.delay_slots > 1 || c->force_delay_variant;
     im.syn_format = c->syn_format;
@@ -1044,7 +1053,17 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         return 0;
     }
     // Timed mode (bench.py roofline block): HIP events on the kernels' own stream.
-    std::vector<hipEvent_t> ev((size_t) n_steps * 4);
+    struct Events // destroyed on every exit path
+    {
+        std::vector<hipEvent_t> v;
+        ~Events()
+        {
+            for (hipEvent_t e : v)
+                if (e) (void) hipEventDestroy(e);
+        }
+    } events;
+    events.v.assign((size_t) n_steps * 4, nullptr);
+    std::vector<hipEvent_t> &ev = events.v;
     for (auto &e : ev) HIPCHK(hipEventCreate(&e));
     for (int64_t s = 0; s < n_steps; s++)
     {
@@ -1071,7 +1090,6 @@ extern "C" int sanafe_hip_step(sanafe_hip_chip *c, int64_t n_steps, int simple_t
         c->t_reduce += d;
     }
     c->t_launches += n_steps;
-    for (auto &e : ev) (void) hipEventDestroy(e);
     return 0;
 }
 

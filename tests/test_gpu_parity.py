@@ -479,6 +479,41 @@ def test_hodgkin_huxley_plugin_c5(S, timing):
     assert fired_any > 0
 
 
+@pytest.mark.parametrize("timing", ["simple", "detailed"])
+@pytest.mark.parametrize("position", ["inside", "before"])
+def test_plugin_somas_pay_the_dendrite_of_the_neuron_pipeline(S, timing, position):
+    """With the buffer before or inside the dendrite unit the neuron-processing pipeline runs dendrite -> soma
+    (src/pipeline.cpp:268-310), so every update of a PLUGIN soma also costs the dendrite's energy_update /
+    latency_update (energy, simple sim_time, detailed generation delays)."""
+    D = S.description
+    arch, net = nets.hodgkin_huxley(S)
+    seen = set()
+    for core in arch.cores():
+        core.buffer_position = D.BUF_INSIDE_DENDRITE if position == "inside" else D.BUF_BEFORE_DENDRITE
+        for u in core.units:
+            if id(u) not in seen and (u.implements & D.IMPL_DENDRITE):
+                seen.add(id(u))
+                u.attributes["energy_update"] = (D.ATTR_DOUBLE, 1.5e-12, None, None)
+                u.attributes["latency_update"] = (D.ATTR_DOUBLE, 2.0e-9, None, None)
+    chip, orc = make(S, arch, net)
+    e_dend = 0.0
+    for t in range(40):
+        a = chip.run(1, timing, record=True, messages=(timing == "detailed"))
+        b = orc.step(timing)
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        assert np.array_equal(chip.status(), orc.status()), t
+        if timing == "detailed":
+            ma, mb = chip.step_messages(0), orc.messages()
+            assert len(ma) == len(mb)
+            for name in ("generation_delay", "sent_timestamp", "processed_timestamp"):
+                assert np.array_equal(ma[name], mb[name]), (t, name)
+        e_dend += a["dendrite_energy"]
+    assert e_dend > 0.0
+
+
 def test_cpp_frontend_yaml_on_gpu(S):
     """The product front-end end to end: C++ YAML reader -> C++ description -> mapper -> HIP, against the oracle
     fed by the independent Python twin (PyYAML) reading the same files."""
