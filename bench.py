@@ -42,9 +42,12 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
                                 "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(seed)
     g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128.0, 0.0), integer=True)
-    # a rank only needs the edges that start or end in its own shard of the neurons
+    # a rank only needs the edges that start or end in its own shard of the neurons.  Weak scaling: every neuron draws
+    # its targets from the n_per_gpu neurons (one GPU's worth of cores) centred on itself, ids wrapping -- on one GPU
+    # that is the uniform recipe of SURVEY 8(d); on N GPUs the fan-in statistics of a core (sources per core, synapses
+    # per axon) stay what they are on one, and a quarter of the edges cross a GPU boundary
     shard = None if n_gpus == 1 else (rank * n_per_gpu, (rank + 1) * n_per_gpu)
-    src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard)
+    src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard, window=n_per_gpu)
     if weights == "int12":    # integers beyond int8: the 12-bit-weight synapse word (format 3)
         w *= 100.0
     elif weights == "float":  # not representable as integers: fp64 weights beside the synapse words (format 4)

@@ -153,6 +153,10 @@ int sanafe_generate_random_edges(int64_t n_neurons, int64_t out_degree, uint64_t
 typedef struct sanafe_edge_set sanafe_edge_set;
 int sanafe_generate_random_edges_sharded(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
         int64_t lo, int64_t hi, sanafe_edge_set **out, int64_t *count);
+/* Locally connected variant (weak scaling): targets drawn uniformly from the `window` neurons centred on the source
+ * (ids wrap); window == n_neurons is the uniform recipe.  Keeps the edges with source or destination in [lo, hi). */
+int sanafe_generate_random_edges_windowed(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t window, int64_t lo, int64_t hi, sanafe_edge_set **out, int64_t *count);
 int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t *dst, double *weight);
 void sanafe_edge_set_free(sanafe_edge_set *set);
 

@@ -528,10 +528,28 @@ def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
         L.sanafe_chip_destroy(h)
 
 
-def generate_random_edges(n_neurons, out_degree, seed=1, n_threads=None, src_base=0, dst_base=0, shard=None):
+def generate_random_edges(n_neurons, out_degree, seed=1, n_threads=None, src_base=0, dst_base=0, shard=None, window=None):
     """(src, dst, weight) of the synthetic random SNN of the benchmark configs.
-    ``shard=(lo, hi)`` keeps only the edges with source or destination in [lo, hi)."""
+    ``shard=(lo, hi)`` keeps only the edges with source or destination in [lo, hi); ``window`` draws every neuron's
+    targets from the `window` neurons centred on it (ids wrap) instead of from all of them."""
     n_threads = n_threads or min(32, os.cpu_count() or 1)
+    if window is not None:
+        L = lib()
+        L.sanafe_generate_random_edges_windowed.argtypes = [C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.c_int64,
+                                                            C.c_int64, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.sanafe_edge_set_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.sanafe_edge_set_free.argtypes = [C.c_void_p]
+        lo, hi = shard if shard is not None else (0, n_neurons)
+        h, cnt = C.c_void_p(), C.c_int64()
+        if L.sanafe_generate_random_edges_windowed(n_neurons, out_degree, seed, n_threads, int(window), lo, hi,
+                                                   C.byref(h), C.byref(cnt)) != 0:
+            raise RuntimeError(L.sanafe_last_error().decode())
+        src = np.empty(cnt.value, dtype=np.int64)
+        dst = np.empty(cnt.value, dtype=np.int64)
+        w = np.empty(cnt.value, dtype=np.float64)
+        L.sanafe_edge_set_copy(h, src.ctypes.data, dst.ctypes.data, w.ctypes.data)
+        L.sanafe_edge_set_free(h)
+        return src, dst, w
     if shard is not None:
         L = lib()
         L.sanafe_generate_random_edges_sharded.argtypes = [C.c_int64, C.c_int64, C.c_uint64, C.c_int, C.c_int64, C.c_int64,

@@ -138,6 +138,73 @@ extern "C" int sanafe_generate_random_edges_sharded(int64_t n_neurons, int64_t o
     return 0;
 }
 
+// Locally connected variant -- the weak-scaling form of the recipe: every neuron draws its `out_degree` distinct
+// targets uniformly from the `window` neurons centred on itself (ids wrap around), so the fan-in statistics of a core
+// (sources per core, synapses per axon) do not change when the chip grows by whole windows; with window == n_neurons
+// it is the uniform recipe.  Only sources within window / 2 of [lo, hi) can reach it, so a rank generates its slice
+// of a chip of any size in time proportional to its own share.
+extern "C" int sanafe_generate_random_edges_windowed(int64_t n_neurons, int64_t out_degree, uint64_t seed, int n_threads,
+        int64_t window, int64_t lo, int64_t hi, sanafe_edge_set **out, int64_t *count)
+{
+    if (n_neurons <= 0 || window <= 0 || window > n_neurons || out_degree < 0 || out_degree > window || lo < 0 || hi > n_neurons || lo > hi ||
+            !out || !count)
+        return fail(SANAFE_HIP_ERR_INVALID, "bad generator arguments");
+    n_threads = std::max(1, n_threads);
+    auto set = std::make_unique<sanafe_edge_set>();
+    set->src.resize(n_threads);
+    set->dst.resize(n_threads);
+    set->w.resize(n_threads);
+    // candidate sources: [lo - window/2 - 1, hi + window/2 + 1), clipped to one lap of the ring
+    const int64_t half = window / 2 + 1;
+    const int64_t span = std::min<int64_t>(n_neurons, (hi - lo) + 2 * half);
+    const int64_t first = ((lo - half) % n_neurons + n_neurons) % n_neurons;
+    auto work = [&](int tid) {
+        std::vector<uint64_t> seen((window + 63) / 64, 0);
+        std::vector<int64_t> draws(out_degree);
+        const int64_t b = span * tid / n_threads, e = span * (tid + 1) / n_threads;
+        const size_t cap = static_cast<size_t>(static_cast<double>(out_degree) * static_cast<double>(e - b) * 0.75) + 4096;
+        set->src[tid].reserve(cap);
+        set->dst[tid].reserve(cap);
+        set->w[tid].reserve(cap);
+        for (int64_t q = b; q < e; q++)
+        {
+            const int64_t i = (first + q) % n_neurons;
+            std::mt19937_64 gen(seed * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(i) + 1);
+            const bool src_local = (i >= lo && i < hi);
+            const int64_t base = i - window / 2;
+            for (int64_t k = 0; k < out_degree; k++)
+            {
+                uint64_t r;
+                do
+                {
+                    r = gen() % static_cast<uint64_t>(window);
+                } while (seen[r >> 6] & (1ull << (r & 63)));
+                seen[r >> 6] |= 1ull << (r & 63);
+                draws[k] = static_cast<int64_t>(r);
+                const int64_t t = ((base + static_cast<int64_t>(r)) % n_neurons + n_neurons) % n_neurons;
+                const uint64_t wv = gen();
+                if (src_local || (t >= lo && t < hi))
+                {
+                    const double mag = static_cast<double>(1 + (wv % 8));
+                    set->src[tid].push_back(i);
+                    set->dst[tid].push_back(t);
+                    set->w[tid].push_back((wv & (1ull << 40)) ? mag : -mag);
+                }
+            }
+            for (int64_t k = 0; k < out_degree; k++) seen[draws[k] >> 6] &= ~(1ull << (draws[k] & 63));
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < n_threads; t++) pool.emplace_back(work, t);
+    work(0);
+    for (auto &th : pool) th.join();
+    int64_t total = 0;
+    for (auto &v : set->src) total += static_cast<int64_t>(v.size());
+    *count = total;
+    *out = set.release();
+    return 0;
+}
+
 extern "C" int sanafe_edge_set_copy(sanafe_edge_set *set, int64_t *src, int64_t *dst, double *weight)
 {
     if (!set || !src || !dst || !weight) return fail(SANAFE_HIP_ERR_INVALID, "null argument");

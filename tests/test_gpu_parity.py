@@ -560,3 +560,33 @@ def test_cpp_frontend_sim_result_dict(S):
     r2 = chip.sim(5)  # cumulative: continues at step 11 with the default detailed model
     assert r2["timestep_start"] == 11 and r2["sim_time"] > 0
     assert chip.get_power() > 0
+
+
+@pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_refractory"])
+def test_uniform_and_table_driven_neuron_kernels_agree(S, monkeypatch, which):
+    """Chips whose neurons all carry one class word run neuron_kernel<MODEL, UNI=true> (parameters in scalar registers,
+    no class word loaded); SANAFE_NEURON_GENERIC=1 forces the table-driven kernel on the same chip.  Both against the
+    oracle, and bit-identical to each other."""
+    if which == "truenorth":
+        arch, net = nets.truenorth_net(S, n_tiles=16)
+    elif which == "loihi_delays":
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=100, out_degree=24, arch_kind="large", delays=True, seed=17)
+    else:
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=128, out_degree=24, arch_kind="loihi", refractory=True, seed=18)
+    # every neuron the same class word?  (bias is per-slot data, not part of the class)
+    chip_u, orc = check_stepwise(S, arch, net, steps=15)
+    monkeypatch.setenv("SANAFE_NEURON_GENERIC", "1")
+    chip_g = S.SpikingChip(arch)
+    chip_g.load(net)
+    a = chip_g.run(15, "simple", record=True)
+    chip_u2 = None
+    monkeypatch.delenv("SANAFE_NEURON_GENERIC")
+    chip_u2 = S.SpikingChip(arch)
+    chip_u2.load(net)
+    b = chip_u2.run(15, "simple", record=True)
+    assert a == b  # RunData incl. energies and sim_time: both kernels use the same fixed associations
+    ra, rb = chip_g.step_totals(0, 15), chip_u2.step_totals(0, 15)
+    for k in ra.dtype.names:
+        assert np.array_equal(ra[k], rb[k]), k
+    assert np.array_equal(chip_g.potentials(), chip_u2.potentials())
+    assert np.array_equal(chip_g.potentials(), orc.potentials())
