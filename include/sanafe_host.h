@@ -85,6 +85,10 @@ int sanafe_chip_commit_attributes(sanafe_chip *chip);
  * generators, the rand() sequence, noise files).  sim() does this itself; the call exists for mapped-only
  * chips and for callers that drive sanafe_hip_* directly. */
 int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out);
+/* Profiling hook for the host-side detailed NoC schedule: rebuilds the messages of one timestep from `status` (one
+ * NeuronStatus byte per local slot of a single-rank chip, device or mapped-only) and schedules them `reps` times. */
+int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, int reps, double *sim_time, int64_t *n_messages,
+        double *build_seconds, double *schedule_seconds);
 /* Self-check hook: the first n values of the host's restatement of glibc rand() for `seed`. */
 void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out);
 int sanafe_chip_reset(sanafe_chip *chip);

@@ -14,6 +14,7 @@
 #include <limits>
 #include <random>
 #include <thread>
+#include <type_traits>
 #include <list>
 #include <memory>
 #include <queue>
@@ -187,6 +188,17 @@ struct ExtStreams
 struct Msg : sanafe_message
 {
     bool in_noc{false};
+};
+// What the NoC schedule itself reads and writes of a message: 96 bytes instead of the 240 of the traced record.
+// Used when no message trace is kept (same member names, so the scheduler is one template).
+struct SchedMsg
+{
+    double generation_delay, processing_delay, min_hop_delay;
+    double sent_timestamp, received_timestamp, processed_timestamp;
+    double blocking_delay, network_delay, messages_along_route;
+    uint32_t src_core_id, dest_core_id;
+    uint16_t hops, src_x, src_y, dest_x, dest_y, src_core_offset;
+    uint8_t placeholder, in_noc;
 };
 } // namespace
 
@@ -459,11 +471,14 @@ struct sanafe_chip
     // 694-708, 802-834: per core, neurons in mapped order; latencies accumulate into
     // next_message_generation_delay; the first message of a firing neuron carries it.
     // ------------------------------------------------------------------------------
-    void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<Msg>> &per_core,
+    template <typename M>
+    void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<M>> &per_core,
             int64_t mid_base) const
     {
+        constexpr bool FULL = std::is_same<M, Msg>::value; // the traced record carries every field of `Message`
         int64_t next_mid = mid_base;
-        per_core.assign(mc.n_cores, {});
+        per_core.resize(mc.n_cores);
+        for (auto &q : per_core) q.clear(); // capacity is kept: the caller reuses the queues from step to step
         for (uint32_t c = 0; c < mc.n_cores; c++)
         {
             double next_delay = 0.0;
@@ -488,25 +503,28 @@ struct sanafe_chip
                 for (uint64_t o = mc.out_ptr[s]; o < mc.out_ptr[s + 1]; o++)
                 {
                     const uint64_t a = mc.out_axon[o];
-                    Msg m{};
-                    m.timestep = timestep;
-                    m.mid = next_mid++;
-                    m.src_neuron = mc.gid_of_slot[s];
-                    m.src_tile = st;
+                    M m{};
+                    const uint32_t dc = mc.ax_dest_core[a];
+                    const uint32_t dt = mc.core_tile[dc];
+                    if constexpr (FULL)
+                    {
+                        m.timestep = timestep;
+                        m.mid = next_mid++;
+                        m.src_neuron = mc.gid_of_slot[s];
+                        m.src_tile = st;
+                        m.dest_tile = dt;
+                        m.dest_core_offset = mc.core_offset[dc];
+                        m.dest_axon_id = mc.ax_dest_axon_id[a];
+                        m.spikes = mc.ax_nsyn[a];
+                    }
                     m.src_core_id = c;
                     m.src_core_offset = mc.core_offset[c];
                     m.src_x = mc.tile_x[st];
                     m.src_y = mc.tile_y[st];
-                    const uint32_t dc = mc.ax_dest_core[a];
-                    const uint32_t dt = mc.core_tile[dc];
-                    m.dest_tile = dt;
                     m.dest_core_id = dc;
-                    m.dest_core_offset = mc.core_offset[dc];
                     m.dest_x = mc.tile_x[dt];
                     m.dest_y = mc.tile_y[dt];
-                    m.dest_axon_id = mc.ax_dest_axon_id[a];
                     m.hops = mc.ax_hops[a];
-                    m.spikes = mc.ax_nsyn[a];
                     m.placeholder = 0;
                     m.generation_delay = next_delay + lat_access;
                     next_delay = 0.0;
@@ -518,11 +536,14 @@ struct sanafe_chip
             }
             if (next_delay != 0.0) // placeholder, src/chip.cpp:640-652
             {
-                Msg m{};
-                m.timestep = timestep;
-                m.mid = -1;
-                m.src_neuron = last_gid;
-                m.src_tile = st;
+                M m{};
+                if constexpr (FULL)
+                {
+                    m.timestep = timestep;
+                    m.mid = -1;
+                    m.src_neuron = last_gid;
+                    m.src_tile = st;
+                }
                 m.src_core_id = c;
                 m.src_core_offset = mc.core_offset[c];
                 m.src_x = mc.tile_x[st];
@@ -615,36 +636,53 @@ struct sanafe_chip
             return (x * h * lpr) + (y * lpr) + link;
         }
     };
-    template <typename F> static void walk_route(const Noc &noc, const Msg &m, F &&visit)
+    template <typename M, typename F> static void walk_route(const Noc &noc, const M &m, F &&visit)
     {
         // dimension-order route; NocInfo::update_message_density / calculate_route_congestion,
-        // src/schedule.cpp:478-611 (directions: north 0, east 1, south 2, west 3)
-        const int xi = (m.src_x < m.dest_x) ? 1 : -1, yi = (m.src_y < m.dest_y) ? 1 : -1;
+        // src/schedule.cpp:478-611 (directions: north 0, east 1, south 2, west 3).  The cell index
+        // idx(x, y, link) = (x * h + y) * links + link is advanced by its strides instead of recomputed.
+        const int64_t sx = m.src_x, sy = m.src_y, dx = m.dest_x, dy = m.dest_y;
+        const int64_t lpr = static_cast<int64_t>(noc.max_cpt) + 4, stride_x = static_cast<int64_t>(noc.h) * lpr;
         const size_t own = 4 + m.src_core_offset;
         size_t prev = own;
-        for (int64_t x = m.src_x; x != m.dest_x; x += xi)
+        int64_t cell = sx * stride_x + sy * lpr; // (x, y) of the walk, link 0
+        if (sx != dx)
         {
-            const size_t dir = (xi > 0) ? 1 : 3;
-            visit(noc.idx(x, m.src_y, x == m.src_x ? own : dir));
+            const int64_t step = (sx < dx) ? stride_x : -stride_x;
+            const size_t dir = (sx < dx) ? 1 : 3;
+            visit(static_cast<size_t>(cell) + own);
+            cell += step;
+            for (int64_t x = sx + ((sx < dx) ? 1 : -1); x != dx; x += (sx < dx) ? 1 : -1, cell += step) visit(static_cast<size_t>(cell) + dir);
             prev = dir;
         }
-        for (int64_t y = m.src_y; y != m.dest_y; y += yi)
+        if (sy != dy)
         {
-            const size_t dir = (yi > 0) ? 0 : 2;
-            visit(noc.idx(m.dest_x, y, (m.src_x == m.dest_x && y == m.src_y) ? own : prev));
+            const int64_t step = (sy < dy) ? lpr : -lpr;
+            const size_t dir = (sy < dy) ? 0 : 2;
+            visit(static_cast<size_t>(cell) + prev); // at (dest_x, src_y): the own link when there was no x leg
+            cell += step;
+            for (int64_t y = sy + ((sy < dy) ? 1 : -1); y != dy; y += (sy < dy) ? 1 : -1, cell += step) visit(static_cast<size_t>(cell) + dir);
             prev = dir;
         }
-        visit(noc.idx(m.dest_x, m.dest_y, (m.src_x == m.dest_x && m.src_y == m.dest_y) ? own : prev));
+        visit(static_cast<size_t>(cell) + prev);
     }
-    static void track(Noc &noc, const Msg &m, bool entering)
+    template <typename M> static void check_bounds(const Noc &noc, const M &m)
     {
         if (static_cast<size_t>(m.src_x) > noc.w || static_cast<size_t>(m.dest_x) > noc.w)
             throw std::runtime_error("Message x > NoC width");
         if (static_cast<size_t>(m.src_y) > noc.h || static_cast<size_t>(m.dest_y) > noc.h)
             throw std::runtime_error("Message y > NoC height");
+    }
+    template <typename M> static void track(Noc &noc, const M &m, bool entering)
+    {
+        check_bounds(noc, m);
         double adjust = 1.0 / (2.0 + static_cast<double>(m.hops));
         if (!entering) adjust *= -1.0;
         walk_route(noc, m, [&](size_t i) { noc.density[i] += adjust; });
+        rolling_average(noc, m, entering);
+    }
+    template <typename M> static void rolling_average(Noc &noc, const M &m, bool entering)
+    {
         if (entering) // update_rolling_averages, src/schedule.cpp:449-476
         {
             noc.mean_delay += (m.processing_delay - noc.mean_delay) / (static_cast<double>(noc.in_noc) + 1.0);
@@ -657,26 +695,33 @@ struct sanafe_chip
             noc.in_noc--;
         }
     }
-    struct BySent
-    {
-        bool operator()(const Msg &a, const Msg &b) const noexcept { return a.sent_timestamp > b.sent_timestamp; }
-    };
     // schedule_messages_timestep_detailed, src/schedule.cpp:208-292, with the same arithmetic in the same order but
     // without its O(cores) scan per scheduled message: the reference walks every core's list of in-flight messages
     // at each pop (noc_update_all_tracked_messages, :380-400) and retires those received by `now`, in (core, list)
     // order.  Here the in-flight messages sit in a min-heap on their received time; the ones due are popped,
     // put back into (destination core, arrival) order and retired -- the identical sequence of density and
     // rolling-average updates, so every timestamp is bit-identical (checked against the oracle, which keeps the scan).
-    double schedule_detailed(std::vector<std::vector<Msg>> &per_core, bool keep_order) const
+    // Scratch of one scheduler thread, reused from timestep to timestep (no allocation in the steady state).
+    template <typename M> struct SchedScratch
     {
         Noc noc;
+        std::vector<size_t> head;
+        std::vector<std::vector<M>> per_core;
+    };
+    template <typename M> double schedule_detailed(std::vector<std::vector<M>> &per_core, bool keep_order, SchedScratch<M> &scratch) const
+    {
+        using Msg = M; // (the body below is written against the member names both message types share)
+        Noc &noc = scratch.noc;
         noc.w = mc.noc_width;
         noc.h = mc.noc_height;
         noc.max_cpt = mc.max_cores_per_tile;
+        noc.mean_delay = 0.0;
+        noc.in_noc = 0;
         noc.core_finished.assign(mc.n_cores, 0.0);
         noc.density.assign(static_cast<size_t>(mc.noc_height) * mc.noc_width * (4 + mc.max_cores_per_tile), 0.0);
-        std::vector<size_t> head(mc.n_cores, 0);
-        std::vector<std::vector<const Msg *>> sched_order(mc.n_cores); // pop order per source core
+        std::vector<size_t> &head = scratch.head;
+        head.assign(mc.n_cores, 0);
+        std::vector<std::vector<const Msg *>> sched_order(keep_order ? mc.n_cores : 0); // pop order per source core
         // The send queue holds handles; its order depends only on the comparisons, which are the reference's
         // (CompareMessagesBySentTime, src/message.cpp:61-65), so ties break exactly as there.
         struct Pending
@@ -690,19 +735,58 @@ struct sanafe_chip
         };
         std::priority_queue<Pending, std::vector<Pending>, BySentHandle> pq;
         // messages are scheduled in place, in their source core's FIFO (the vectors do not move while this runs)
-        struct InFlight
+        struct InFlight // 32 bytes: everything retirement needs without touching the message again but for its route
         {
             double received;
-            uint64_t seq; // arrival order at its destination core's list
+            double adjust;   // the density share 1 / (2 + hops) this message added along its route
             const Msg *m;
+            uint32_t seq;    // arrival order at its destination core's list
+            uint32_t dest;   // destination core
         };
-        struct ByReceived
+        // 4-ary min-heap on the received time: half the levels of a binary heap for the few hundred to few thousand
+        // messages in flight.  Which of several equal keys pops first does not matter: what is due is re-ordered below.
+        struct Heap
         {
-            bool operator()(const InFlight &a, const InFlight &b) const noexcept { return a.received > b.received; }
-        };
-        std::priority_queue<InFlight, std::vector<InFlight>, ByReceived> in_flight;
+            std::vector<InFlight> v;
+            bool empty() const { return v.empty(); }
+            const InFlight &top() const { return v.front(); }
+            void push(const InFlight &e)
+            {
+                size_t i = v.size();
+                v.push_back(e);
+                while (i > 0)
+                {
+                    const size_t p = (i - 1) >> 2;
+                    if (!(v[p].received > e.received)) break;
+                    v[i] = v[p];
+                    i = p;
+                }
+                v[i] = e;
+            }
+            void pop()
+            {
+                const InFlight e = v.back();
+                v.pop_back();
+                const size_t n = v.size();
+                if (n == 0) return;
+                size_t i = 0;
+                for (;;)
+                {
+                    const size_t c0 = 4 * i + 1;
+                    if (c0 >= n) break;
+                    size_t best = c0;
+                    const size_t c1 = std::min(n, c0 + 4);
+                    for (size_t c = c0 + 1; c < c1; c++)
+                        if (v[c].received < v[best].received) best = c;
+                    if (!(v[best].received < e.received)) break;
+                    v[i] = v[best];
+                    i = best;
+                }
+                v[i] = e;
+            }
+        } in_flight;
         std::vector<InFlight> due;
-        uint64_t seq = 0;
+        uint32_t seq = 0;
         for (uint32_t c = 0; c < mc.n_cores; c++)
             if (!per_core[c].empty())
             {
@@ -724,15 +808,25 @@ struct sanafe_chip
                 in_flight.pop();
             }
             if (due.size() > 1)
-                std::sort(due.begin(), due.end(), [](const InFlight &a, const InFlight &b) {
-                    return a.m->dest_core_id != b.m->dest_core_id ? a.m->dest_core_id < b.m->dest_core_id : a.seq < b.seq;
-                });
-            for (const InFlight &r : due) track(noc, *r.m, false);
+                std::sort(due.begin(), due.end(), [](const InFlight &a, const InFlight &b) { return a.dest != b.dest ? a.dest < b.dest : a.seq < b.seq; });
+            for (const InFlight &r : due) // NocInfo::update_message_density(leaving) + update_rolling_averages
+            {
+                const double leave = r.adjust * -1.0;
+                walk_route(noc, *r.m, [&](size_t i) { noc.density[i] += leave; });
+                rolling_average(noc, *r.m, false);
+            }
             if (!m.placeholder) // schedule_handle_message
             {
                 const size_t dc = m.dest_core_id;
+                // one walk reads the densities along the route (calculate_route_congestion) and adds this message's own
+                // share to them (update_message_density): each cell is read before it is changed, as in two walks
+                check_bounds(noc, m);
+                const double adjust = 1.0 / (2.0 + static_cast<double>(m.hops));
                 double flow = 0.0;
-                walk_route(noc, m, [&](size_t i) { flow += noc.density[i]; });
+                walk_route(noc, m, [&](size_t i) {
+                    flow += noc.density[i];
+                    noc.density[i] += adjust;
+                });
                 m.messages_along_route = flow;
                 const double cap = static_cast<double>((m.hops + 1UL) * mc.noc_buffer);
                 if (m.messages_along_route > cap)
@@ -751,8 +845,8 @@ struct sanafe_chip
                 noc.core_finished[dc] = std::max(noc.core_finished[dc] + m.processing_delay, earliest + m.processing_delay);
                 m.processed_timestamp = noc.core_finished[dc];
                 m.in_noc = true;
-                in_flight.push(InFlight{m.received_timestamp, seq++, &m});
-                track(noc, m, true);
+                in_flight.push(InFlight{m.received_timestamp, adjust, &m, seq++, static_cast<uint32_t>(dc)});
+                rolling_average(noc, m, true);
                 last = std::max(last, m.processed_timestamp);
             }
             const size_t sc = m.src_core_id;
@@ -1137,11 +1231,19 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         auto run_job = [&](Job &job) {
             try
             {
-                std::vector<std::vector<Msg>> per_core;
-                chip->build_messages(job.ts.timesteps, job.status, per_core, job.mid_base);
-                job.ts.sim_time = chip->schedule_detailed(per_core, want_messages);
-                if (want_messages)
-                    for (auto &q : per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
+                if (want_messages) // the traced record of every message, in scheduling order
+                {
+                    thread_local sanafe_chip::SchedScratch<Msg> scratch;
+                    chip->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    job.ts.sim_time = chip->schedule_detailed(scratch.per_core, true, scratch);
+                    for (auto &q : scratch.per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
+                }
+                else // only sim_time is wanted: the compact message, queues and NoC state reused by this thread
+                {
+                    thread_local sanafe_chip::SchedScratch<SchedMsg> scratch;
+                    chip->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    job.ts.sim_time = chip->schedule_detailed(scratch.per_core, false, scratch);
+                }
             }
             catch (const std::exception &e)
             {
@@ -1367,6 +1469,42 @@ extern "C" void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out)
 {
     GlibcRand g(seed);
     for (int64_t i = 0; i < n; i++) out[i] = g.next();
+}
+
+// Test / profiling hook: rebuilds the messages of one timestep from `status` (one NeuronStatus byte per local slot)
+// and runs the detailed NoC schedule `reps` times on the calling thread -- no device involved, so the host-side cost
+// per message can be measured on any machine.  Returns sim_time of the step and the number of messages.
+extern "C" int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, int reps, double *sim_time, int64_t *n_messages,
+        double *build_seconds, double *schedule_seconds)
+{
+    if (!chip || !status || chip->mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_INVALID, "needs a single-rank chip and a status array");
+    try
+    {
+        const std::vector<uint8_t> st(status, status + chip->mc.n_slots);
+        sanafe_chip::SchedScratch<SchedMsg> scratch;
+        double tb = 0.0, tsch = 0.0, last = 0.0;
+        int64_t n = 0;
+        for (int r = 0; r < reps; r++)
+        {
+            const auto t0 = std::chrono::steady_clock::now();
+            chip->build_messages(1, st, scratch.per_core, 0);
+            const auto t1 = std::chrono::steady_clock::now();
+            last = chip->schedule_detailed(scratch.per_core, false, scratch);
+            const auto t2 = std::chrono::steady_clock::now();
+            tb += std::chrono::duration<double>(t1 - t0).count();
+            tsch += std::chrono::duration<double>(t2 - t1).count();
+        }
+        for (const auto &q : scratch.per_core) n += static_cast<int64_t>(q.size());
+        if (sim_time) *sim_time = last;
+        if (n_messages) *n_messages = n;
+        if (build_seconds) *build_seconds = tb;
+        if (schedule_seconds) *schedule_seconds = tsch;
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    return 0;
 }
 
 extern "C" int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out)
