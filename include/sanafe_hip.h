@@ -70,6 +70,10 @@ enum {
                                  synapse's delay field carries the tap index; tap state advances once per step, the
                                  step's charge is added per tap, and tap 0 is handed to the soma at t+1 if an event
                                  reached the neuron at t (slot_aux = entry of the tap tables) */
+    SANAFE_IN_LAST_DELAY = 5, /* `accumulator_with_delay` with the buffer BEFORE the dendrite unit: the neuron-side call happens
+                                 every step (the line shifts, the matured charge reaches the soma) and integrates only the LAST
+                                 synaptic event's current, without a synapse address -- so with the delay of the unit's synapse
+                                 address 0 (src/models.cpp:96-131, src/pipeline.hpp:460-508); slot_aux = that delay */
     SANAFE_IN_LAST = 2        /* buffer before the dendrite unit (`buffer_position: dendrite`, outside): the kernel's
                                  time-step buffer keeps only the LAST synaptic event's current (src/chip.cpp:759), which the
                                  accumulator then integrates alone; always "has input" (the lazy clear leaves 0.0) */

@@ -201,7 +201,8 @@ int validate(const sanafe_hip_image *im)
         {
             const uint32_t cl = im->slot_cls[im->core_nbase[c] + k];
             if ((cl & 7u) == SANAFE_SOMA_NONE) continue;
-            ((((cl >> 3) & 7u) == SANAFE_IN_LAST) ? any_last : any_other) = true;
+            const uint32_t kind = (cl >> 3) & 7u;
+            ((kind == SANAFE_IN_LAST || kind == SANAFE_IN_LAST_DELAY) ? any_last : any_other) = true;
         }
         if (any_last && any_other) return fail(SANAFE_HIP_ERR_INVALID, "core %u mixes SANAFE_IN_LAST with other input kinds", c);
     }
@@ -268,7 +269,9 @@ int validate(const sanafe_hip_image *im)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
-        if (((cls >> 3) & 7u) > SANAFE_IN_TAPS) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) > SANAFE_IN_LAST_DELAY) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) == SANAFE_IN_LAST_DELAY && im->slot_aux[g] + 2u > im->ring_slots)
+            return fail(SANAFE_HIP_ERR_INVALID, "slot %u: delay %u needs %u ring slots", g, im->slot_aux[g], im->slot_aux[g] + 2u);
         if (((cls >> 3) & 7u) == SANAFE_IN_TAPS && (im->slot_aux[g] >= im->n_taps || im->tap_count[im->slot_aux[g]] < 1 || im->tap_count[im->slot_aux[g]] > 8))
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad tap table entry", g);
     }
@@ -396,6 +399,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             c->neuron_model = (same_model && (model0 == SANAFE_SOMA_LIF || model0 == SANAFE_SOMA_TRUENORTH)) ? (int) model0 : 0;
             const uint32_t cpc = (ncount0 + 63u) / 64u, wpc = (cpc + 3u) / 4u;
             c->uni = c->neuron_model != 0 && same_cls && equal_cores && h.n_ext == 0 && (wpc & (wpc - 1u)) == 0u &&
+                    ((cls0 >> 3) & 7u) != SANAFE_IN_LAST_DELAY && // its per-slot delay lives in slot_aux
                     (cls0 >> 16) < h.n_soma_classes && ((cls0 >> 6) & 1023u) < h.n_cost_classes &&
                     std::getenv("SANAFE_NEURON_GENERIC") == nullptr; // tests: force the table-driven kernel
             if (c->uni)
@@ -724,7 +728,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(dalloc(c, (size_t) h.ring_slots * h.n_slots, &st.ring_valid));
     im.has_last = 0;
     for (uint32_t g = 0; g < h.n_slots && !im.has_last; g++)
-        im.has_last = ((h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE && ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST) ? 1 : 0;
+        im.has_last = ((h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE &&
+                              (((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST || ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST_DELAY))
+                ? 1 : 0;
     st.ring_last = nullptr;
     if (im.has_last) TRYC(dalloc(c, h.n_slots, &st.ring_last));
     st.arrived = nullptr;

@@ -372,6 +372,32 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                     cur = has_in ? in_value : 0.0;
                 }
             }
+            else if (inkind == SANAFE_IN_LAST_DELAY)
+            {
+                // accumulator_with_delay called from the NEURON pipeline every step: the line shifts (the charge maturing
+                // now goes to the soma, if any), then the one current the time-step buffer kept is added with the delay
+                // of the unit's synapse address 0 and matures delay + 1 steps later (src/models.cpp:96-131)
+                has_in = in_valid != 0;
+                cur = has_in ? in_value : 0.0;
+                if (has_in)
+                {
+                    p_ring[lane] = 0.0;
+                    p_rvalid[lane] = 0;
+                }
+                const uint32_t last = st.ring_last[c0 + lane];
+                if (last != 0u)
+                {
+                    const uint32_t cr = (core != 0xffffffffu) ? core : im.wg_desc[wg].core;
+                    const unsigned long long pos = im.core_syn_base[cr] + (last - 1u);
+                    const double w = (im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
+                                                          : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
+                    const uint32_t row = (uint32_t) ((t + 1 + (long long) im.slot_aux[c0 + lane]) % im.ring_slots);
+                    const size_t at = (size_t) row * im.n_slots + c0 + lane;
+                    st.ring[at] = (st.ring_valid[at] ? st.ring[at] : 0.0) + w;
+                    st.ring_valid[at] = 1;
+                    st.ring_last[c0 + lane] = 0u;
+                }
+            }
             else if (inkind == SANAFE_IN_LAST)
             {
                 // the accumulator integrates the one current the time-step buffer kept, after its lazy clear
@@ -715,7 +741,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     uint8_t *touched = deliver_lds + (size_t) im.delay_slots * (im.max_core_slots + 1u) * sizeof(double); // [D][RS]
     uint32_t *w_beg = s_beg[wave], *w_pref = s_pref[wave];
     const uint32_t core_inkind = sd.inkind;  // the buffer position belongs to the core
-    const bool last_mode = LAST && core_inkind == SANAFE_IN_LAST; // workgroup-uniform
+    const bool last_mode = LAST && (core_inkind == SANAFE_IN_LAST || core_inkind == SANAFE_IN_LAST_DELAY); // workgroup-uniform
 
     uint32_t *lastv = reinterpret_cast<uint32_t *>(deliver_lds);                          // [npad + 1] in last_mode
 

@@ -827,11 +827,17 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         if (du.model == M_TAPS) kind = SANAFE_IN_TAPS, neuron_dend_kind[gid] = 3, any_taps = true;
         if (du.model == M_ACC_DELAY)
         {
-            if (bp == SANAFE_BUF_BEFORE_DENDRITE)
-                throw UnsupportedError("accumulator_with_delay with the buffer before the dendrite unit is not implemented");
             if (bp == SANAFE_BUF_BEFORE_SOMA) kind = SANAFE_IN_GATED, any_gated_delay = true;
             any_delay_dendrite = true;
             neuron_dend_kind[gid] = 2;
+            if (bp == SANAFE_BUF_BEFORE_DENDRITE)
+            {
+                // the message pipeline stops after the synapse: delays of the edges never reach the delivery; the unit's
+                // neuron-side call uses the delay of ITS synapse address 0 (filled in below, with the edges)
+                kind = SANAFE_IN_LAST_DELAY;
+                neuron_dend_kind[gid] = 4;
+                any_gated_delay = true; // a current added at step t with delay 5 matures at t + 6: seven ring slots
+            }
         }
         const uint32_t s = mc.slot_of_gid[gid];
         if (su.model == M_TRUENORTH && random_mask_key >= 0)
@@ -850,6 +856,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         // ---- cost class (src/pipeline.hpp:574-714) ----
         sanafe_hip_cost_class cc{};
         const bool host_soma = (su.model == M_PLUGIN);
+        if (host_soma && kind == SANAFE_IN_LAST_DELAY)
+            throw UnsupportedError("plugin somas behind an accumulator_with_delay with the buffer before the dendrite unit");
         if (host_soma && (su.syn || su.dend))
             throw UnsupportedError("plugin unit '" + su.name + "': only soma plugins are implemented on the MI355X backend");
         // a plugin may simulate its own energy/latency instead of using architecture defaults
@@ -1151,7 +1159,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     throw UnsupportedError("several neurons receive synapses through one `taps` dendrite unit (they would share its RC "
                                            "line): not implemented on the MI355X backend");
             }
-            if (neuron_dend_kind[dst] == 2)
+            if (neuron_dend_kind[dst] == 2 || neuron_dend_kind[dst] == 4)
             {
                 auto &tab = delays[{c, dend_unit[dst]}];
                 if (tab.size() <= addr) tab.resize(addr + 1, 0); // every forwarded attribute resizes (weight included)
@@ -1168,6 +1176,15 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 if (tab.size() <= addr) tab.resize(addr + 1, 0);
                 tab[addr] = static_cast<uint8_t>(edge_attr - 64);
             }
+        }
+        // SANAFE_IN_LAST_DELAY: the delay the unit's synapse address 0 carries
+        for (int64_t gid = 0; gid < N; gid++)
+        {
+            if (neuron_dend_kind[gid] != 4) continue;
+            const uint32_t sl = mc.slot_of_gid[gid];
+            if (sl < SO || sl >= SO + LS) continue;
+            const auto it = delays.find({static_cast<uint32_t>(d.neuron_core[gid]), dend_unit[gid]});
+            mc.slot_aux[sl - SO] = (it != delays.end() && !it->second.empty()) ? it->second[0] : 0u;
         }
         edge_delay_eff.assign(E, 0);
         for (int64_t e = 0; e < E; e++)

@@ -590,3 +590,15 @@ def test_uniform_and_table_driven_neuron_kernels_agree(S, monkeypatch, which):
         assert np.array_equal(ra[k], rb[k]), k
     assert np.array_equal(chip_g.potentials(), chip_u2.potentials())
     assert np.array_equal(chip_g.potentials(), orc.potentials())
+
+
+@pytest.mark.parametrize("delays", [False, True])
+def test_delay_line_behind_buffer_before_dendrite(S, delays):
+    """`accumulator_with_delay` with `buffer_position: dendrite` (outside the unit): the message pipeline stops after the
+    synapse, the kernel's buffer keeps the LAST event's current, and the unit's neuron-side call -- every step, without
+    a synapse address -- integrates it with the delay of the unit's synapse address 0 (src/models.cpp:96-131,
+    src/pipeline.hpp:460-508)."""
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=80, out_degree=20, arch_kind="before_dendrite",
+                                  dendrite="loihi_dendrites_delay", delays=delays, p_fire=0.2, seed=23)
+    chip, orc = check_stepwise(S, arch, net, steps=30)
+    assert chip.run(0, "simple")["neurons_fired"] == 0
