@@ -224,9 +224,12 @@ int sanafe_hip_read_step_state(sanafe_hip_chip *chip, int64_t first, int64_t cou
 int sanafe_hip_write_ext(sanafe_hip_chip *chip, int64_t n_steps, const int32_t *values);
 int sanafe_hip_synchronize(sanafe_hip_chip *chip);
 /* How the image was packed for the device (diagnostics, tests): synapse format 0 = 4 bytes (axon code, accumulator
- * index, int8 weight), 3 = 4 bytes (12-bit integer weight), 4 = 4 + 8 bytes (fp64 weight) -- the streamable layouts --
- * or the gather-only fall-backs 1 = 4 bytes (12-bit weight), 2 = 4 + 8 bytes for cores with too many accumulators;
- * number of delivery slices whose axon records use the 2-byte delta form instead of the 8-byte form. */
+ * index, int8 weight), 3 = 4 bytes (12-bit integer weight), 4 = 4 + 8 bytes (fp64 weight), 6 = 2 bytes (first-synapse
+ * bit, 5-bit code into a dictionary of the chip's <= 32 distinct weights, 10-bit accumulator index), 7 = the words of
+ * 6 for a dictionary of integers, summed in 32-bit integer accumulators -- the streamable layouts -- or the gather-only
+ * fall-backs 1 = 4 bytes (12-bit weight), 2 = 4 + 8 bytes for cores with too many accumulators; number of delivery
+ * slices whose axon records use the 2-byte delta form instead of the 8-byte form.  The environment variable
+ * SANAFE_SYN_FORMAT (0, 1, 2, 3, 4, 6) picks a wider layout than the default where the image allows it (tests). */
 int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_compact_slices);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.

@@ -88,6 +88,8 @@ struct sanafe_hip_chip
     std::vector<uint32_t> h_core_wg_beg, h_core_slice_beg; // host copies for sanafe_hip_read_core_delays
     std::vector<double> h_core_out_lat;
     uint64_t layout_bytes[SANAFE_HIP_LAYOUT_FIELDS]{};
+    std::vector<double> weight_lut; // formats 6, 7: the chip's distinct weight values (<= 32)
+    int acc_shift{0};               // format 7: see DevImage
     // state log (record bit 3): potentials / input currents of listed slots, one row per recorded step
     uint32_t *d_log_slots_v{nullptr}, *d_log_slots_u{nullptr};
     uint32_t n_log_v{0}, n_log_u{0};
@@ -487,18 +489,117 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (weights == 0) fmt = n_acc <= 32768ull ? 0 : 1;
         else if (weights == 1) fmt = n_acc <= 4096ull ? 3 : 1;
         else fmt = n_acc <= 32768ull ? 4 : 2;
+        // format 6 (2-byte words, dictionary-coded weights): at most 32 distinct weight values on the chip, none of them
+        // -0.0 (the untouched-accumulator sentinel), at most 1024 accumulators per core
+        bool dict_ok = n_acc <= 1024ull && h.n_synapses > 0;
+        if (dict_ok) // the words carry no axon code: every axon must own at least one of them
+        {
+            std::atomic<bool> empty_axon{false};
+            parallel_for(h.n_axons, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t a = lo; a < hi; a++)
+                    if (h.ax_nsyn[a] == 0) empty_axon = true;
+            });
+            dict_ok = !empty_axon.load();
+        }
+        if (dict_ok)
+        {
+            std::mutex lut_mutex;
+            std::vector<double> lut;
+            std::atomic<bool> too_many{false};
+            parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
+                std::vector<double> local;
+                for (uint64_t k = lo; k < hi && !too_many.load(std::memory_order_relaxed); k++)
+                {
+                    const double w = h.syn_weight[k];
+                    bool known = false;
+                    for (double v : local) known = known || (std::memcmp(&v, &w, sizeof w) == 0);
+                    if (!known)
+                    {
+                        local.push_back(w);
+                        if (local.size() > 32) too_many = true;
+                    }
+                }
+                std::lock_guard<std::mutex> lock(lut_mutex);
+                for (double w : local)
+                {
+                    bool known = false;
+                    for (double v : lut) known = known || (std::memcmp(&v, &w, sizeof w) == 0);
+                    if (!known) lut.push_back(w);
+                }
+                if (lut.size() > 32) too_many = true;
+            });
+            dict_ok = !too_many.load();
+            for (double w : lut) dict_ok = dict_ok && !(w == 0.0 && std::signbit(w));
+            if (dict_ok)
+            {
+                std::sort(lut.begin(), lut.end()); // thread-count independent codes
+                lut.resize(32, 0.0);
+                c->weight_lut = lut;
+            }
+        }
+        // format 7 (integer accumulators): a dictionary of integers, and per slice and accumulator the bounds that
+        // keep "events * 2^shift + sum of weights" decodable (see DevImage)
+        bool int_ok = dict_ok;
+        if (int_ok)
+            for (double w : c->weight_lut) int_ok = int_ok && std::fabs(w) <= 1048576.0 && w == (double) (long long) w;
+        if (int_ok)
+        {
+            std::atomic<uint64_t> max_count{0}, max_abs{0};
+            parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
+                std::vector<uint32_t> count(n_acc);
+                std::vector<uint64_t> abs_sum(n_acc);
+                uint64_t mc = 0, ma = 0;
+                for (uint64_t sl = lo; sl < hi; sl++)
+                {
+                    const uint32_t core = h.slice_core[sl];
+                    const uint32_t row = ((h.core_ncount[core] + 63u) & ~63u) + 1u;
+                    std::fill(count.begin(), count.end(), 0u);
+                    std::fill(abs_sum.begin(), abs_sum.end(), 0ull);
+                    for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl]; a++)
+                    {
+                        const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
+                        for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
+                        {
+                            const uint32_t m = h.syn_meta[src + k];
+                            if ((m >> 19) & 1u) continue; // lost charge: the trash entry may wrap
+                            const uint32_t idx = ((m >> 16) & 7u) * row + (m & 0xffffu);
+                            count[idx]++;
+                            abs_sum[idx] += (uint64_t) std::fabs(h.syn_weight[src + k]);
+                        }
+                    }
+                    for (uint64_t q = 0; q < n_acc; q++) mc = std::max<uint64_t>(mc, count[q]), ma = std::max(ma, abs_sum[q]);
+                }
+                uint64_t seen = max_count.load();
+                while (seen < mc && !max_count.compare_exchange_weak(seen, mc)) {}
+                seen = max_abs.load();
+                while (seen < ma && !max_abs.compare_exchange_weak(seen, ma)) {}
+            });
+            int shift = 1;
+            while ((1ull << (shift - 1)) <= max_abs.load() && shift < 32) shift++;
+            int_ok = shift <= 15 && ((max_count.load() + 1ull) << shift) <= (1ull << 32); // weight + 2^shift: 16 bits in the kernel's table
+            c->acc_shift = int_ok ? shift : 0;
+        }
+        const int plain = fmt;
+        // integer dictionary: 7.  Other dictionaries: 6 beats the 12-byte fp64 layouts; integers that fail the bounds
+        // of 7 keep their 4-byte streamable form when they have one (fp64 LDS adds bound both, 4 bytes has less ALU work).
+        if (int_ok) fmt = 7;
+        else if (dict_ok && !(plain == 0 || plain == 3)) fmt = 6;
         if (h.n_synapses == 0) fmt = 2;
         if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // tests / experiments: 1 or 2 force the gather-only
-        {                                                       // layouts, 3 / 4 the wider streamable ones
+        {                                                       // layouts, 0 / 3 / 4 the wider streamable ones
             const int want = std::atoi(env);
-            if (want == 1) fmt = weights <= 1 ? 1 : 2;
+            if (want == 0) fmt = plain; // no dictionary coding
+            else if (want == 6 && dict_ok) fmt = 6; // dictionary with fp64 accumulators
+            else if (want == 1) fmt = weights <= 1 ? 1 : 2;
             else if (want == 2) fmt = 2;
             else if (want == 3 && weights <= 1 && n_acc <= 4096ull) fmt = 3;
             else if (want == 4 && n_acc <= 32768ull) fmt = 4;
         }
         c->syn_format = fmt;
     }
-    const bool stream_layout = (c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4);
+    const bool dict16 = (c->syn_format == 6 || c->syn_format == 7); // 2-byte dictionary-coded words
+    const bool stream_layout = (c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4 || dict16);
+    const uint64_t group_words = dict16 ? 8ull : 4ull; // words per 16-byte group
     {
         // ---- axon records: per slice, compact (2 B/axon) when its axons allow it, else wide (8 B/axon) ----
         std::vector<unsigned long long> rec_off(h.n_slices, 0);
@@ -555,7 +656,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 for (uint64_t k = 0; k < nck; k++)
                 {
                     chunk_pos[chunk0[sl] + k] = pos;
-                    pos += (chunk_syn_count(sl, k) + 3ull) & ~3ull;
+                    pos += (chunk_syn_count(sl, k) + group_words - 1ull) / group_words * group_words;
                 }
                 chunk_pos[chunk0[sl] + nck] = pos;
                 if (pos - dev_core_base[core] > 0xffffffffull)
@@ -580,8 +681,15 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<uint8_t> exact(h.n_slices, 0);
         std::vector<uint32_t> meta; // device synapse words (all formats but 2, which keeps the image's arrays)
         std::vector<double> wdev;   // format 4: the fp64 weights at the device positions of their words
-        if (c->syn_format != 2) meta.assign(n_dev_syn + 256, 0u);
+        std::vector<uint16_t> meta16; // formats 6, 7: 2-byte words
+        if (dict16) meta16.assign(n_dev_syn + 512, 0);
+        else if (c->syn_format != 2) meta.assign(n_dev_syn + 256, 0u);
         if (c->syn_format == 4) wdev.assign(n_dev_syn + 256, 0.0);
+        auto lut_code = [&](double w) {
+            for (uint32_t q = 0; q < 32; q++)
+                if (std::memcmp(&c->weight_lut[q], &w, sizeof w) == 0) return q;
+            return 0u;
+        };
         parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t sl = lo; sl < hi; sl++)
             {
@@ -594,7 +702,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 if (stream_layout) // padding words of every chunk: weight 0 into the trash entry
                     for (uint64_t k = 0; k < nck; k++)
                         for (uint64_t q = chunk_pos[chunk0[sl] + k] + chunk_syn_count((uint32_t) sl, k); q < chunk_pos[chunk0[sl] + k + 1]; q++)
-                            meta[q] = trash_post << 8; // code 0, weight 0: adds nothing wherever it lands
+                        {
+                            if (dict16) meta16[q] = (uint16_t) (trash_post << 6); // no first-synapse bit, trash entry
+                            else meta[q] = trash_post << 8; // code 0, weight 0: adds nothing wherever it lands
+                        }
                 for (uint64_t a = b0; a < e0; a++)
                 {
                     const uint64_t rel = a - b0;
@@ -627,7 +738,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                         {
                             const bool drop = (m >> 19) & 1u;
                             const uint32_t idx = drop ? trash_post : ((m >> 16) & 7u) * (trash_post + 1u) + (m & 0xffffu);
-                            if (c->syn_format == 0) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
+                            if (dict16)
+                                meta16[dpos + k] = (uint16_t) ((idx << 6) | (lut_code(h.syn_weight[src + k]) << 1) | (k == 0 ? 1u : 0u));
+                            else if (c->syn_format == 0) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
                             else if (c->syn_format == 3) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xfff) << 20);
                             else
                             {
@@ -693,17 +806,25 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
         for (uint8_t m : mode) c->n_compact_slices += m;
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
-        c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : 4ull);
+        c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : dict16 ? 2ull : 4ull);
         c->layout_bytes[1] = n_bytes;
         c->layout_bytes[2] = n_chunks * 8ull;
         c->layout_bytes[3] = (uint64_t) h.n_slices * sizeof(SliceDesc);
         c->layout_bytes[4] = h.n_global_slots / 8;
         im.syn_meta = nullptr;
+        im.weight_lut = nullptr;
         im.syn_weight = nullptr;
         if (c->syn_format == 2)
         {
             TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
             TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
+        }
+        else if (dict16)
+        {
+            const uint16_t *d16 = nullptr;
+            TRYC(upload(c, meta16.data(), meta16.size(), &d16));
+            im.syn_meta = reinterpret_cast<const uint32_t *>(d16);
+            TRYC(upload(c, c->weight_lut.data(), c->weight_lut.size(), &im.weight_lut));
         }
         else
         {
@@ -807,6 +928,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     c->deliver_lds = (size_t) im.delay_slots * (max_pad + 1) * (sizeof(double) + 1);
     c->has_delay = im.delay_slots > 1 || c->force_delay_variant;
     im.syn_format = c->syn_format;
+    im.acc_shift = c->acc_shift;
     if (im.has_last && c->has_delay)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "cores with the buffer before the dendrite unit cannot be mixed with synaptic delays"));
     if (c->deliver_lds + 9 * 1024 > 160 * 1024)
@@ -819,6 +941,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     SANAFE_SET_LDS_LAST(2);
     SANAFE_SET_LDS_LAST(3);
     SANAFE_SET_LDS_LAST(4);
+    SANAFE_SET_LDS_LAST(6);
 #undef SANAFE_SET_LDS_LAST
     SANAFE_SET_LDS(0, true);
     SANAFE_SET_LDS(0, false);
@@ -830,6 +953,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     SANAFE_SET_LDS(3, false);
     SANAFE_SET_LDS(4, true);
     SANAFE_SET_LDS(4, false);
+    SANAFE_SET_LDS(6, true);
+    SANAFE_SET_LDS(6, false);
 #undef SANAFE_SET_LDS
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -996,6 +1121,8 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
         case 1: SANAFE_LAUNCH_FORMAT(1); break;
         case 3: SANAFE_LAUNCH_FORMAT(3); break;
         case 4: SANAFE_LAUNCH_FORMAT(4); break;
+        case 6: SANAFE_LAUNCH_FORMAT(6); break;
+        case 7: SANAFE_LAUNCH_FORMAT(7); break;
         default: SANAFE_LAUNCH_FORMAT(2); break;
         }
 #undef SANAFE_LAUNCH_FORMAT

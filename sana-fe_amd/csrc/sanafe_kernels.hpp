@@ -111,10 +111,23 @@ struct DevImage
     //   3: 4 bytes      axon code (8b) | accumulator index (12b) << 8 | 12-bit signed weight << 20: the streamable
     //                   form of 1, for chips whose cores need at most 4096 accumulators
     //   4: 4 + 8 bytes  axon code (8b) | accumulator index (15b) << 8, syn_weight = fp64: the streamable form of 2
-    // Formats 0, 3 and 4 give every 256-axon chunk a 16-byte aligned, padded run of words (stream layout).
+    //   6: 2 bytes      first synapse of its axon (1b) | weight code (5b) << 1 | accumulator index (10b) << 6:
+    //                   dictionary-coded weights (weight_lut, at most 32 distinct values on the chip) for cores with at
+    //                   most 1024 accumulators.  No axon code: the words of a chunk are in axon order, so a word's axon
+    //                   is the number of "first synapse" bits up to it (a per-lane popcount + one wave prefix sum per
+    //                   16 bytes = 8 words).  Half the bytes of format 0 on the networks the benchmark recipe builds.
+    //   7: 2 bytes      the words of 6 for dictionaries of INTEGERS: the LDS accumulators are 32-bit integers (an LDS
+    //                   integer add costs a third of an fp64 one, profiles/micro/lds_ops.hip) and the sum of integers is
+    //                   exact in any order, so the result equals the fp64 sum bit for bit.  Every event adds
+    //                   weight + 2^acc_shift: a touched accumulator is never 0 (the buffer "holds a value, even a zero
+    //                   one") and count and sum separate again at write-back; the host proves per slice and accumulator
+    //                   that |sum| < 2^(acc_shift-1) and (count + 1) * 2^acc_shift <= 2^32 before it picks this format.
+    // Formats 0, 3, 4, 6 and 7 give every 256-axon chunk a 16-byte aligned, padded run of words (stream layout).
     const uint32_t *syn_meta;     // padded by 256 words so the streaming loads may run past the end
     const double *syn_weight;
-    int syn_format;               // 0 .. 4 as above
+    const double *weight_lut;     // [32] formats 6, 7: the chip's distinct weight values
+    int syn_format;               // 0 .. 4, 6, 7 as above
+    int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
 };
 
@@ -210,6 +223,14 @@ __device__ __forceinline__ int cvt_int_x86(double x)
 {
     if (!(x > -2147483649.0 && x < 2147483648.0)) return (int) 0x80000000;
     return (int) x;
+}
+
+// Weight of the synapse at position `pos` of the device layout, whatever the format (slow paths only).
+__device__ __forceinline__ double synapse_weight_at(const DevImage &im, unsigned long long pos)
+{
+    if (im.syn_format == 2 || im.syn_format == 4) return im.syn_weight[pos];
+    if (im.syn_format == 6 || im.syn_format == 7) return im.weight_lut[(reinterpret_cast<const uint16_t *>(im.syn_meta)[pos] >> 1) & 31u];
+    return (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
 }
 
 __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group);
@@ -389,8 +410,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 {
                     const uint32_t cr = (core != 0xffffffffu) ? core : im.wg_desc[wg].core;
                     const unsigned long long pos = im.core_syn_base[cr] + (last - 1u);
-                    const double w = (im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
-                                                          : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
+                    const double w = synapse_weight_at(im, pos);
                     const uint32_t row = (uint32_t) ((t + 1 + (long long) im.slot_aux[c0 + lane]) % im.ring_slots);
                     const size_t at = (size_t) row * im.n_slots + c0 + lane;
                     st.ring[at] = (st.ring_valid[at] ? st.ring[at] : 0.0) + w;
@@ -409,8 +429,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 {
                     const uint32_t cr = (core != 0xffffffffu) ? core : im.wg_desc[wg].core;
                     const unsigned long long pos = im.core_syn_base[cr] + (last - 1u);
-                    const double w = (im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
-                                                          : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
+                    const double w = synapse_weight_at(im, pos);
                     cur = 0.0 + w;
                     st.ring_last[c0 + lane] = 0u;
                 }
@@ -654,7 +673,10 @@ constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bit
 #define SANAFE_DELIVER_WAVES_PER_EU 5
 #endif
 constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
-constexpr uint32_t STREAM_MIN_ACTIVE_LANES = 8; // lanes (4 axons each) with a spiking axon from which streaming a chunk beats gathering
+#ifndef SANAFE_STREAM_MIN_ACTIVE_LANES
+#define SANAFE_STREAM_MIN_ACTIVE_LANES 8
+#endif
+constexpr uint32_t STREAM_MIN_ACTIVE_LANES = SANAFE_STREAM_MIN_ACTIVE_LANES; // lanes (4 axons each) with a spiking axon from which streaming a chunk beats gathering
 constexpr unsigned long long ACC_UNTOUCHED = 0x8000000000000000ull; // -0.0: no sum of additions yields it
 
 // Inclusive prefix sum over the 64 lanes with DPP moves (no LDS round trips): Hillis-Steele inside each
@@ -685,6 +707,9 @@ extern __shared__ __align__(16) unsigned char deliver_lds[];
 // The synapse words are read exactly once per launch: non-temporal loads (global_load_dwordx4 ... nt) keep them from
 // displacing the spike bitmap and the axon records in the caches.
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+// Keeps the stream loads in program order: the scheduler would otherwise reorder independent loads, and the wait
+// for "the oldest group" (vmcnt) would again cover all of them.
+__device__ __forceinline__ void keep_load_order() { asm volatile("" ::: "memory"); }
 __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 {
 #ifdef SANAFE_STREAM_PLAIN_LOADS
@@ -706,8 +731,21 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
     __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
+    constexpr bool DICT16 = (SYN_FMT == 6 || SYN_FMT == 7); // 2-byte words, dictionary-coded weights
+    constexpr bool INT_ACC = (SYN_FMT == 7);                // 32-bit integer accumulators (see DevImage)
+    __shared__ double s_lut[(SYN_FMT == 6) ? 32 : 1];      // format 6: the weight dictionary
+    __shared__ uint16_t s_lut16[INT_ACC ? 32 : 2];         // format 7: weight + 2^acc_shift (acc_shift <= 15)
+    // Formats 6, 7: a wave takes RUN_MAX consecutive chunks, notes which axons spiked in a bit table and streams the
+    // words of all of them in one go (a "run"): the words carry no chunk-relative axon code, so nothing ties the
+    // stream to 256 axons, and the fixed cost of starting a stream is paid once per run.
+    constexpr bool RUNS = DICT16;
+    constexpr uint32_t RUN_MAX = 8;
+    __shared__ uint32_t s_bits[RUNS ? DELIVER_BLOCK / WAVE : 1][RUNS ? RUN_MAX * 8 + 8 : 1]; // bit 32 + a = "axon a of the run spiked"
+    if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
+    if (INT_ACC && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
-    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // a scalar: chunk offsets and bases stay in SGPRs
     // Descriptors are in launch order: slices whose axons all start on this GPU first (delivered while the
     // spike bitmaps of the other GPUs are still being gathered), the rest after them.
     const SliceDesc sd = im.slice_desc[first_slice + blockIdx.x];
@@ -719,7 +757,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const uint32_t D = HAS_DELAY ? im.delay_slots : 1u; // LDS holds one accumulator row per delay value in use
     // Row stride of the accumulators.  Format 0 appends one "trash" entry per row: synapses whose charge is lost
     // (and the padding words) are packed with post == npad, so the stream path needs no test for them.
-    constexpr bool STREAMABLE = (SYN_FMT == 0 || SYN_FMT == 3 || SYN_FMT == 4); // stream layout, index-coded words
+    constexpr bool STREAMABLE = (SYN_FMT == 0 || SYN_FMT == 3 || SYN_FMT == 4 || DICT16); // stream layout, index-coded words
+    constexpr uint32_t GROUP_WORDS = DICT16 ? 8u : 4u; // synapse words in one 16-byte group
     constexpr bool FP_WEIGHTS = (SYN_FMT == 2 || SYN_FMT == 4);
     constexpr int SDEPTH = (SYN_FMT == 4) ? 2 : STREAM_DEPTH; // fp64 weights triple the registers of a group in flight
     const uint32_t RS = STREAMABLE ? npad + 1u : npad;
@@ -734,6 +773,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const uint32_t *chunk_pre0 = im.chunk_pre0 + sd.chunk0;
     const double slice_lat = sd.slice_lat;
     double *acc = reinterpret_cast<double *>(deliver_lds);                                  // [D][npad]
+    uint32_t *acc32 = reinterpret_cast<uint32_t *>(deliver_lds);                            // the same in format 7
     // Which accumulators received a synaptic event (the buffer holds a value, even a zero one: src/chip.cpp:759)?
     // Integer-weight formats start every accumulator at -0.0, which no addition of weights can produce again;
     // fp64 weights (format 2) could be -0.0 themselves and keep a byte per accumulator instead.
@@ -776,36 +816,51 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 #pragma unroll
         for (int k = 0; k < AX_PER_THREAD; k++) r[k] = (a0 + k < n_ax) ? wide[a0 + k] : NONE;
     };
-    // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.  A wave whose
-    // previous chunk streamed ("hot") starts the loads of the next chunk before it knows which axons spiked.
-    bool hot = false;
+    // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.
     uint4 sq[SDEPTH];
     double2 sw[FP_WEIGHTS ? SDEPTH : 1][2]; // the four fp64 weights of each group (format 4)
     const uint4 *st_src = nullptr;
     const double2 *st_wsrc = nullptr;
     uint32_t st_groups = 0, st_pos0 = 0;
     constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
-    uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // axon offset of the chunk inside the slice
+    // Chunk order of a wave: every (DELIVER_BLOCK / WAVE)-th chunk, or with RUNS `run_len` consecutive chunks at a
+    // time (a power of two, small enough that all waves get chunks of a short slice).
+    uint32_t run_len = 1;
+    if (RUNS)
+        while (run_len < RUN_MAX && run_len * (DELIVER_BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
+    auto next_c = [&](uint32_t c) -> uint32_t {
+        if (!RUNS) return c + stride;
+        const uint32_t ci = c / WAVE_CHUNK + 1u;
+        return ((ci & (run_len - 1u)) ? ci : ci + (DELIVER_BLOCK / WAVE - 1u) * run_len) * WAVE_CHUNK;
+    };
+    uint32_t c0 = (uint32_t) wave * run_len * WAVE_CHUNK; // axon offset of the chunk inside the slice
+    // the run being collected (wave-uniform): chunks, 16-byte groups, first synapse (relative to the core), the
+    // chunk that would continue it
+    uint32_t run_n = 0, run_groups = 0, run_pos0 = 0, run_expect = 0;
+    uint32_t *w_bits = s_bits[RUNS ? wave : 0];
     auto stream_preload = [&]() {
         const uint32_t ci = c0 / WAVE_CHUNK;
         const uint32_t s0 = chunk_syn0[ci];
         st_pos0 = s0;
-        st_groups = (chunk_syn0[ci + 1] - s0) >> 2; // chunks are 16-byte aligned and padded (format 0)
-        st_src = reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
+        st_groups = (chunk_syn0[ci + 1] - s0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
+        st_src = DICT16 ? reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + s0))
+                                : reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
         if (SYN_FMT == 4) st_wsrc = reinterpret_cast<const double2 *>(im.syn_weight + (syn_base + s0));
+        // All loads of the stream are unconditional (past the end: the last group again) and issued in one fixed
+        // pattern: only then can the loads in flight be counted, so that a group waits for ITS load
+        // (vmcnt(SDEPTH - 1)) and not for all of them.
 #pragma unroll
         for (int u = 0; u < SDEPTH; u++)
         {
-            const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
-            if (g < st_groups)
+            const uint32_t g_u = (uint32_t) lane + (uint32_t) u * WAVE;
+            const uint32_t g = g_u < st_groups ? g_u : st_groups - 1u; // streamed chunks hold synapses
+            sq[u] = load_stream16(st_src + g);
+            if (SYN_FMT == 4)
             {
-                sq[u] = load_stream16(st_src + g);
-                if (SYN_FMT == 4)
-                {
-                    sw[u][0] = st_wsrc[2 * g];
-                    sw[u][1] = st_wsrc[2 * g + 1];
-                }
+                sw[u][0] = st_wsrc[2 * g];
+                sw[u][1] = st_wsrc[2 * g + 1];
             }
+            keep_load_order();
         }
     };
     // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
@@ -857,7 +912,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     {
         load4(c0 + (uint32_t) lane * AX_PER_THREAD, cur);
         decode_and_probe(c0);
-        if (c0 + stride < n_ax) load4(c0 + stride + (uint32_t) lane * AX_PER_THREAD, cur);
+        if (next_c(c0) < n_ax) load4(next_c(c0) + (uint32_t) lane * AX_PER_THREAD, cur);
     }
     // The accumulators are cleared while the first records and bitmap words are in flight.
     for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
@@ -865,6 +920,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (LAST && last_mode)
         {
             reinterpret_cast<unsigned long long *>(acc)[i] = 0ull; // two `lastv` entries
+        }
+        else if (INT_ACC)
+        {
+            acc32[i] = 0u;
         }
         else if (TOUCH_BYTES)
         {
@@ -877,43 +936,196 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         }
     }
     __syncthreads();
-    for (; c0 < n_ax; c0 += stride)
+    for (;; c0 = next_c(c0))
     {
-        if (STREAMABLE && hot) stream_preload();
         // ---- this chunk: take over what the previous iteration decoded and probed ----
         const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
         uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
+        bool dense = false; // wave-uniform: enough spiking axons to stream the chunk
+        if (c0 < n_ax)
+        {
 #pragma unroll
-        for (int k = 0; k < AX_PER_THREAD; k++)
-        {
-            nsyn[k] = nx_nsyn[k];
-            lcls[k] = nx_lcls[k];
-            amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
-        }
-        // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
-        if (c0 + stride < n_ax)
-        {
-            decode_and_probe(c0 + stride);
-            if (c0 + 2 * stride < n_ax) load4(a0 + 2 * stride, cur);
-        }
-        if (__ballot(amask != 0) == 0ull)
-        {
-            hot = false;
-            continue; // wave-uniform
-        }
-        if (STREAMABLE && compact)
-        {
-            // ---- STREAM: with many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
-            //      so read them all once, in order (16 bytes per lane), and let each word say whether its axon
-            //      spiked: no compaction, no ownership search, no per-event address arithmetic. ----
-            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
-            if (n_act_lanes >= STREAM_MIN_ACTIVE_LANES)
+            for (int k = 0; k < AX_PER_THREAD; k++)
             {
+                nsyn[k] = nx_nsyn[k];
+                lcls[k] = nx_lcls[k];
+                amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
+            }
+            // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
+            const uint32_t c1 = next_c(c0);
+            if (c1 < n_ax)
+            {
+                decode_and_probe(c1);
+                const uint32_t c2 = next_c(c1);
+                if (c2 < n_ax) load4(c2 + (uint32_t) lane * AX_PER_THREAD, cur);
+            }
+            // STREAM or GATHER?  With many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
+            // so read them all once, in order (16 bytes per lane), and let each word say whether its axon
+            // spiked: no compaction, no ownership search, no per-event address arithmetic.
+            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
+            dense = STREAMABLE && compact && n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
+        }
+        if constexpr (RUNS)
+        {
+            // ---- the run ends here (a chunk that is not streamed, a chunk elsewhere in the slice, the end of the
+            //      slice): stream its words.  The only place the stream loop is instantiated. ----
+            if (run_n > 0 && (!dense || c0 != run_expect || run_n == RUN_MAX))
+            {
+                const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0));
+                // The first SDEPTH groups of every lane.  All loads of the stream are unconditional (past the end: the last
+                // group again) and issued in one fixed pattern: only then can the loads in flight be counted, so that a
+                // group waits for ITS load (vmcnt(SDEPTH - 1)) and not for all of them.
+#pragma unroll
+                for (int u = 0; u < SDEPTH; u++)
+                {
+                    const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
+                    sq[u] = load_stream16(src + (g < run_groups ? g : run_groups - 1u));
+                    keep_load_order();
+                }
+                // 8 words per lane and group.  A word's axon = (first-synapse bits of the run up to and including it) - 1:
+                // per group the lanes count their bits, one DPP prefix sum orders the lanes, a scalar carries the count
+                // from group to group.  The eight axons of a lane are consecutive, so ONE 32-bit window of the bit
+                // table (two dwords, funnel-shifted) answers "spiked?" for all eight words.
+                uint32_t before = 0; // first-synapse bits of the run before the current group-instruction (wave-uniform)
+                // LDS address of the accumulators, hidden from constant folding: the compiler then forms
+                // base + (index << 2) in one instruction instead of rebuilding it from shifted masks
+                typedef __attribute__((address_space(3))) uint32_t lds_u32;
+                uint32_t acc_base = (uint32_t) (uintptr_t) (lds_u32 *) acc32;
+                asm volatile("" : "+v"(acc_base));
+                auto add8 = [&](const uint4 &q, uint32_t pos0, bool live) {
+                    const uint32_t d4[4] = {q.x, q.y, q.z, q.w};
+                    // first-synapse bits up to and including word 1, 3, 5, 7 of the lane: one chained popcount each
+                    uint32_t upto[4];
+                    upto[0] = (uint32_t) __popc(d4[0] & 0x00010001u);
+                    upto[1] = upto[0] + (uint32_t) __popc(d4[1] & 0x00010001u);
+                    upto[2] = upto[1] + (uint32_t) __popc(d4[2] & 0x00010001u);
+                    upto[3] = upto[2] + (uint32_t) __popc(d4[3] & 0x00010001u);
+                    const uint32_t mine = upto[3];
+                    const uint32_t incl = wave_inclusive_scan(mine);
+                    const uint32_t t = 31u + before + incl - mine; // table bit of the axon before this lane's first first-synapse bit
+                    before += (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
+                    // the window, bit-reversed: "axon spiked" becomes a sign test after one shift
+                    const uint32_t winr = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w_bits[(t >> 5) + 1u], w_bits[t >> 5], t & 31u));
+                    bool fired[8];
+                    uint32_t x = winr;
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        fired[2 * j] = (int) (x << (d4[j] & 1u)) < 0;   // axon of the even word: one further if it starts one
+                        x = winr << upto[j];
+                        fired[2 * j + 1] = (int) x < 0;
+                    }
+                    if constexpr (INT_ACC)
+                    {
+                        uint32_t wv[8]; // all eight dictionary reads in flight together
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                        {
+                            wv[2 * j] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + (d4[j] & 0x3eu));
+                            wv[2 * j + 1] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + ((d4[j] >> 16) & 0x3eu));
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(wv[k])); // keeps the zero-extension in the load (ds_read_u16), not an AND per use
+                        if (live)
+                        {
+#pragma unroll
+                            for (int k = 0; k < 8; k++)
+                                if (fired[k])
+                                {
+                                    // (LDS byte address = opaque base + 4 * index: a bit-field extract and one shift-add)
+                                    uint32_t idx = __builtin_amdgcn_ubfe(d4[k >> 1], (k & 1) ? 22u : 6u, 10u);
+                                    asm("" : "+v"(idx)); // (or the shift is folded back into the extract: three instructions)
+                                    lds_u32 *slot = reinterpret_cast<lds_u32 *>(acc_base + (idx << 2));
+                                    if (LAST && last_mode) __hip_atomic_fetch_max(slot, pos0 + (uint32_t) k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                    else __hip_atomic_fetch_add(slot, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_u32 (lost charge lands in the trash entry)
+                                }
+                        }
+                    }
+                    else
+                    {
+#pragma unroll
+                        for (int h = 0; h < 8; h += 4)
+                        {
+                            double wv[4];
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                wv[k] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(s_lut) + (((d4[(h + k) >> 1] >> ((k & 1) ? 16 : 0)) & 0x3eu) << 2));
+#pragma unroll
+                            for (int k = 0; k < 4; k++)
+                                if (live && fired[h + k])
+                                {
+                                    const uint32_t idx = __builtin_amdgcn_ubfe(d4[(h + k) >> 1], (k & 1) ? 22u : 6u, 10u);
+                                    if (LAST && last_mode) atomicMax(&lastv[idx], pos0 + (uint32_t) (h + k) + 1u);
+                                    else atomicAdd(&acc[idx], wv[k]); // ds_add_f64 (lost charge lands in the trash entry)
+                                }
+                        }
+                    }
+                };
+                // Lanes past the end of the run keep whatever their registers hold: they are the highest lanes of the last
+                // group-row, so their first-synapse counts reach no live lane, and `live` keeps them from adding.
+                const int lane_groups = (int) run_groups - lane; // this lane has group (row + lane) while row < lane_groups
+                for (uint32_t row = 0; row < run_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
+                {
+#pragma unroll
+                    for (int u = 0; u < SDEPTH; u++)
+                    {
+                        const uint32_t r = row + (uint32_t) u * WAVE;
+                        if (r < run_groups) add8(sq[u], run_pos0 + 8u * (r + (uint32_t) lane), (int) r < lane_groups);
+                        // The refill is unconditional (past the end: the last group again): with a load behind a branch
+                        // the compiler cannot count the loads in flight and waits for ALL of them before every group,
+                        // which leaves one group per wave in flight instead of SDEPTH.
+                        const uint32_t nxt = r + (uint32_t) SDEPTH * WAVE + (uint32_t) lane;
+                        sq[u] = load_stream16(src + (nxt < run_groups ? nxt : run_groups - 1u));
+                        keep_load_order();
+                    }
+                }
+                wave_lds_fence(); // the table is rewritten by the next run
+                run_n = 0;
+            }
+        }
+        if (c0 >= n_ax) break;
+        if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
+        if (dense)
+        {
+            {
+                if constexpr (RUNS)
+                {
+                    // ---- append the chunk to the run.  Eight lanes' masks make one dword of the bit table: three DPP
+                    //      steps inside the rows, no LDS atomics; the dword after the chunk's eight is cleared for the
+                    //      window reads (and overwritten when the next chunk joins). ----
+                    uint32_t m8 = amask;
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
+                    if (lane == 0)
+                    {
+                        w_bits[0] = 0u;
+                        w_bits[9u + 8u * run_n] = 0u;
+                    }
+                    if ((lane & 7) == 0) w_bits[1u + 8u * run_n + ((uint32_t) lane >> 3)] = m8;
+                    wave_lds_fence();
+                    const uint32_t ci = c0 / WAVE_CHUNK;
+                    const uint32_t s0 = chunk_syn0[ci];
+                    const uint32_t groups = (chunk_syn0[ci + 1] - s0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
+                    if (run_n == 0)
+                    {
+                        run_pos0 = s0;
+                        run_groups = 0;
+                    }
+                    run_groups += groups;
+                    run_n++;
+                    run_expect = c0 + WAVE_CHUNK;
+                    // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
+                    // in integers here, priced once at the end of the slice
+#pragma unroll
+                    for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
+                    stream_msgs += (uint32_t) __popc(amask);
+                    continue;
+                }
                 // 256-byte table: byte a = "axon a of the chunk spiked"; lane L owns axons 4L..4L+3 = one dword
                 w_pref[lane] = (amask * 0x00204081u) & 0x01010101u;
                 wave_lds_fence();
-                if (!hot) stream_preload();
-                hot = true;
+                stream_preload();
                 const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
                 auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
                     const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
@@ -937,23 +1149,25 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         }
                 };
                 // rolling window: SDEPTH 16-byte groups per lane in flight while one is added
-                for (uint32_t g = (uint32_t) lane; g < st_groups; g += WAVE * SDEPTH)
+                for (uint32_t row = 0; row < st_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
                 {
 #pragma unroll
                     for (int u = 0; u < SDEPTH; u++)
                     {
                         // add, then refill the same registers (the other groups of the window are still in flight)
-                        if (g + (uint32_t) u * WAVE < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * (g + (uint32_t) u * WAVE));
-                        const uint32_t nxt = g + (uint32_t) (SDEPTH + u) * WAVE;
-                        if (nxt < st_groups)
+                        const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
+                        if (g < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * g);
+                        // unconditional refill (past the end: the last group again), so that the loads in flight can be
+                        // counted and a group waits for its own load only
+                        const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
+                        const uint32_t nxt = nxt_g < st_groups ? nxt_g : st_groups - 1u;
+                        sq[u] = load_stream16(st_src + nxt);
+                        if (SYN_FMT == 4)
                         {
-                            sq[u] = load_stream16(st_src + nxt);
-                            if (SYN_FMT == 4)
-                            {
-                                sw[u][0] = st_wsrc[2 * nxt];
-                                sw[u][1] = st_wsrc[2 * nxt + 1];
-                            }
+                            sw[u][0] = st_wsrc[2 * nxt];
+                            sw[u][1] = st_wsrc[2 * nxt + 1];
                         }
+                        keep_load_order();
                     }
                 }
                 // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
@@ -965,7 +1179,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 continue;
             }
         }
-        hot = false;
         // ---- GATHER: few spiking axons; touch only their synapses ----
         // the chunk's synapses are contiguous: one base + a prefix over ALL its axons' counts
         const uint32_t lane_syn = nsyn[0] + nsyn[1] + nsyn[2] + nsyn[3];
@@ -1033,12 +1246,14 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 uint32_t meta[EXPAND_UNROLL]; // post (16b) | delay << 16 | drop << 19, whatever the stored format
                 uint32_t spos[EXPAND_UNROLL]; // position among the core's synapses (used in last_mode)
                 double wgt[EXPAND_UNROLL];
+                uint32_t wgt32[EXPAND_UNROLL]; // format 7
 #pragma unroll
                 for (int u = 0; u < EXPAND_UNROLL; u++)
                 {
                     const uint32_t tile = e0 + u * WAVE;
                     meta[u] = 1u << 19; // "drop": nothing to add
                     wgt[u] = 0.0;
+                    wgt32[u] = 0u;
                     spos[u] = 0u;
                     if (tile < w_end) // wave-uniform
                     {
@@ -1051,7 +1266,14 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         {
                             spos[u] = (uint32_t) (w_beg[owner] + e);
                             const unsigned long long s = syn_base + spos[u];
-                            if (STREAMABLE)
+                            if (DICT16)
+                            {
+                                const uint32_t m = reinterpret_cast<const uint16_t *>(im.syn_meta)[s];
+                                meta[u] = m >> 6;
+                                if (INT_ACC) wgt32[u] = s_lut16[(m >> 1) & 31u];
+                                else wgt[u] = s_lut[(m >> 1) & 31u];
+                            }
+                            else if (STREAMABLE)
                             {
                                 const uint32_t m = im.syn_meta[s];
                                 meta[u] = (m >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu); // the accumulator index itself (trash entry when the charge is lost)
@@ -1082,7 +1304,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         }
                         const uint32_t idx = STREAMABLE ? meta[u]
                                                             : (HAS_DELAY ? __umul24((meta[u] >> 16) & 7u, RS) : 0u) + (meta[u] & 0xffffu);
-                        atomicAdd(&acc[idx], wgt[u]); // ds_add_f64
+                        if (INT_ACC) atomicAdd(&acc32[idx], wgt32[u]); // ds_add_u32
+                        else atomicAdd(&acc[idx], wgt[u]);           // ds_add_f64
                         if (TOUCH_BYTES) touched[idx] = 1;
                     }
             }
@@ -1113,7 +1336,20 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     else
     for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
     {
-        if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
+        double sum;
+        if (INT_ACC)
+        {
+            // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (checked by the host): 0 = no event arrived
+            const uint32_t v = acc32[i];
+            if (v == 0u) continue;
+            const uint32_t events = (v + (1u << (im.acc_shift - 1))) >> im.acc_shift;
+            sum = (double) (int) (v - (events << im.acc_shift));
+        }
+        else
+        {
+            if (TOUCH_BYTES ? !touched[i] : (reinterpret_cast<const unsigned long long *>(acc)[i] == ACC_UNTOUCHED)) continue;
+            sum = acc[i];
+        }
         const uint32_t d = i / RS, n = i - d * RS;
         if (n >= npad) continue; // trash entry
         // per neuron: a core may mix dendrite units
@@ -1121,7 +1357,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (post_kind == SANAFE_IN_TAPS)
         {
             // row d is tap d of the neuron's dendrite: taps_kernel integrates it after this launch
-            atomicAdd(&st.tap_in[(size_t) im.slot_aux[nbase + n] * 8u + d], acc[i]);
+            atomicAdd(&st.tap_in[(size_t) im.slot_aux[nbase + n] * 8u + d], sum);
             st.arrived[nbase + n] = 1;
             continue;
         }
@@ -1130,9 +1366,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         const size_t gi = (size_t) wslot * im.n_slots + nbase + n;
         // Without synaptic delays all charge for step t+1 arrives in step t and the neuron launch of step t left
         // every consumed entry at 0.0: a core with one slice stores, it need not read.
-        if (shared_core) atomicAdd(&st.ring[gi], acc[i]);
-        else if (!HAS_DELAY) st.ring[gi] = acc[i];
-        else st.ring[gi] += acc[i];
+        if (shared_core) atomicAdd(&st.ring[gi], sum);
+        else if (!HAS_DELAY) st.ring[gi] = sum;
+        else st.ring[gi] += sum;
         st.ring_valid[gi] = 1;
         if (gated) st.arrived[nbase + n] = 1;
     }
@@ -1407,8 +1643,7 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
             uint32_t core = 0; // the slot's core: cores are few, slots of a core contiguous
             while (core + 1 < im.n_cores && im.core_nbase[core + 1] <= g) core++;
             const unsigned long long pos = im.core_syn_base[core] + (last - 1u);
-            c = 0.0 + ((im.syn_format == 2 || im.syn_format == 4) ? im.syn_weight[pos]
-                                                                   : (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20)));
+            c = 0.0 + synapse_weight_at(im, pos);
             st.ring_last[g] = 0u;
         }
         cur[i] = c;

@@ -30,7 +30,9 @@ def test_c3_full_size_properties(S, monkeypatch):
     chip, tot, recs, fired, v = _run(S, arch, net)
     lay, info = chip.device_layout(), chip.info()
     assert info["n_synapses"] == 262144 * OUT_DEGREE
-    assert lay["syn_format"] == 0 and lay["n_compact_slices"] == info["n_slices"]  # the stream path is what runs
+    # 16 distinct integer weights, 513 accumulators per core: 2-byte dictionary-coded words, integer accumulators;
+    # the stream path is what runs
+    assert lay["syn_format"] == 7 and lay["n_compact_slices"] == info["n_slices"]
     for t in range(STEPS):
         n_fired = int(fired[t].sum())
         assert recs["neurons_fired"][t] == n_fired > 0
@@ -43,13 +45,16 @@ def test_c3_full_size_properties(S, monkeypatch):
     assert recs["neurons_fired"][0] < 0.2 * 262144 < recs["neurons_fired"][2]
     del chip
 
-    # the same image through the other delivery code path (12-bit weight words, gather only): identical results
-    monkeypatch.setenv("SANAFE_SYN_FORMAT", "1")
-    chip2, tot2, recs2, fired2, v2 = _run(S, arch, net)
-    assert chip2.device_layout()["syn_format"] == 1
-    assert np.array_equal(fired, fired2)
-    assert np.array_equal(v, v2)                                        # integer weights: exact in any order
-    for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
-        assert np.array_equal(recs[k], recs2[k]), k
-    for k in ("total_energy", "synapse_energy", "soma_energy", "network_energy", "sim_time"):
-        assert np.allclose(recs[k], recs2[k], rtol=1e-12, atol=0), k
+    # the same image through the other delivery code paths -- dictionary words with fp64 accumulators (format 6), 4-byte
+    # int8 words streamed (format 0), 12-bit weight words gathered (format 1): identical results
+    for force, fmt in (("6", 6), ("0", 0), ("1", 1)):
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+        chip2, tot2, recs2, fired2, v2 = _run(S, arch, net)
+        assert chip2.device_layout()["syn_format"] == fmt
+        assert np.array_equal(fired, fired2)
+        assert np.array_equal(v, v2)                                    # integer weights: exact in any order
+        for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
+            assert np.array_equal(recs[k], recs2[k]), k
+        for k in ("total_energy", "synapse_energy", "soma_energy", "network_energy", "sim_time"):
+            assert np.allclose(recs[k], recs2[k], rtol=1e-12, atol=0), k
+        del chip2

@@ -278,6 +278,51 @@ def test_twelve_bit_integer_weights(S, monkeypatch, force, fmt):
     assert chip.device_layout()["syn_format"] == fmt
 
 
+@pytest.mark.parametrize("force,fmt", [(None, 7), ("6", 6), ("0", 0), ("1", 1)])
+def test_small_integer_weights_four_layouts(S, monkeypatch, force, fmt):
+    """Weights in {-8..8}: 2-byte dictionary-coded words with integer accumulators (format 7, the default) or fp64
+    accumulators (format 6), 4-byte int8 words (format 0) and the gather-only 12-bit words (format 1) -- dense cores
+    so that whole chunks stream, half of the neurons firing."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=180, arch_kind="loihi", p_fire=0.5, seed=29)
+    chip, _ = check_stepwise(S, arch, net, steps=12)
+    lay = chip.device_layout()
+    assert lay["syn_format"] == fmt and lay["n_compact_slices"] > 0
+
+
+def test_dictionary_coded_float_weights(S):
+    """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
+    rng = np.random.default_rng(5)
+    table = rng.normal(size=20) * 3.0
+    for blk in net._edge_blocks:  # (src, dst, weight, delay, synapse_hw)
+        blk[2][:] = table[rng.integers(0, 20, size=len(blk[2]))]
+    chip, _ = check_stepwise(S, arch, net, steps=12, exact_v=False)
+    assert chip.device_layout()["syn_format"] == 6
+
+
+def test_integer_accumulators_zero_sums_and_sparse_spikes(S, monkeypatch):
+    """Format 7 keeps "an event arrived" apart from "the sum is zero": weights +-1 cancel often, and the buffer still
+    holds a value (src/chip.cpp:759).  Low firing rate: the gather path adds into the same integer accumulators.
+    A dictionary too wide for the bounds of format 7 (|w| up to 2^20 on dense cores is fine; 2^21 is not integer-coded)
+    falls back to the 4-byte / fp64-accumulator layouts."""
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=37)
+    rng = np.random.default_rng(9)
+    for blk in net._edge_blocks:
+        blk[2][:] = rng.choice([-1.0, 1.0], size=len(blk[2]))
+    chip, _ = check_stepwise(S, arch, net, steps=12)
+    assert chip.device_layout()["syn_format"] == 7
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.02, seed=38)
+    chip, _ = check_stepwise(S, arch, net, steps=12)
+    assert chip.device_layout()["syn_format"] == 7
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=39)
+    for blk in net._edge_blocks:
+        blk[2][:] = rng.choice([-2097152.0, 3.0, 1048576.0], size=len(blk[2]))
+    chip, _ = check_stepwise(S, arch, net, steps=8)
+    assert chip.device_layout()["syn_format"] == 6  # integers, but no int8/int12 form and outside the bounds of 7
+
+
 @pytest.mark.parametrize("weights,fmt", [("int12", 3), ("float", 4)])
 def test_streamed_delay_lines_other_formats(S, weights, fmt):
     """The stream path of formats 3 / 4 with synaptic delays (several accumulator rows) on dense cores."""
@@ -300,7 +345,7 @@ def test_mixed_axon_record_modes(S):
     g.connect_neurons_sparse(g, {"weight": np.ones(300), "delay": rng.integers(0, 6, size=300)}, pairs, narrow_float=False)
     chip, _ = check_stepwise(S, arch, net, steps=12)
     lay, info = chip.device_layout(), chip.info()
-    assert lay["syn_format"] == 0  # 2 + 1 bytes per synapse
+    assert lay["syn_format"] == 0  # 6 delay rows x 513 accumulators: too many for the 2-byte words -> 4-byte int8 words
     assert 0 < lay["n_compact_slices"] < info["n_slices"]
 
 
