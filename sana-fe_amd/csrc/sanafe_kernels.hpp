@@ -826,7 +826,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     // Chunk order of a wave: every (DELIVER_BLOCK / WAVE)-th chunk, or with RUNS `run_len` consecutive chunks at a
     // time (a power of two, small enough that all waves get chunks of a short slice).
     uint32_t run_len = 1;
-    if (RUNS)
+    if (RUNS && compact)
         while (run_len < RUN_MAX && run_len * (DELIVER_BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
     auto next_c = [&](uint32_t c) -> uint32_t {
         if (!RUNS) return c + stride;
@@ -834,9 +834,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         return ((ci & (run_len - 1u)) ? ci : ci + (DELIVER_BLOCK / WAVE - 1u) * run_len) * WAVE_CHUNK;
     };
     uint32_t c0 = (uint32_t) wave * run_len * WAVE_CHUNK; // axon offset of the chunk inside the slice
-    // the run being collected (wave-uniform): chunks, 16-byte groups, first synapse (relative to the core), the
-    // chunk that would continue it
-    uint32_t run_n = 0, run_groups = 0, run_pos0 = 0, run_expect = 0;
     uint32_t *w_bits = s_bits[RUNS ? wave : 0];
     auto stream_preload = [&]() {
         const uint32_t ci = c0 / WAVE_CHUNK;
@@ -908,7 +905,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 #pragma unroll
         for (int k = 0; k < AX_PER_THREAD; k++) nx_word[k] = bits[nx_pre[k] >> 5]; // pad axons read word 0: in bounds
     };
-    if (c0 < n_ax)
+    if (!(RUNS && compact) && c0 < n_ax)
     {
         load4(c0 + (uint32_t) lane * AX_PER_THREAD, cur);
         decode_and_probe(c0);
@@ -936,253 +933,13 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         }
     }
     __syncthreads();
-    for (;; c0 = next_c(c0))
-    {
-        // ---- this chunk: take over what the previous iteration decoded and probed ----
-        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
-        uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
-        bool dense = false; // wave-uniform: enough spiking axons to stream the chunk
-        if (c0 < n_ax)
-        {
-#pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++)
-            {
-                nsyn[k] = nx_nsyn[k];
-                lcls[k] = nx_lcls[k];
-                amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
-            }
-            // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
-            const uint32_t c1 = next_c(c0);
-            if (c1 < n_ax)
-            {
-                decode_and_probe(c1);
-                const uint32_t c2 = next_c(c1);
-                if (c2 < n_ax) load4(c2 + (uint32_t) lane * AX_PER_THREAD, cur);
-            }
-            // STREAM or GATHER?  With many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
-            // so read them all once, in order (16 bytes per lane), and let each word say whether its axon
-            // spiked: no compaction, no ownership search, no per-event address arithmetic.
-            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
-            dense = STREAMABLE && compact && n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
-        }
-        if constexpr (RUNS)
-        {
-            // ---- the run ends here (a chunk that is not streamed, a chunk elsewhere in the slice, the end of the
-            //      slice): stream its words.  The only place the stream loop is instantiated. ----
-            if (run_n > 0 && (!dense || c0 != run_expect || run_n == RUN_MAX))
-            {
-                const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0));
-                // The first SDEPTH groups of every lane.  All loads of the stream are unconditional (past the end: the last
-                // group again) and issued in one fixed pattern: only then can the loads in flight be counted, so that a
-                // group waits for ITS load (vmcnt(SDEPTH - 1)) and not for all of them.
-#pragma unroll
-                for (int u = 0; u < SDEPTH; u++)
-                {
-                    const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
-                    sq[u] = load_stream16(src + (g < run_groups ? g : run_groups - 1u));
-                    keep_load_order();
-                }
-                // 8 words per lane and group.  A word's axon = (first-synapse bits of the run up to and including it) - 1:
-                // per group the lanes count their bits, one DPP prefix sum orders the lanes, a scalar carries the count
-                // from group to group.  The eight axons of a lane are consecutive, so ONE 32-bit window of the bit
-                // table (two dwords, funnel-shifted) answers "spiked?" for all eight words.
-                uint32_t before = 0; // first-synapse bits of the run before the current group-instruction (wave-uniform)
-                // LDS address of the accumulators, hidden from constant folding: the compiler then forms
-                // base + (index << 2) in one instruction instead of rebuilding it from shifted masks
-                typedef __attribute__((address_space(3))) uint32_t lds_u32;
-                uint32_t acc_base = (uint32_t) (uintptr_t) (lds_u32 *) acc32;
-                asm volatile("" : "+v"(acc_base));
-                auto add8 = [&](const uint4 &q, uint32_t pos0, bool live) {
-                    const uint32_t d4[4] = {q.x, q.y, q.z, q.w};
-                    // first-synapse bits up to and including word 1, 3, 5, 7 of the lane: one chained popcount each
-                    uint32_t upto[4];
-                    upto[0] = (uint32_t) __popc(d4[0] & 0x00010001u);
-                    upto[1] = upto[0] + (uint32_t) __popc(d4[1] & 0x00010001u);
-                    upto[2] = upto[1] + (uint32_t) __popc(d4[2] & 0x00010001u);
-                    upto[3] = upto[2] + (uint32_t) __popc(d4[3] & 0x00010001u);
-                    const uint32_t mine = upto[3];
-                    const uint32_t incl = wave_inclusive_scan(mine);
-                    const uint32_t t = 31u + before + incl - mine; // table bit of the axon before this lane's first first-synapse bit
-                    before += (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
-                    // the window, bit-reversed: "axon spiked" becomes a sign test after one shift
-                    const uint32_t winr = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w_bits[(t >> 5) + 1u], w_bits[t >> 5], t & 31u));
-                    bool fired[8];
-                    uint32_t x = winr;
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                    {
-                        fired[2 * j] = (int) (x << (d4[j] & 1u)) < 0;   // axon of the even word: one further if it starts one
-                        x = winr << upto[j];
-                        fired[2 * j + 1] = (int) x < 0;
-                    }
-                    if constexpr (INT_ACC)
-                    {
-                        uint32_t wv[8]; // all eight dictionary reads in flight together
-#pragma unroll
-                        for (int j = 0; j < 4; j++)
-                        {
-                            wv[2 * j] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + (d4[j] & 0x3eu));
-                            wv[2 * j + 1] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + ((d4[j] >> 16) & 0x3eu));
-                        }
-#pragma unroll
-                        for (int k = 0; k < 8; k++) asm volatile("" : "+v"(wv[k])); // keeps the zero-extension in the load (ds_read_u16), not an AND per use
-                        if (live)
-                        {
-#pragma unroll
-                            for (int k = 0; k < 8; k++)
-                                if (fired[k])
-                                {
-                                    // (LDS byte address = opaque base + 4 * index: a bit-field extract and one shift-add)
-                                    uint32_t idx = __builtin_amdgcn_ubfe(d4[k >> 1], (k & 1) ? 22u : 6u, 10u);
-                                    asm("" : "+v"(idx)); // (or the shift is folded back into the extract: three instructions)
-                                    lds_u32 *slot = reinterpret_cast<lds_u32 *>(acc_base + (idx << 2));
-                                    if (LAST && last_mode) __hip_atomic_fetch_max(slot, pos0 + (uint32_t) k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                    else __hip_atomic_fetch_add(slot, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_u32 (lost charge lands in the trash entry)
-                                }
-                        }
-                    }
-                    else
-                    {
-#pragma unroll
-                        for (int h = 0; h < 8; h += 4)
-                        {
-                            double wv[4];
-#pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                wv[k] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(s_lut) + (((d4[(h + k) >> 1] >> ((k & 1) ? 16 : 0)) & 0x3eu) << 2));
-#pragma unroll
-                            for (int k = 0; k < 4; k++)
-                                if (live && fired[h + k])
-                                {
-                                    const uint32_t idx = __builtin_amdgcn_ubfe(d4[(h + k) >> 1], (k & 1) ? 22u : 6u, 10u);
-                                    if (LAST && last_mode) atomicMax(&lastv[idx], pos0 + (uint32_t) (h + k) + 1u);
-                                    else atomicAdd(&acc[idx], wv[k]); // ds_add_f64 (lost charge lands in the trash entry)
-                                }
-                        }
-                    }
-                };
-                // Lanes past the end of the run keep whatever their registers hold: they are the highest lanes of the last
-                // group-row, so their first-synapse counts reach no live lane, and `live` keeps them from adding.
-                const int lane_groups = (int) run_groups - lane; // this lane has group (row + lane) while row < lane_groups
-                for (uint32_t row = 0; row < run_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
-                {
-#pragma unroll
-                    for (int u = 0; u < SDEPTH; u++)
-                    {
-                        const uint32_t r = row + (uint32_t) u * WAVE;
-                        if (r < run_groups) add8(sq[u], run_pos0 + 8u * (r + (uint32_t) lane), (int) r < lane_groups);
-                        // The refill is unconditional (past the end: the last group again): with a load behind a branch
-                        // the compiler cannot count the loads in flight and waits for ALL of them before every group,
-                        // which leaves one group per wave in flight instead of SDEPTH.
-                        const uint32_t nxt = r + (uint32_t) SDEPTH * WAVE + (uint32_t) lane;
-                        sq[u] = load_stream16(src + (nxt < run_groups ? nxt : run_groups - 1u));
-                        keep_load_order();
-                    }
-                }
-                wave_lds_fence(); // the table is rewritten by the next run
-                run_n = 0;
-            }
-        }
-        if (c0 >= n_ax) break;
-        if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
-        if (dense)
-        {
-            {
-                if constexpr (RUNS)
-                {
-                    // ---- append the chunk to the run.  Eight lanes' masks make one dword of the bit table: three DPP
-                    //      steps inside the rows, no LDS atomics; the dword after the chunk's eight is cleared for the
-                    //      window reads (and overwritten when the next chunk joins). ----
-                    uint32_t m8 = amask;
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
-                    if (lane == 0)
-                    {
-                        w_bits[0] = 0u;
-                        w_bits[9u + 8u * run_n] = 0u;
-                    }
-                    if ((lane & 7) == 0) w_bits[1u + 8u * run_n + ((uint32_t) lane >> 3)] = m8;
-                    wave_lds_fence();
-                    const uint32_t ci = c0 / WAVE_CHUNK;
-                    const uint32_t s0 = chunk_syn0[ci];
-                    const uint32_t groups = (chunk_syn0[ci + 1] - s0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
-                    if (run_n == 0)
-                    {
-                        run_pos0 = s0;
-                        run_groups = 0;
-                    }
-                    run_groups += groups;
-                    run_n++;
-                    run_expect = c0 + WAVE_CHUNK;
-                    // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
-                    // in integers here, priced once at the end of the slice
-#pragma unroll
-                    for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
-                    stream_msgs += (uint32_t) __popc(amask);
-                    continue;
-                }
-                // 256-byte table: byte a = "axon a of the chunk spiked"; lane L owns axons 4L..4L+3 = one dword
-                w_pref[lane] = (amask * 0x00204081u) & 0x01010101u;
-                wave_lds_fence();
-                stream_preload();
-                const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
-                auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
-                    const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
-                    const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
-                    uint32_t fired[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0xffu];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (fired[u])
-                        {
-                            const uint32_t idx = (w4[u] >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu);
-                            if (LAST && last_mode)
-                            {
-                                atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
-                                continue;
-                            }
-                            // ds_add_f64 (lost charge lands in the trash entry)
-                            atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
-                            if (TOUCH_BYTES) touched[idx] = 1;
-                        }
-                };
-                // rolling window: SDEPTH 16-byte groups per lane in flight while one is added
-                for (uint32_t row = 0; row < st_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
-                {
-#pragma unroll
-                    for (int u = 0; u < SDEPTH; u++)
-                    {
-                        // add, then refill the same registers (the other groups of the window are still in flight)
-                        const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
-                        if (g < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * g);
-                        // unconditional refill (past the end: the last group again), so that the loads in flight can be
-                        // counted and a group waits for its own load only
-                        const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
-                        const uint32_t nxt = nxt_g < st_groups ? nxt_g : st_groups - 1u;
-                        sq[u] = load_stream16(st_src + nxt);
-                        if (SYN_FMT == 4)
-                        {
-                            sw[u][0] = st_wsrc[2 * nxt];
-                            sw[u][1] = st_wsrc[2 * nxt + 1];
-                        }
-                        keep_load_order();
-                    }
-                }
-                // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
-                // in integers here, priced once at the end of the slice
-#pragma unroll
-                for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
-                stream_msgs += (uint32_t) __popc(amask);
-                wave_lds_fence(); // w_pref is rewritten by the next chunk
-                continue;
-            }
-        }
+    // ---- GATHER: the spiking axons of one chunk (axon offset cg inside the slice; per lane the mask of its 4 axons,
+    //      their synapse counts and latency classes) ----
+    auto gather_chunk = [&](uint32_t cg, uint32_t amask, const uint32_t (&nsyn)[AX_PER_THREAD], const uint32_t (&lcls)[AX_PER_THREAD]) {
         // ---- GATHER: few spiking axons; touch only their synapses ----
         // the chunk's synapses are contiguous: one base + a prefix over ALL its axons' counts
         const uint32_t lane_syn = nsyn[0] + nsyn[1] + nsyn[2] + nsyn[3];
-        uint32_t syn_off = chunk_syn0[c0 / WAVE_CHUNK] + wave_inclusive_scan(lane_syn) - lane_syn;
+        uint32_t syn_off = chunk_syn0[cg / WAVE_CHUNK] + wave_inclusive_scan(lane_syn) - lane_syn;
         // ---- compact the active axons in axon (= reference delivery) order ----
         const uint32_t my_act = (uint32_t) __popc(amask);
         const uint32_t incl_act = wave_inclusive_scan(my_act);
@@ -1205,7 +962,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     j++;
                     my_ev += nsyn[k];
                     if (compact) proc += ain_lat + (double) nsyn[k] * slice_lat;
-                    else proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a_beg + a0 + k];
+                    else proc += (lcls[k] != 255u) ? ain_lat + (double) nsyn[k] * im.lat_class[lcls[k]] : im.ax_proc_delay[a_beg + cg + (uint32_t) lane * AX_PER_THREAD + k];
                 }
                 syn_off += nsyn[k];
             }
@@ -1312,6 +1069,314 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             heads_before = seen;
         }
         wave_lds_fence(); // the lists are rewritten by the next chunk
+    };
+    if (RUNS && compact)
+    {
+        // ================= dictionary formats, compact slices: runs of `run_len` consecutive chunks =================
+        // Phase A, all chunks of the run at once: axon records -> pre slots -> spike-bitmap words -> which axons
+        // spiked.  Every load is unconditional (clamped for chunks and lanes past the end), so the 8 record loads and then
+        // the 32 bitmap probes are in flight together: two exposed memory round trips per run, not two per chunk.
+        // Phase B: the words of the dense chunks of the run, streamed in one go.  Phase C: chunks with few spiking axons
+        // go through the gather path.
+        constexpr uint32_t NW = DELIVER_BLOCK / WAVE;
+        for (uint32_t r0 = (uint32_t) wave * run_len * WAVE_CHUNK; r0 < n_ax; r0 += NW * run_len * WAVE_CHUNK)
+        {
+            const uint32_t ci0 = r0 / WAVE_CHUNK;
+            unsigned long long q[RUN_MAX];
+            uint32_t amask_all = 0;                 // per lane: 4 bits per chunk of the run
+            uint32_t dense_mask = 0, gather_mask = 0; // wave-uniform: chunks to stream / to gather
+#pragma unroll
+            for (uint32_t j = 0; j < RUN_MAX; j++)
+            {
+                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                const bool have = j < run_len && a0 < n_ax; // (records past the end inside the slice's 16-byte padding read as 0)
+                q[j] = *reinterpret_cast<const unsigned long long *>(rec + 2ull * (have ? a0 : 0u));
+                keep_load_order();
+            }
+            // (the bitmap probes in two halves of 16: 32 destination registers at once would spill)
+#pragma unroll
+            for (uint32_t half = 0; half < RUN_MAX; half += RUN_MAX / 2)
+            {
+            if (half >= run_len) continue; // short runs (small slices): nothing in the second half
+            uint32_t word[RUN_MAX / 2][AX_PER_THREAD], shifts[RUN_MAX / 2];
+#pragma unroll
+            for (uint32_t jj = 0; jj < RUN_MAX / 2; jj++)
+            {
+                const uint32_t j = half + jj;
+                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                const bool have = j < run_len && a0 < n_ax;
+                if (!have) q[j] = 0ull;
+                const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
+                const uint32_t dl[AX_PER_THREAD] = {lo & 0xffu, (lo >> 16) & 0xffu, hi & 0xffu, (hi >> 16) & 0xffu};
+                const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+                const bool chunk_here = j < run_len && r0 + j * WAVE_CHUNK < n_ax; // scalar
+                uint32_t pre = chunk_pre0[chunk_here ? ci0 + j : ci0] + wave_inclusive_scan(lane_d) - lane_d;
+                shifts[jj] = 0;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                {
+                    pre += dl[k];
+                    word[jj][k] = bits[pre >> 5]; // pad axons repeat the slot before them: in bounds
+                    shifts[jj] |= (pre & 31u) << (8 * k);
+                }
+                keep_load_order();
+            }
+#pragma unroll
+            for (uint32_t jj = 0; jj < RUN_MAX / 2; jj++)
+            {
+                const uint32_t j = half + jj;
+                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                uint32_t amask = 0;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                    amask |= ((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & ((j < run_len && a0 + k < n_ax) ? 1u : 0u)) << k;
+                const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
+                const bool dense = n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
+                dense_mask |= dense ? (1u << j) : 0u;
+                gather_mask |= (!dense && n_act_lanes > 0) ? (1u << j) : 0u;
+                amask_all |= amask << (4 * j);
+                // Bit table: bit 32 + 256 j + a = "axon a of chunk j spiked" (chunks that are not streamed: zeros).  Eight
+                // lanes' masks make one dword: three DPP steps inside the rows, no LDS atomics.
+                uint32_t m8 = dense ? amask : 0u;
+                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
+                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
+                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
+                if ((lane & 7) == 0) w_bits[1u + 8u * j + ((uint32_t) lane >> 3)] = m8;
+                if (dense)
+                {
+                    // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
+                    // in integers here, priced once at the end of the slice
+                    const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
+                    stream_events += ((amask & 1u) ? (lo >> 8) & 0xffu : 0u) + ((amask & 2u) ? lo >> 24 : 0u) +
+                                     ((amask & 4u) ? (hi >> 8) & 0xffu : 0u) + ((amask & 8u) ? hi >> 24 : 0u);
+                    stream_msgs += (uint32_t) __popc(amask);
+                }
+            }
+            }
+            if (dense_mask != 0u)
+            {
+                // ---- Phase B: stream the words of chunks first_dense .. last_dense ----
+                wave_lds_fence();
+                const uint32_t first_dense = (uint32_t) __builtin_ctz(dense_mask), last_dense = 31u - (uint32_t) __builtin_clz(dense_mask);
+                const uint32_t run_pos0 = chunk_syn0[ci0 + first_dense];
+                const uint32_t run_groups = (chunk_syn0[ci0 + last_dense + 1u] - run_pos0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
+                const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0));
+                // The first SDEPTH groups of every lane.  All loads of the stream are unconditional (past the end: the last
+                // group again) and issued in one fixed pattern: only then can the loads in flight be counted, so that a
+                // group waits for ITS load (vmcnt(SDEPTH - 1)) and not for all of them.
+#pragma unroll
+                for (int u = 0; u < SDEPTH; u++)
+                {
+                    const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
+                    sq[u] = load_stream16(src + (g < run_groups ? g : run_groups - 1u));
+                    keep_load_order();
+                }
+                // 8 words per lane and group.  A word's axon = (first-synapse bits of the run up to and including it) - 1:
+                // per group the lanes count their bits, one DPP prefix sum orders the lanes, a scalar carries the count
+                // from group to group.  The eight axons of a lane are consecutive, so ONE 32-bit window of the bit
+                // table (two dwords, funnel-shifted) answers "spiked?" for all eight words.
+            uint32_t before = first_dense * WAVE_CHUNK; // first-synapse bits of the run before the current group-instruction (wave-uniform)
+            // LDS address of the accumulators, hidden from constant folding: the compiler then forms
+            // base + (index << 2) in one instruction instead of rebuilding it from shifted masks
+            typedef __attribute__((address_space(3))) uint32_t lds_u32;
+            uint32_t acc_base = (uint32_t) (uintptr_t) (lds_u32 *) acc32;
+            asm volatile("" : "+v"(acc_base));
+            auto add8 = [&](const uint4 &q, uint32_t pos0, bool live) {
+                const uint32_t d4[4] = {q.x, q.y, q.z, q.w};
+                // first-synapse bits up to and including word 1, 3, 5, 7 of the lane: one chained popcount each
+                uint32_t upto[4];
+                upto[0] = (uint32_t) __popc(d4[0] & 0x00010001u);
+                upto[1] = upto[0] + (uint32_t) __popc(d4[1] & 0x00010001u);
+                upto[2] = upto[1] + (uint32_t) __popc(d4[2] & 0x00010001u);
+                upto[3] = upto[2] + (uint32_t) __popc(d4[3] & 0x00010001u);
+                const uint32_t mine = upto[3];
+                const uint32_t incl = wave_inclusive_scan(mine);
+                const uint32_t t = 31u + before + incl - mine; // table bit of the axon before this lane's first first-synapse bit
+                before += (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
+                // the window, bit-reversed: "axon spiked" becomes a sign test after one shift
+                const uint32_t winr = __builtin_bitreverse32(__builtin_amdgcn_alignbit(w_bits[(t >> 5) + 1u], w_bits[t >> 5], t & 31u));
+                bool fired[8];
+                uint32_t x = winr;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                {
+                    fired[2 * j] = (int) (x << (d4[j] & 1u)) < 0;   // axon of the even word: one further if it starts one
+                    x = winr << upto[j];
+                    fired[2 * j + 1] = (int) x < 0;
+                }
+                if constexpr (INT_ACC)
+                {
+                    uint32_t wv[8]; // all eight dictionary reads in flight together
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                    {
+                        wv[2 * j] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + (d4[j] & 0x3eu));
+                        wv[2 * j + 1] = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(s_lut16) + ((d4[j] >> 16) & 0x3eu));
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) asm volatile("" : "+v"(wv[k])); // keeps the zero-extension in the load (ds_read_u16), not an AND per use
+                    if (live)
+                    {
+#pragma unroll
+                        for (int k = 0; k < 8; k++)
+                            if (fired[k])
+                            {
+                                // (LDS byte address = opaque base + 4 * index: a bit-field extract and one shift-add)
+                                uint32_t idx = __builtin_amdgcn_ubfe(d4[k >> 1], (k & 1) ? 22u : 6u, 10u);
+                                asm("" : "+v"(idx)); // (or the shift is folded back into the extract: three instructions)
+                                lds_u32 *slot = reinterpret_cast<lds_u32 *>(acc_base + (idx << 2));
+                                if (LAST && last_mode) __hip_atomic_fetch_max(slot, pos0 + (uint32_t) k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                else __hip_atomic_fetch_add(slot, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_u32 (lost charge lands in the trash entry)
+                            }
+                    }
+                }
+                else
+                {
+#pragma unroll
+                    for (int h = 0; h < 8; h += 4)
+                    {
+                        double wv[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            wv[k] = *reinterpret_cast<const double *>(reinterpret_cast<const uint8_t *>(s_lut) + (((d4[(h + k) >> 1] >> ((k & 1) ? 16 : 0)) & 0x3eu) << 2));
+#pragma unroll
+                        for (int k = 0; k < 4; k++)
+                            if (live && fired[h + k])
+                            {
+                                const uint32_t idx = __builtin_amdgcn_ubfe(d4[(h + k) >> 1], (k & 1) ? 22u : 6u, 10u);
+                                if (LAST && last_mode) atomicMax(&lastv[idx], pos0 + (uint32_t) (h + k) + 1u);
+                                else atomicAdd(&acc[idx], wv[k]); // ds_add_f64 (lost charge lands in the trash entry)
+                            }
+                    }
+                }
+            };
+            // Lanes past the end of the run keep whatever their registers hold: they are the highest lanes of the last
+            // group-row, so their first-synapse counts reach no live lane, and `live` keeps them from adding.
+            const int lane_groups = (int) run_groups - lane; // this lane has group (row + lane) while row < lane_groups
+            for (uint32_t row = 0; row < run_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
+            {
+#pragma unroll
+                for (int u = 0; u < SDEPTH; u++)
+                {
+                    const uint32_t r = row + (uint32_t) u * WAVE;
+                    if (r < run_groups) add8(sq[u], run_pos0 + 8u * (r + (uint32_t) lane), (int) r < lane_groups);
+                    // The refill is unconditional (past the end: the last group again): with a load behind a branch
+                    // the compiler cannot count the loads in flight and waits for ALL of them before every group,
+                    // which leaves one group per wave in flight instead of SDEPTH.
+                    const uint32_t nxt = r + (uint32_t) SDEPTH * WAVE + (uint32_t) lane;
+                    sq[u] = load_stream16(src + (nxt < run_groups ? nxt : run_groups - 1u));
+                    keep_load_order();
+                }
+            }
+                wave_lds_fence(); // the table is rewritten by the next run
+            }
+            // ---- Phase C: chunks with a few spiking axons ----
+            while (gather_mask != 0u) // wave-uniform
+            {
+                const uint32_t j = (uint32_t) __builtin_ctz(gather_mask);
+                gather_mask &= gather_mask - 1u;
+                const uint32_t cg = r0 + j * WAVE_CHUNK;
+                const uint32_t a0 = cg + (uint32_t) lane * AX_PER_THREAD;
+                const unsigned long long qq = (a0 < n_ax) ? *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0) : 0ull;
+                const uint32_t lo = (uint32_t) qq, hi = (uint32_t) (qq >> 32);
+                const uint32_t nsyn[AX_PER_THREAD] = {(lo >> 8) & 0xffu, lo >> 24, (hi >> 8) & 0xffu, hi >> 24};
+                const uint32_t lcls[AX_PER_THREAD] = {0u, 0u, 0u, 0u};
+                gather_chunk(cg, (amask_all >> (4u * j)) & 15u, nsyn, lcls);
+            }
+        }
+    }
+    else
+    for (;; c0 = next_c(c0))
+    {
+        // ---- this chunk: take over what the previous iteration decoded and probed ----
+        uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
+        bool dense = false; // wave-uniform: enough spiking axons to stream the chunk
+        if (c0 < n_ax)
+        {
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                nsyn[k] = nx_nsyn[k];
+                lcls[k] = nx_lcls[k];
+                amask |= ((nx_word[k] >> (nx_pre[k] & 31u)) & (nx_valid >> k) & 1u) << k;
+            }
+            // ---- next chunk: decode its records, probe the bitmap; then start the loads of the chunk after it ----
+            const uint32_t c1 = next_c(c0);
+            if (c1 < n_ax)
+            {
+                decode_and_probe(c1);
+                const uint32_t c2 = next_c(c1);
+                if (c2 < n_ax) load4(c2 + (uint32_t) lane * AX_PER_THREAD, cur);
+            }
+            // STREAM or GATHER?  With many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
+            // so read them all once, in order (16 bytes per lane), and let each word say whether its axon
+            // spiked: no compaction, no ownership search, no per-event address arithmetic.
+            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
+            dense = STREAMABLE && !RUNS && compact && n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
+        }
+        if (c0 >= n_ax) break;
+        if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
+        if (dense)
+        {
+            {
+                // 256-byte table: byte a = "axon a of the chunk spiked"; lane L owns axons 4L..4L+3 = one dword
+                w_pref[lane] = (amask * 0x00204081u) & 0x01010101u;
+                wave_lds_fence();
+                stream_preload();
+                const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
+                auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
+                    const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
+                    const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
+                    uint32_t fired[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0xffu];
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (fired[u])
+                        {
+                            const uint32_t idx = (w4[u] >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu);
+                            if (LAST && last_mode)
+                            {
+                                atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
+                                continue;
+                            }
+                            // ds_add_f64 (lost charge lands in the trash entry)
+                            atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
+                            if (TOUCH_BYTES) touched[idx] = 1;
+                        }
+                };
+                // rolling window: SDEPTH 16-byte groups per lane in flight while one is added
+                for (uint32_t row = 0; row < st_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
+                {
+#pragma unroll
+                    for (int u = 0; u < SDEPTH; u++)
+                    {
+                        // add, then refill the same registers (the other groups of the window are still in flight)
+                        const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
+                        if (g < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * g);
+                        // unconditional refill (past the end: the last group again), so that the loads in flight can be
+                        // counted and a group waits for its own load only
+                        const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
+                        const uint32_t nxt = nxt_g < st_groups ? nxt_g : st_groups - 1u;
+                        sq[u] = load_stream16(st_src + nxt);
+                        if (SYN_FMT == 4)
+                        {
+                            sw[u][0] = st_wsrc[2 * nxt];
+                            sw[u][1] = st_wsrc[2 * nxt + 1];
+                        }
+                        keep_load_order();
+                    }
+                }
+                // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
+                // in integers here, priced once at the end of the slice
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
+                stream_msgs += (uint32_t) __popc(amask);
+                wave_lds_fence(); // w_pref is rewritten by the next chunk
+                continue;
+            }
+        }
+        gather_chunk(c0, amask, nsyn, lcls);
     }
     // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
     if (STREAMABLE) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
