@@ -676,7 +676,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             }
         }
         TRYC(upload(c, reinterpret_cast<const unsigned long long *>(dev_core_base.data()), h.n_cores, &im.core_syn_base));
-        std::vector<unsigned char> bytes(n_bytes + 16, 0);
+        std::vector<unsigned char> bytes(n_bytes + 4096 + 16, 0); // (the delivery kernel reads up to 8 chunks of records at fixed offsets)
         std::vector<uint32_t> csyn(n_chunks, 0), cpre(n_chunks, 0);
         std::vector<uint8_t> exact(h.n_slices, 0);
         std::vector<uint32_t> meta; // device synapse words (all formats but 2, which keeps the image's arrays)

@@ -1085,12 +1085,16 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             unsigned long long q[RUN_MAX];
             uint32_t amask_all = 0;                 // per lane: 4 bits per chunk of the run
             uint32_t dense_mask = 0, gather_mask = 0; // wave-uniform: chunks to stream / to gather
+            // pre slot of each chunk's first axon: lane j fetches chunk j's (one load, broadcast by readlane below)
+            const uint32_t n_here = min(run_len, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK); // chunks of this run inside the slice
+            const uint32_t pre0_lane = chunk_pre0[ci0 + min((uint32_t) lane, n_here - 1u)];
+            // one address, eight immediate offsets: the record array ends in 4 KB of padding, reads past the slice stay in
+            // bounds and are zeroed below
+            const unsigned long long *rec_lane = reinterpret_cast<const unsigned long long *>(rec + 2ull * (r0 + (uint32_t) lane * AX_PER_THREAD));
 #pragma unroll
             for (uint32_t j = 0; j < RUN_MAX; j++)
             {
-                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
-                const bool have = j < run_len && a0 < n_ax; // (records past the end inside the slice's 16-byte padding read as 0)
-                q[j] = *reinterpret_cast<const unsigned long long *>(rec + 2ull * (have ? a0 : 0u));
+                q[j] = rec_lane[j * (WAVE_CHUNK * 2u / 8u)];
                 keep_load_order();
             }
             // (the bitmap probes in two halves of 16: 32 destination registers at once would spill)
@@ -1109,8 +1113,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
                 const uint32_t dl[AX_PER_THREAD] = {lo & 0xffu, (lo >> 16) & 0xffu, hi & 0xffu, (hi >> 16) & 0xffu};
                 const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
-                const bool chunk_here = j < run_len && r0 + j * WAVE_CHUNK < n_ax; // scalar
-                uint32_t pre = chunk_pre0[chunk_here ? ci0 + j : ci0] + wave_inclusive_scan(lane_d) - lane_d;
+                uint32_t pre = (uint32_t) __builtin_amdgcn_readlane((int) pre0_lane, (int) j) + wave_inclusive_scan(lane_d) - lane_d;
                 shifts[jj] = 0;
 #pragma unroll
                 for (int k = 0; k < AX_PER_THREAD; k++)
@@ -1125,11 +1128,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             for (uint32_t jj = 0; jj < RUN_MAX / 2; jj++)
             {
                 const uint32_t j = half + jj;
-                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                // (an axon of these formats owns at least one synapse: a zero count marks the records past the end)
                 uint32_t amask = 0;
 #pragma unroll
                 for (int k = 0; k < AX_PER_THREAD; k++)
-                    amask |= ((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & ((j < run_len && a0 + k < n_ax) ? 1u : 0u)) << k;
+                    amask |= ((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & (((q[j] >> (16 * k + 8)) & 0xffull) != 0ull ? 1u : 0u)) << k;
                 const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
                 const bool dense = n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
                 dense_mask |= dense ? (1u << j) : 0u;
