@@ -231,6 +231,10 @@ int sanafe_hip_synchronize(sanafe_hip_chip *chip);
  * slices whose axon records use the 2-byte delta form instead of the 8-byte form.  The environment variable
  * SANAFE_SYN_FORMAT (0, 1, 2, 3, 4, 6) picks a wider layout than the default where the image allows it (tests). */
 int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_compact_slices);
+/* > 0: the delivery workgroups sum integer weights in 32-bit integer LDS accumulators, every event adding
+ * weight + 2^shift (formats 7, and 0 / 3 when the per-accumulator bounds hold); 0: fp64 accumulators.  The result is the
+ * same bit for bit -- sums of integers are exact in any order; SANAFE_INT_ACC=0 keeps the fp64 accumulators (tests). */
+int sanafe_hip_get_acc_shift(sanafe_hip_chip *chip);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.
  *   [0] synapse words (+ fp64 weights in format 2)   [1] axon records   [2] chunk tables   [3] slice descriptors

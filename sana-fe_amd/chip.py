@@ -398,7 +398,8 @@ class SpikingChip(_Base):
         H.sanafe_hip_get_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
         if H.sanafe_hip_get_layout(self.device_handle(), C.byref(fmt), C.byref(n)) != 0:
             raise RuntimeError(H.sanafe_hip_last_error().decode())
-        return {"syn_format": fmt.value, "n_compact_slices": n.value}
+        H.sanafe_hip_get_acc_shift.argtypes = [C.c_void_p]
+        return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle()))}
 
     def step_neurons(self):
         self._check(self._L.sanafe_chip_step_neurons(self._h))

@@ -486,7 +486,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // the index-coded words address (max delay + 1) rows of npad + 1 accumulators: 15 bits (12 with 12-bit weights)
         const uint64_t n_acc = (uint64_t) fmt0_rows * (fmt0_max_pad + 1u);
         const int weights = fmt; // 0 int8, 1 12-bit integers, 2 fp64
-        if (weights == 0) fmt = n_acc <= 32768ull ? 0 : 1;
+        if (weights == 0) fmt = n_acc <= 8192ull ? 0 : 1;
         else if (weights == 1) fmt = n_acc <= 4096ull ? 3 : 1;
         else fmt = n_acc <= 32768ull ? 4 : 2;
         // format 6 (2-byte words, dictionary-coded weights): at most 32 distinct weight values on the chip, none of them
@@ -537,12 +537,13 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 c->weight_lut = lut;
             }
         }
-        // format 7 (integer accumulators): a dictionary of integers, and per slice and accumulator the bounds that
-        // keep "events * 2^shift + sum of weights" decodable (see DevImage)
+        // Integer accumulators (format 7; formats 0 and 3 when they can): integer weights, and per slice and accumulator the
+        // bounds that keep "events * 2^shift + sum of weights" decodable (see DevImage)
         bool int_ok = dict_ok;
         if (int_ok)
             for (double w : c->weight_lut) int_ok = int_ok && std::fabs(w) <= 1048576.0 && w == (double) (long long) w;
-        if (int_ok)
+        int acc_shift = 0; // 0: the bounds do not hold
+        if ((int_ok || weights <= 1) && n_acc <= 32768ull && h.n_synapses > 0)
         {
             std::atomic<uint64_t> max_count{0}, max_abs{0};
             parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
@@ -576,9 +577,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             });
             int shift = 1;
             while ((1ull << (shift - 1)) <= max_abs.load() && shift < 32) shift++;
-            int_ok = shift <= 15 && ((max_count.load() + 1ull) << shift) <= (1ull << 32); // weight + 2^shift: 16 bits in the kernel's table
-            c->acc_shift = int_ok ? shift : 0;
+            if (shift <= 30 && ((max_count.load() + 1ull) << shift) <= (1ull << 32)) acc_shift = shift;
         }
+        if (const char *env = std::getenv("SANAFE_INT_ACC")) // tests: 0 keeps the fp64 accumulators
+            if (std::atoi(env) == 0) acc_shift = 0;
+        int_ok = int_ok && acc_shift > 0 && acc_shift <= 15; // format 7: weight + 2^shift has 16 bits in the kernel's table
         const int plain = fmt;
         // integer dictionary: 7.  Other dictionaries: 6 beats the 12-byte fp64 layouts; integers that fail the bounds
         // of 7 keep their 4-byte streamable form when they have one (fp64 LDS adds bound both, 4 bytes has less ALU work).
@@ -596,6 +599,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             else if (want == 4 && n_acc <= 32768ull) fmt = 4;
         }
         c->syn_format = fmt;
+        c->acc_shift = (fmt == 7 || ((fmt == 0 || fmt == 3) && weights <= 1)) ? acc_shift : 0;
     }
     const bool dict16 = (c->syn_format == 6 || c->syn_format == 7); // 2-byte dictionary-coded words
     const bool stream_layout = (c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4 || dict16);
@@ -607,6 +611,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<uint32_t> chunk0(h.n_slices, 0);
         uint64_t n_chunks = 0, n_bytes = 0;
         bool any_exact = false;
+        const bool runs_format = dict16 || c->syn_format == 0 || c->syn_format == 4; // deliver_kernel: RUNS
         parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t sl = lo; sl < hi; sl++)
             {
@@ -614,7 +619,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 bool ok = e0 > b0 && h.ax_lat_class != nullptr && h.ax_lat_class[b0] != 255u;
                 for (uint64_t a = b0; a < e0 && ok; a++)
                 {
-                    ok = h.ax_nsyn[a] < 256u && h.ax_lat_class[a] == h.ax_lat_class[b0];
+                    ok = h.ax_nsyn[a] < 256u && h.ax_lat_class[a] == h.ax_lat_class[b0] &&
+                         (h.ax_nsyn[a] > 0u || !runs_format); // (the run formats mark records past the end with a zero count)
                     if (ok && ((a - b0) % WAVE_CHUNK) != 0) ok = h.ax_pre[a] >= h.ax_pre[a - 1] && h.ax_pre[a] - h.ax_pre[a - 1] < 256u;
                 }
                 mode[sl] = ok ? 1 : 0;
@@ -704,7 +710,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                         for (uint64_t q = chunk_pos[chunk0[sl] + k] + chunk_syn_count((uint32_t) sl, k); q < chunk_pos[chunk0[sl] + k + 1]; q++)
                         {
                             if (dict16) meta16[q] = (uint16_t) (trash_post << 6); // no first-synapse bit, trash entry
-                            else meta[q] = trash_post << 8; // code 0, weight 0: adds nothing wherever it lands
+                            else meta[q] = trash_post << (c->syn_format == 3 ? 8 : 11); // code 0, weight 0: adds nothing wherever it lands
                         }
                 for (uint64_t a = b0; a < e0; a++)
                 {
@@ -729,7 +735,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[b0 + (rel / WAVE_CHUNK) * WAVE_CHUNK];
                     const uint64_t dpos = chunk_pos[chunk0[sl] + rel / WAVE_CHUNK] + (src - chunk_first);
-                    const uint32_t code = in_chunk; // index of the axon inside its 256-axon chunk
+                    // index of the axon inside its 256-axon chunk; formats 0 and 4 add the chunk's place in a run of 8
+                    const uint32_t code = in_chunk | (c->syn_format == 3 ? 0u : (uint32_t) ((rel / WAVE_CHUNK) & 7u) << 8);
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t m = h.syn_meta[src + k];
@@ -740,11 +747,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                             const uint32_t idx = drop ? trash_post : ((m >> 16) & 7u) * (trash_post + 1u) + (m & 0xffffu);
                             if (dict16)
                                 meta16[dpos + k] = (uint16_t) ((idx << 6) | (lut_code(h.syn_weight[src + k]) << 1) | (k == 0 ? 1u : 0u));
-                            else if (c->syn_format == 0) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xff) << 24);
+                            else if (c->syn_format == 0) meta[dpos + k] = code | (idx << 11) | ((uint32_t) (w & 0xff) << 24);
                             else if (c->syn_format == 3) meta[dpos + k] = code | (idx << 8) | ((uint32_t) (w & 0xfff) << 20);
                             else
                             {
-                                meta[dpos + k] = code | (idx << 8);
+                                meta[dpos + k] = code | (idx << 11);
                                 wdev[dpos + k] = h.syn_weight[src + k];
                             }
                         }
@@ -1115,17 +1122,32 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
     if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(F);               \
     else if (c->has_delay) SANAFE_LAUNCH_DELIVER(F, true);           \
     else SANAFE_LAUNCH_DELIVER(F, false)
+// formats 0 and 3 with 32-bit integer accumulators (the per-accumulator bounds hold: acc_shift > 0)
+#define SANAFE_LAUNCH_FORMAT_IACC(F)                                                                                                            \
+    if (c->im.has_last)                                                                                                                        \
+        hipLaunchKernelGGL((deliver_kernel<F, false, true, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first);  \
+    else if (c->has_delay)                                                                                                                     \
+        hipLaunchKernelGGL((deliver_kernel<F, true, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first);  \
+    else                                                                                                                                       \
+        hipLaunchKernelGGL((deliver_kernel<F, false, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
         switch (c->syn_format)
         {
-        case 0: SANAFE_LAUNCH_FORMAT(0); break;
+        case 0:
+            if (c->acc_shift > 0) { SANAFE_LAUNCH_FORMAT_IACC(0); }
+            else { SANAFE_LAUNCH_FORMAT(0); }
+            break;
         case 1: SANAFE_LAUNCH_FORMAT(1); break;
-        case 3: SANAFE_LAUNCH_FORMAT(3); break;
+        case 3:
+            if (c->acc_shift > 0) { SANAFE_LAUNCH_FORMAT_IACC(3); }
+            else { SANAFE_LAUNCH_FORMAT(3); }
+            break;
         case 4: SANAFE_LAUNCH_FORMAT(4); break;
         case 6: SANAFE_LAUNCH_FORMAT(6); break;
         case 7: SANAFE_LAUNCH_FORMAT(7); break;
         default: SANAFE_LAUNCH_FORMAT(2); break;
         }
 #undef SANAFE_LAUNCH_FORMAT
+#undef SANAFE_LAUNCH_FORMAT_IACC
 #undef SANAFE_LAUNCH_DELIVER
 #undef SANAFE_LAUNCH_DELIVER_LAST
         HIPCHK(hipGetLastError());
@@ -1246,6 +1268,10 @@ extern "C" int sanafe_hip_write_ext(sanafe_hip_chip *c, int64_t n_steps, const i
     return 0;
 }
 
+extern "C" int sanafe_hip_get_acc_shift(sanafe_hip_chip *c)
+{
+    return c ? c->acc_shift : 0;
+}
 extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32_t *n_compact_slices)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");

@@ -100,8 +100,8 @@ struct DevImage
     const double *ax_proc_delay;  // exact processing delays, only dereferenced for latency class 255
     const double *lat_class;      // [256] per-event latency of each class
     // Synapses, one of three formats (chip-wide):
-    //   0: 4 bytes      axon code (8b) | accumulator index (15b) << 8 | int8 weight << 24
-    //                   axon code = index of the synapse's axon inside its 256-axon chunk: lets a chunk with many
+    //   0: 4 bytes      axon code (11b) | accumulator index (13b) << 11 | int8 weight << 24
+    //                   axon code = (chunk of the slice & 7) << 8 | index of the synapse's axon inside its 256-axon chunk: lets a chunk with many
     //                   spikes be STREAMED (every synapse word read once, in order, fired or not decided from the
     //                   word itself via a 256-byte table in LDS) instead of gathered;
     //                   accumulator index = delay * (npad + 1) + post-neuron offset, i.e. the LDS entry the weight is
@@ -110,7 +110,7 @@ struct DevImage
     //   2: 4 + 8 bytes  syn_meta as in 1 without the weight, syn_weight = fp64                    (gather only)
     //   3: 4 bytes      axon code (8b) | accumulator index (12b) << 8 | 12-bit signed weight << 20: the streamable
     //                   form of 1, for chips whose cores need at most 4096 accumulators
-    //   4: 4 + 8 bytes  axon code (8b) | accumulator index (15b) << 8, syn_weight = fp64: the streamable form of 2
+    //   4: 4 + 8 bytes  axon code (11b) | accumulator index (15b) << 11, syn_weight = fp64: the streamable form of 2
     //   6: 2 bytes      first synapse of its axon (1b) | weight code (5b) << 1 | accumulator index (10b) << 6:
     //                   dictionary-coded weights (weight_lut, at most 32 distinct values on the chip) for cores with at
     //                   most 1024 accumulators.  No axon code: the words of a chunk are in axon order, so a word's axon
@@ -724,7 +724,7 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 // workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
 // instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
 // (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
-template <int SYN_FMT, bool HAS_DELAY, bool LAST>
+template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false>
 __global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, uint32_t first_slice)
 {
@@ -732,17 +732,22 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[DELIVER_BLOCK / WAVE];
     constexpr bool DICT16 = (SYN_FMT == 6 || SYN_FMT == 7); // 2-byte words, dictionary-coded weights
-    constexpr bool INT_ACC = (SYN_FMT == 7);                // 32-bit integer accumulators (see DevImage)
+    constexpr bool INT_ACC = (SYN_FMT == 7) || IACC;        // 32-bit integer accumulators (see DevImage): format 7 always, formats 0 / 3 when the bounds hold
+    static_assert(!IACC || SYN_FMT == 0 || SYN_FMT == 3, "integer accumulators: formats 0, 3 and 7");
     __shared__ double s_lut[(SYN_FMT == 6) ? 32 : 1];      // format 6: the weight dictionary
-    __shared__ uint16_t s_lut16[INT_ACC ? 32 : 2];         // format 7: weight + 2^acc_shift (acc_shift <= 15)
+    __shared__ uint16_t s_lut16[(SYN_FMT == 7) ? 32 : 2];  // format 7: weight + 2^acc_shift (acc_shift <= 15)
     // Formats 6, 7: a wave takes RUN_MAX consecutive chunks, notes which axons spiked in a bit table and streams the
     // words of all of them in one go (a "run"): the words carry no chunk-relative axon code, so nothing ties the
     // stream to 256 axons, and the fixed cost of starting a stream is paid once per run.
-    constexpr bool RUNS = DICT16;
+    // Formats 0 and 4 take runs as well: their words carry an 11-bit axon code = (chunk of the slice & 7) << 8 | axon of the
+    // chunk, which indexes a byte table of 8 x 256 entries.
+    constexpr bool RUNS = DICT16 || SYN_FMT == 0 || SYN_FMT == 4;
+    constexpr bool BYTE_TABLE = RUNS && !DICT16;
     constexpr uint32_t RUN_MAX = 8;
-    __shared__ uint32_t s_bits[RUNS ? DELIVER_BLOCK / WAVE : 1][RUNS ? RUN_MAX * 8 + 8 : 1]; // bit 32 + a = "axon a of the run spiked"
+    // formats 6, 7: bit 32 + a = "axon a of the run spiked"; formats 0, 4: byte (code11) = "that axon spiked"
+    __shared__ uint32_t s_bits[RUNS ? DELIVER_BLOCK / WAVE : 1][BYTE_TABLE ? RUN_MAX * 64 : RUNS ? RUN_MAX * 8 + 8 : 1];
     if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
-    if (INT_ACC && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
+    if (SYN_FMT == 7 && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // a scalar: chunk offsets and bases stay in SGPRs
@@ -1033,8 +1038,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                             else if (STREAMABLE)
                             {
                                 const uint32_t m = im.syn_meta[s];
-                                meta[u] = (m >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu); // the accumulator index itself (trash entry when the charge is lost)
-                                wgt[u] = SYN_FMT == 4 ? im.syn_weight[s] : (double) ((int) m >> (SYN_FMT == 0 ? 24 : 20));
+                                // the accumulator index itself (trash entry when the charge is lost)
+                                meta[u] = SYN_FMT == 3 ? (m >> 8) & 0xfffu : (m >> 11) & (SYN_FMT == 0 ? 0x1fffu : 0x7fffu);
+                                if (INT_ACC) wgt32[u] = (uint32_t) (((int) m >> (SYN_FMT == 0 ? 24 : 20)) + (1 << im.acc_shift));
+                                else wgt[u] = SYN_FMT == 4 ? im.syn_weight[s] : (double) ((int) m >> (SYN_FMT == 0 ? 24 : 20));
                             }
                             else if (SYN_FMT == 1)
                             {
@@ -1140,11 +1147,19 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 amask_all |= amask << (4 * j);
                 // Bit table: bit 32 + 256 j + a = "axon a of chunk j spiked" (chunks that are not streamed: zeros).  Eight
                 // lanes' masks make one dword: three DPP steps inside the rows, no LDS atomics.
-                uint32_t m8 = dense ? amask : 0u;
-                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
-                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
-                m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
-                if ((lane & 7) == 0) w_bits[1u + 8u * j + ((uint32_t) lane >> 3)] = m8;
+                if constexpr (BYTE_TABLE)
+                {
+                    // byte table: lane L owns axons 4L..4L+3 of the chunk = one dword of the chunk's 256 bytes
+                    w_bits[64u * ((ci0 + j) & 7u) + (uint32_t) lane] = dense ? (amask * 0x00204081u) & 0x01010101u : 0u;
+                }
+                else
+                {
+                    uint32_t m8 = dense ? amask : 0u;
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
+                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
+                    if ((lane & 7) == 0) w_bits[1u + 8u * j + ((uint32_t) lane >> 3)] = m8;
+                }
                 if (dense)
                 {
                     // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
@@ -1163,17 +1178,27 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 const uint32_t first_dense = (uint32_t) __builtin_ctz(dense_mask), last_dense = 31u - (uint32_t) __builtin_clz(dense_mask);
                 const uint32_t run_pos0 = chunk_syn0[ci0 + first_dense];
                 const uint32_t run_groups = (chunk_syn0[ci0 + last_dense + 1u] - run_pos0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
-                const uint4 *src = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0));
+                const uint4 *src = DICT16 ? reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0))
+                                          : reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + run_pos0));
+                const double2 *wsrc = (SYN_FMT == 4) ? reinterpret_cast<const double2 *>(im.syn_weight + (syn_base + run_pos0)) : nullptr;
                 // The first SDEPTH groups of every lane.  All loads of the stream are unconditional (past the end: the last
                 // group again) and issued in one fixed pattern: only then can the loads in flight be counted, so that a
                 // group waits for ITS load (vmcnt(SDEPTH - 1)) and not for all of them.
 #pragma unroll
                 for (int u = 0; u < SDEPTH; u++)
                 {
-                    const uint32_t g = (uint32_t) lane + (uint32_t) u * WAVE;
-                    sq[u] = load_stream16(src + (g < run_groups ? g : run_groups - 1u));
+                    const uint32_t g_u = (uint32_t) lane + (uint32_t) u * WAVE;
+                    const uint32_t g = g_u < run_groups ? g_u : run_groups - 1u;
+                    sq[u] = load_stream16(src + g);
+                    if (SYN_FMT == 4)
+                    {
+                        sw[u][0] = wsrc[2 * g];
+                        sw[u][1] = wsrc[2 * g + 1];
+                    }
                     keep_load_order();
                 }
+                if constexpr (DICT16)
+                {
                 // 8 words per lane and group.  A word's axon = (first-synapse bits of the run up to and including it) - 1:
                 // per group the lanes count their bits, one DPP prefix sum orders the lanes, a scalar carries the count
                 // from group to group.  The eight axons of a lane are consecutive, so ONE 32-bit window of the bit
@@ -1271,6 +1296,54 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     keep_load_order();
                 }
             }
+                }
+                else
+                {
+                    // 4 words per lane and group: the word's low 11 bits index the byte table, the next bits ARE the LDS
+                    // accumulator index (lost charge lands in the trash entry)
+                    const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_bits);
+                    const int acc_bias = 1 << im.acc_shift; // integer accumulators: every event adds weight + 2^acc_shift
+                    auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
+                        const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
+                        const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
+                        uint32_t fired[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0x7ffu];
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (fired[u])
+                            {
+                                const uint32_t idx = (w4[u] >> 11) & (SYN_FMT == 0 ? 0x1fffu : 0x7fffu);
+                                if (LAST && last_mode)
+                                {
+                                    atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
+                                    continue;
+                                }
+                                if (INT_ACC) atomicAdd(&acc32[idx], (uint32_t) (((int) w4[u] >> 24) + acc_bias)); // ds_add_u32
+                                else atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> 24));   // ds_add_f64
+                                if (TOUCH_BYTES) touched[idx] = 1;
+                            }
+                    };
+                    for (uint32_t row = 0; row < run_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
+                    {
+#pragma unroll
+                        for (int u = 0; u < SDEPTH; u++)
+                        {
+                            // add, then refill the same registers (the other groups of the window are still in flight)
+                            const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
+                            if (g < run_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], run_pos0 + 4u * g);
+                            const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
+                            const uint32_t nxt = nxt_g < run_groups ? nxt_g : run_groups - 1u;
+                            sq[u] = load_stream16(src + nxt);
+                            if (SYN_FMT == 4)
+                            {
+                                sw[u][0] = wsrc[2 * nxt];
+                                sw[u][1] = wsrc[2 * nxt + 1];
+                            }
+                            keep_load_order();
+                        }
+                    }
+                }
                 wave_lds_fence(); // the table is rewritten by the next run
             }
             // ---- Phase C: chunks with a few spiking axons ----
@@ -1327,6 +1400,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 wave_lds_fence();
                 stream_preload();
                 const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
+                const int acc_bias = 1 << im.acc_shift; // integer accumulators: every event adds weight + 2^acc_shift
                 auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
                     const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
                     const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
@@ -1337,14 +1411,15 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     for (int u = 0; u < 4; u++)
                         if (fired[u])
                         {
-                            const uint32_t idx = (w4[u] >> 8) & (SYN_FMT == 3 ? 0xfffu : 0x7fffu);
+                            const uint32_t idx = (w4[u] >> 8) & 0xfffu; // (format 3: the other streamable formats take runs)
                             if (LAST && last_mode)
                             {
                                 atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
                                 continue;
                             }
-                            // ds_add_f64 (lost charge lands in the trash entry)
-                            atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
+                            // ds_add_u32 / ds_add_f64 (lost charge lands in the trash entry)
+                            if (INT_ACC) atomicAdd(&acc32[idx], (uint32_t) (((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)) + acc_bias));
+                            else atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
                             if (TOUCH_BYTES) touched[idx] = 1;
                         }
                 };

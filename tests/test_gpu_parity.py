@@ -291,6 +291,27 @@ def test_small_integer_weights_four_layouts(S, monkeypatch, force, fmt):
     assert lay["syn_format"] == fmt and lay["n_compact_slices"] > 0
 
 
+@pytest.mark.parametrize("weights,force,fmt", [("int", "0", 0), ("int12", None, 3)])
+@pytest.mark.parametrize("int_acc", [True, False])
+def test_integer_and_fp64_accumulators_of_the_4_byte_words(S, monkeypatch, weights, force, fmt, int_acc):
+    """Formats 0 and 3 sum integer weights in 32-bit integer LDS accumulators when the per-accumulator bounds hold
+    (sanafe_hip_get_acc_shift > 0) and in fp64 otherwise (forced here with SANAFE_INT_ACC=0): the same results, bit for
+    bit, on a streamed network and with synaptic delays."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    if not int_acc:
+        monkeypatch.setenv("SANAFE_INT_ACC", "0")
+    kw = {} if weights == "int" else {"weights": weights}
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=180, arch_kind="loihi", p_fire=0.5, seed=41, **kw)
+    chip, _ = check_stepwise(S, arch, net, steps=10)
+    lay = chip.device_layout()
+    assert lay["syn_format"] == fmt and (lay["acc_shift"] > 0) == int_acc and lay["n_compact_slices"] > 0
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=128, out_degree=60, arch_kind="large", delays=True, p_fire=0.05,
+                                  seed=42, **kw)
+    chip, _ = check_stepwise(S, arch, net, steps=10)
+    assert (chip.device_layout()["acc_shift"] > 0) == int_acc
+
+
 def test_dictionary_coded_float_weights(S):
     """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
