@@ -312,6 +312,18 @@ def test_integer_and_fp64_accumulators_of_the_4_byte_words(S, monkeypatch, weigh
     assert (chip.device_layout()["acc_shift"] > 0) == int_acc
 
 
+@pytest.mark.parametrize("force", [None, "6", "0", "1"])
+def test_last_event_wins_on_streamed_chunks(S, monkeypatch, force):
+    """Buffer before the dendrite unit (only the LAST event of a step reaches the accumulator, src/chip.cpp:759) on dense
+    cores: the stream path of every layout keeps the position of the last event in delivery order, not a sum."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=170, arch_kind="before_dendrite", p_fire=0.5, seed=43)
+    chip, _ = check_stepwise(S, arch, net, steps=10)
+    lay = chip.device_layout()
+    assert lay["syn_format"] == {None: 7, "6": 6, "0": 0, "1": 1}[force] and lay["n_compact_slices"] > 0
+
+
 def test_dictionary_coded_float_weights(S):
     """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
