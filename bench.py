@@ -50,8 +50,18 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
     src, dst, w = S.chip.generate_random_edges(n, out_degree, seed, shard=shard, window=n_per_gpu)
     if weights == "int12":    # integers beyond int8: the 12-bit-weight synapse word (format 3)
         w *= 100.0
-    elif weights == "float":  # not representable as integers: fp64 weights beside the synapse words (format 4)
+    elif weights == "float":  # 16 distinct non-integers: dictionary-coded 2-byte words, fp64 accumulators (format 6)
         w *= 0.7310585786300049
+    elif weights in ("int8wide", "floatwide"):
+        # ~240 distinct integers in +-127 (4-byte int8 words, format 0) / as many distinct non-integers as synapses
+        # (4-byte words + fp64 weights, format 4): the layouts of networks whose weights fit no 32-entry dictionary
+        for a in range(0, len(w), 1 << 26):
+            b = min(len(w), a + (1 << 26))
+            jitter = ((np.arange(a, b, dtype=np.uint64) * np.uint64(2654435761)) >> np.uint64(13)) % np.uint64(15)
+            w[a:b] = w[a:b] * 15.0 + (jitter.astype(np.float64) - 7.0)
+            if weights == "floatwide":
+                w[a:b] *= 0.05 + 1e-9 * jitter
+            del jitter
     net.add_edges(src, dst, w, "loihi_sparse_synapse")
     del src, dst, w
     for r in range(n_gpus):
@@ -205,8 +215,9 @@ def main():
     ap.add_argument("--neurons-per-core", type=int, default=512)
     ap.add_argument("--out-degree", type=int, default=2621)
     ap.add_argument("--p-fire", type=float, default=0.1)
-    ap.add_argument("--weights", choices=("int8", "int12", "float"), default="int8",
-                    help="c3: synaptic weights -- integers in +-8 (default, SURVEY 8d), integers in +-800, or non-integers")
+    ap.add_argument("--weights", choices=("int8", "int12", "float", "int8wide", "floatwide"), default="int8",
+                    help="c3: synaptic weights -- integers in +-8 (default, SURVEY 8d), integers in +-800, 16 non-integers, "
+                         "~240 distinct integers in +-127, or a different non-integer per synapse")
     ap.add_argument("--device-warmup", type=int, default=64,
                     help="c3: steps simulated and then undone by chip.reset() before the W warm-up steps -- the GPU's clocks "
                          "need ~30 ms of load to settle (profiles/r02_step_profile.txt); 0 switches it off")
