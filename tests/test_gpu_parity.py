@@ -324,6 +324,21 @@ def test_last_event_wins_on_streamed_chunks(S, monkeypatch, force):
     assert lay["syn_format"] == {None: 7, "6": 6, "0": 0, "1": 1}[force] and lay["n_compact_slices"] > 0
 
 
+@pytest.mark.parametrize("force", [None, "0"])
+def test_several_runs_per_wavefront(S, monkeypatch, force):
+    """One delivery slice per core with ~15 k inbound axons = 60 chunks: every wavefront streams two runs of 8 chunks,
+    the last run of the slice is short and its last chunk partial."""
+    monkeypatch.setenv("SANAFE_TARGET_SLICES", "16")
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "100000")
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=960, out_degree=64, arch_kind="large", p_fire=0.3, seed=47)
+    chip, _ = check_stepwise(S, arch, net, steps=6)
+    lay, info = chip.device_layout(), chip.info()
+    assert lay["syn_format"] == (7 if force is None else 0) and lay["n_compact_slices"] == info["n_slices"] == 16
+    assert info["n_axons"] > 16 * 9000
+
+
 def test_dictionary_coded_float_weights(S):
     """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
