@@ -90,6 +90,7 @@ struct sanafe_hip_chip
     uint64_t layout_bytes[SANAFE_HIP_LAYOUT_FIELDS]{};
     std::vector<double> weight_lut; // formats 6, 7: the chip's distinct weight values (<= 32)
     int acc_shift{0};               // format 7: see DevImage
+    bool small_slices{false};       // every delivery slice holds at most two 256-axon chunks: 64-thread delivery workgroups
     // state log (record bit 3): potentials / input currents of listed slots, one row per recorded step
     uint32_t *d_log_slots_v{nullptr}, *d_log_slots_u{nullptr};
     uint32_t n_log_v{0}, n_log_u{0};
@@ -812,6 +813,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat.begin());
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
         for (uint8_t m : mode) c->n_compact_slices += m;
+        c->small_slices = h.n_slices > 0;
+        for (uint32_t sl = 0; sl < h.n_slices; sl++) c->small_slices = c->small_slices && (h.slice_axon_end[sl] - h.slice_axon_beg[sl]) <= 2 * WAVE_CHUNK;
+        if (const char *env = std::getenv("SANAFE_DELIVER_SMALL")) // tests: 0 keeps the 256-thread workgroups
+            if (std::atoi(env) == 0) c->small_slices = false;
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
         c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : dict16 ? 2ull : 4ull);
         c->layout_bytes[1] = n_bytes;
@@ -1113,7 +1118,11 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
     if (count > 0)
     {
-        const dim3 grid(count), block(DELIVER_BLOCK);
+        // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
+        //  dictionary accumulators)
+        const bool use_small = c->small_slices && !c->im.has_last && !c->has_delay &&
+                               !((c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0);
+        const dim3 grid(count), block(use_small ? 64 : DELIVER_BLOCK);
 #define SANAFE_LAUNCH_DELIVER(F, DLY) \
     hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
 #define SANAFE_LAUNCH_DELIVER_LAST(F) \
@@ -1121,6 +1130,8 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 #define SANAFE_LAUNCH_FORMAT(F)                                      \
     if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(F);               \
     else if (c->has_delay) SANAFE_LAUNCH_DELIVER(F, true);           \
+    else if (use_small)                                              \
+        hipLaunchKernelGGL((deliver_kernel<F, false, false, false, 64>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first); \
     else SANAFE_LAUNCH_DELIVER(F, false)
 // formats 0 and 3 with 32-bit integer accumulators (the per-accumulator bounds hold: acc_shift > 0)
 #define SANAFE_LAUNCH_FORMAT_IACC(F)                                                                                                            \

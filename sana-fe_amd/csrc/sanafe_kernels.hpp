@@ -724,13 +724,15 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 // workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
 // instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
 // (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
-template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false>
-__global__ void __launch_bounds__(DELIVER_BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
+// BLOCK: 256 threads (4 wavefronts share a slice's chunks), or 64 on chips whose slices hold one or two chunks (TrueNorth:
+// ~256 axons per core) -- most of the four wavefronts would idle and hold wave slots.
+template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false, int BLOCK = DELIVER_BLOCK>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, uint32_t first_slice)
 {
-    __shared__ uint32_t s_beg[DELIVER_BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
-    __shared__ __align__(256) uint32_t s_pref[DELIVER_BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
-    __shared__ double s_red[DELIVER_BLOCK / WAVE];
+    __shared__ uint32_t s_beg[BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
+    __shared__ __align__(256) uint32_t s_pref[BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
+    __shared__ double s_red[BLOCK / WAVE];
     constexpr bool DICT16 = (SYN_FMT == 6 || SYN_FMT == 7); // 2-byte words, dictionary-coded weights
     constexpr bool INT_ACC = (SYN_FMT == 7) || IACC;        // 32-bit integer accumulators (see DevImage): format 7 always, formats 0 / 3 when the bounds hold
     static_assert(!IACC || SYN_FMT == 0 || SYN_FMT == 3, "integer accumulators: formats 0, 3 and 7");
@@ -745,7 +747,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool BYTE_TABLE = RUNS && !DICT16;
     constexpr uint32_t RUN_MAX = 8;
     // formats 6, 7: bit 32 + a = "axon a of the run spiked"; formats 0, 4: byte (code11) = "that axon spiked"
-    __shared__ uint32_t s_bits[RUNS ? DELIVER_BLOCK / WAVE : 1][BYTE_TABLE ? RUN_MAX * 64 : RUNS ? RUN_MAX * 8 + 8 : 1];
+    __shared__ uint32_t s_bits[RUNS ? BLOCK / WAVE : 1][BYTE_TABLE ? RUN_MAX * 64 : RUNS ? RUN_MAX * 8 + 8 : 1];
     if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
     if (SYN_FMT == 7 && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
@@ -827,16 +829,16 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const uint4 *st_src = nullptr;
     const double2 *st_wsrc = nullptr;
     uint32_t st_groups = 0, st_pos0 = 0;
-    constexpr uint32_t stride = (DELIVER_BLOCK / WAVE) * WAVE_CHUNK;
-    // Chunk order of a wave: every (DELIVER_BLOCK / WAVE)-th chunk, or with RUNS `run_len` consecutive chunks at a
+    constexpr uint32_t stride = (BLOCK / WAVE) * WAVE_CHUNK;
+    // Chunk order of a wave: every (BLOCK / WAVE)-th chunk, or with RUNS `run_len` consecutive chunks at a
     // time (a power of two, small enough that all waves get chunks of a short slice).
     uint32_t run_len = 1;
     if (RUNS && compact)
-        while (run_len < RUN_MAX && run_len * (DELIVER_BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
+        while (run_len < RUN_MAX && run_len * (BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
     auto next_c = [&](uint32_t c) -> uint32_t {
         if (!RUNS) return c + stride;
         const uint32_t ci = c / WAVE_CHUNK + 1u;
-        return ((ci & (run_len - 1u)) ? ci : ci + (DELIVER_BLOCK / WAVE - 1u) * run_len) * WAVE_CHUNK;
+        return ((ci & (run_len - 1u)) ? ci : ci + (BLOCK / WAVE - 1u) * run_len) * WAVE_CHUNK;
     };
     uint32_t c0 = (uint32_t) wave * run_len * WAVE_CHUNK; // axon offset of the chunk inside the slice
     uint32_t *w_bits = s_bits[RUNS ? wave : 0];
@@ -917,7 +919,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (next_c(c0) < n_ax) load4(next_c(c0) + (uint32_t) lane * AX_PER_THREAD, cur);
     }
     // The accumulators are cleared while the first records and bitmap words are in flight.
-    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * RS; i += BLOCK)
     {
         if (LAST && last_mode)
         {
@@ -1085,7 +1087,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         // the 32 bitmap probes are in flight together: two exposed memory round trips per run, not two per chunk.
         // Phase B: the words of the dense chunks of the run, streamed in one go.  Phase C: chunks with few spiking axons
         // go through the gather path.
-        constexpr uint32_t NW = DELIVER_BLOCK / WAVE;
+        constexpr uint32_t NW = BLOCK / WAVE;
         for (uint32_t r0 = (uint32_t) wave * run_len * WAVE_CHUNK; r0 < n_ax; r0 += NW * run_len * WAVE_CHUNK)
         {
             const uint32_t ci0 = r0 / WAVE_CHUNK;
@@ -1464,7 +1466,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     if (threadIdx.x == 0)
     {
         double p = 0.0;
-        for (int w = 0; w < DELIVER_BLOCK / WAVE; w++) p += s_red[w];
+        for (int w = 0; w < BLOCK / WAVE; w++) p += s_red[w];
         // one value per slice; level 1 of the step reduction adds a core's slices in order (reproducible)
         st.slice_proc[(size_t) (done & 1) * im.n_slices + slice] = p;
     }
@@ -1473,11 +1475,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     if (LAST && last_mode)
     {
         // the latest event over all slices of the core wins: positions grow in delivery order
-        for (uint32_t n = threadIdx.x; n < npad; n += DELIVER_BLOCK)
+        for (uint32_t n = threadIdx.x; n < npad; n += BLOCK)
             if (lastv[n] != 0u) atomicMax(&st.ring_last[nbase + n], lastv[n]);
     }
     else
-    for (uint32_t i = threadIdx.x; i < D * RS; i += DELIVER_BLOCK)
+    for (uint32_t i = threadIdx.x; i < D * RS; i += BLOCK)
     {
         double sum;
         if (INT_ACC)

@@ -253,7 +253,11 @@ def test_plain_accumulator_inside_dendrite_quirk(S):
     check_stepwise(S, arch, net, steps=12)
 
 
-def test_truenorth(S):
+@pytest.mark.parametrize("small", [True, False])
+def test_truenorth(S, monkeypatch, small):
+    """256 axons per core = one chunk per delivery slice: 64-thread delivery workgroups (default) and the 256-thread ones."""
+    if not small:
+        monkeypatch.setenv("SANAFE_DELIVER_SMALL", "0")
     check_stepwise(S, *nets.truenorth_net(S, n_tiles=16, neurons_per_core=256), steps=20)
 
 
