@@ -23,22 +23,37 @@ def short(name):
 import time
 
 summary = {"kernels": {}, "collected_unix": int(time.time())}
-stats = glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True)
+stats = sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(out, "kernel_stats.csv"))
-    with open(stats[0]) as f:
+    shutil.copy(stats[-1], os.path.join(out, "kernel_stats.csv"))
+    with open(stats[-1]) as f:
         for row in csv.DictReader(f):
             k = short(row["Name"])
             if k:
                 summary["kernels"].setdefault(k, {}).update(calls=int(row["Calls"]), avg_ns=float(row["AverageNs"]),
                                                             min_ns=float(row["MinNs"]), max_ns=float(row["MaxNs"]),
                                                             percent=float(row["Percentage"]))
+# The last 20 launches of every kernel = the launches bench.py's roofline pass brackets with HIP events (--timed-steps 20,
+# the last steps of the process): their average is the figure to compare with roofline.avg_launch_ms.  The average over
+# ALL launches above also holds the device warm-up steps, where the clocks are still settling.
+traces = sorted(glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True), key=os.path.getmtime)
+if traces:
+    per = {}
+    with open(traces[-1]) as f:
+        for row in csv.DictReader(f):
+            k = short(row["Kernel_Name"])
+            if k:
+                per.setdefault(k, []).append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+    for k, v in per.items():
+        v.sort()
+        tail = [d for _, d in v[-20:]]
+        summary["kernels"].setdefault(k, {})["avg_ns_last_20_launches"] = sum(tail) / len(tail)
 for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-    files = glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True)
+    files = sorted(glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True), key=os.path.getmtime)
     if not files:
         continue
     rows = []
-    with open(files[0]) as f:
+    with open(files[-1]) as f:
         rd = csv.DictReader(f)
         fields = rd.fieldnames
         for row in rd:
