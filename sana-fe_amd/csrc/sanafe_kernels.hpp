@@ -830,17 +830,13 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const double2 *st_wsrc = nullptr;
     uint32_t st_groups = 0, st_pos0 = 0;
     constexpr uint32_t stride = (BLOCK / WAVE) * WAVE_CHUNK;
-    // Chunk order of a wave: every (BLOCK / WAVE)-th chunk, or with RUNS `run_len` consecutive chunks at a
-    // time (a power of two, small enough that all waves get chunks of a short slice).
+    // Chunk order of a wave: every (BLOCK / WAVE)-th chunk (per-chunk loop), or `run_len` consecutive chunks at a time
+    // (runs; a power of two, small enough that all waves get chunks of a short slice).
     uint32_t run_len = 1;
     if (RUNS && compact)
         while (run_len < RUN_MAX && run_len * (BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
-    auto next_c = [&](uint32_t c) -> uint32_t {
-        if (!RUNS) return c + stride;
-        const uint32_t ci = c / WAVE_CHUNK + 1u;
-        return ((ci & (run_len - 1u)) ? ci : ci + (BLOCK / WAVE - 1u) * run_len) * WAVE_CHUNK;
-    };
-    uint32_t c0 = (uint32_t) wave * run_len * WAVE_CHUNK; // axon offset of the chunk inside the slice
+    auto next_c = [&](uint32_t c) -> uint32_t { return c + stride; };
+    uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // per-chunk loop: axon offset of the chunk inside the slice
     uint32_t *w_bits = s_bits[RUNS ? wave : 0];
     auto stream_preload = [&]() {
         const uint32_t ci = c0 / WAVE_CHUNK;
