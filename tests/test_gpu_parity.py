@@ -343,6 +343,18 @@ def test_several_runs_per_wavefront(S, monkeypatch, force):
     assert info["n_axons"] > 16 * 9000
 
 
+@pytest.mark.parametrize("force", [None, "6", "0"])
+def test_axons_with_two_hundred_synapses(S, monkeypatch, force):
+    """One core, every neuron sends all of its 200 synapses there: a single axon's words span 25 lanes of a group-row
+    (formats 6, 7: only its first word carries the first-synapse bit) and several 16-byte groups."""
+    if force:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, cores_used=1, out_degree=200, arch_kind="loihi", p_fire=0.3, seed=53)
+    chip, _ = check_stepwise(S, arch, net, steps=8)
+    lay = chip.device_layout()
+    assert lay["syn_format"] == {None: 7, "6": 6, "0": 0}[force] and lay["n_compact_slices"] > 0
+
+
 def test_dictionary_coded_float_weights(S):
     """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
