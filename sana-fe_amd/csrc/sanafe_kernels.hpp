@@ -1137,7 +1137,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 uint32_t amask = 0;
 #pragma unroll
                 for (int k = 0; k < AX_PER_THREAD; k++)
-                    amask |= ((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & (((q[j] >> (16 * k + 8)) & 0xffull) != 0ull ? 1u : 0u)) << k;
+                    amask |= min((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & 1u, (uint32_t) (q[j] >> (16 * k + 8)) & 0xffu) << k;
                 const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
                 const bool dense = n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
                 dense_mask |= dense ? (1u << j) : 0u;
@@ -1162,9 +1162,10 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 {
                     // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
                     // in integers here, priced once at the end of the slice
+                    // (a 4 x 8-bit dot product: the synapse counts of the spiking axons)
                     const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
-                    stream_events += ((amask & 1u) ? (lo >> 8) & 0xffu : 0u) + ((amask & 2u) ? lo >> 24 : 0u) +
-                                     ((amask & 4u) ? (hi >> 8) & 0xffu : 0u) + ((amask & 8u) ? hi >> 24 : 0u);
+                    const uint32_t counts = __builtin_amdgcn_perm(hi, lo, 0x07050301u); // bytes 1, 3 of lo and of hi
+                    stream_events = __builtin_amdgcn_udot4(counts, (amask * 0x00204081u) & 0x01010101u, stream_events, false);
                     stream_msgs += (uint32_t) __popc(amask);
                 }
             }
