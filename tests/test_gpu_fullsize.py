@@ -12,7 +12,7 @@ pytestmark = [pytest.mark.gpu, pytest.mark.slow]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 OUT_DEGREE = 2621
-STEPS = 6
+STEPS = int(os.environ.get("SANAFE_FULLSIZE_STEPS", "6"))  # a one-off soak run widens it (120 steps: DESIGN.md)
 
 
 def _run(S, arch, net):
