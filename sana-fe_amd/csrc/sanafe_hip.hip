@@ -612,7 +612,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<uint32_t> chunk0(h.n_slices, 0);
         uint64_t n_chunks = 0, n_bytes = 0;
         bool any_exact = false;
-        const bool runs_format = dict16 || c->syn_format == 0 || c->syn_format == 4; // deliver_kernel: RUNS
+        const bool runs_format = dict16 || c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4; // deliver_kernel: RUNS
         parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t sl = lo; sl < hi; sl++)
             {

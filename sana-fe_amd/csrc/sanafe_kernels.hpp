@@ -741,9 +741,11 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     // Formats 6, 7: a wave takes RUN_MAX consecutive chunks, notes which axons spiked in a bit table and streams the
     // words of all of them in one go (a "run"): the words carry no chunk-relative axon code, so nothing ties the
     // stream to 256 axons, and the fixed cost of starting a stream is paid once per run.
-    // Formats 0 and 4 take runs as well: their words carry an 11-bit axon code = (chunk of the slice & 7) << 8 | axon of the
-    // chunk, which indexes a byte table of 8 x 256 entries.
-    constexpr bool RUNS = DICT16 || SYN_FMT == 0 || SYN_FMT == 4;
+    // Formats 0, 3 and 4 take runs as well, with a byte table of 8 x 256 entries: the words of 0 and 4 carry an 11-bit axon
+    // code = (chunk of the slice & 7) << 8 | axon of the chunk; format 3 has room for the 8-bit axon only and takes the
+    // chunk from the word's POSITION (a chunk's words are 16-byte aligned: a group belongs to one chunk).
+    constexpr bool RUNS = DICT16 || SYN_FMT == 0 || SYN_FMT == 3 || SYN_FMT == 4;
+    constexpr bool CODE11 = (SYN_FMT == 0 || SYN_FMT == 4);
     constexpr bool BYTE_TABLE = RUNS && !DICT16;
     constexpr uint32_t RUN_MAX = 8;
     // formats 6, 7: bit 32 + a = "axon a of the run spiked"; formats 0, 4: byte (code11) = "that axon spiked"
@@ -826,9 +828,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     // Stream path state: the chunk's synapse words, STREAM_DEPTH 16-byte groups per lane loaded ahead.
     uint4 sq[SDEPTH];
     double2 sw[FP_WEIGHTS ? SDEPTH : 1][2]; // the four fp64 weights of each group (format 4)
-    const uint4 *st_src = nullptr;
-    const double2 *st_wsrc = nullptr;
-    uint32_t st_groups = 0, st_pos0 = 0;
     constexpr uint32_t stride = (BLOCK / WAVE) * WAVE_CHUNK;
     // Chunk order of a wave: every (BLOCK / WAVE)-th chunk (per-chunk loop), or `run_len` consecutive chunks at a time
     // (runs; a power of two, small enough that all waves get chunks of a short slice).
@@ -838,31 +837,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     auto next_c = [&](uint32_t c) -> uint32_t { return c + stride; };
     uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // per-chunk loop: axon offset of the chunk inside the slice
     uint32_t *w_bits = s_bits[RUNS ? wave : 0];
-    auto stream_preload = [&]() {
-        const uint32_t ci = c0 / WAVE_CHUNK;
-        const uint32_t s0 = chunk_syn0[ci];
-        st_pos0 = s0;
-        st_groups = (chunk_syn0[ci + 1] - s0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
-        st_src = DICT16 ? reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + s0))
-                                : reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + s0));
-        if (SYN_FMT == 4) st_wsrc = reinterpret_cast<const double2 *>(im.syn_weight + (syn_base + s0));
-        // All loads of the stream are unconditional (past the end: the last group again) and issued in one fixed
-        // pattern: only then can the loads in flight be counted, so that a group waits for ITS load
-        // (vmcnt(SDEPTH - 1)) and not for all of them.
-#pragma unroll
-        for (int u = 0; u < SDEPTH; u++)
-        {
-            const uint32_t g_u = (uint32_t) lane + (uint32_t) u * WAVE;
-            const uint32_t g = g_u < st_groups ? g_u : st_groups - 1u; // streamed chunks hold synapses
-            sq[u] = load_stream16(st_src + g);
-            if (SYN_FMT == 4)
-            {
-                sw[u][0] = st_wsrc[2 * g];
-                sw[u][1] = st_wsrc[2 * g + 1];
-            }
-            keep_load_order();
-        }
-    };
     // The chunk loop is software-pipelined over three loads that depend on each other: axon records ->
     // (pre slots) -> spike-bitmap words -> (which axons spiked) -> synapse words.  While chunk i is delivered,
     // the bitmap words of chunk i+1 and the records of chunk i+2 are in flight.
@@ -1087,89 +1061,98 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         for (uint32_t r0 = (uint32_t) wave * run_len * WAVE_CHUNK; r0 < n_ax; r0 += NW * run_len * WAVE_CHUNK)
         {
             const uint32_t ci0 = r0 / WAVE_CHUNK;
-            unsigned long long q[RUN_MAX];
             uint32_t amask_all = 0;                 // per lane: 4 bits per chunk of the run
             uint32_t dense_mask = 0, gather_mask = 0; // wave-uniform: chunks to stream / to gather
-            // pre slot of each chunk's first axon: lane j fetches chunk j's (one load, broadcast by readlane below)
-            const uint32_t n_here = min(run_len, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK); // chunks of this run inside the slice
-            const uint32_t pre0_lane = chunk_pre0[ci0 + min((uint32_t) lane, n_here - 1u)];
-            // one address, eight immediate offsets: the record array ends in 4 KB of padding, reads past the slice stay in
-            // bounds and are zeroed below
-            const unsigned long long *rec_lane = reinterpret_cast<const unsigned long long *>(rec + 2ull * (r0 + (uint32_t) lane * AX_PER_THREAD));
-#pragma unroll
-            for (uint32_t j = 0; j < RUN_MAX; j++)
-            {
-                q[j] = rec_lane[j * (WAVE_CHUNK * 2u / 8u)];
-                keep_load_order();
-            }
-            // (the bitmap probes in two halves of 16: 32 destination registers at once would spill)
-#pragma unroll
-            for (uint32_t half = 0; half < RUN_MAX; half += RUN_MAX / 2)
-            {
-            if (half >= run_len) continue; // short runs (small slices): nothing in the second half
-            uint32_t word[RUN_MAX / 2][AX_PER_THREAD], shifts[RUN_MAX / 2];
-#pragma unroll
-            for (uint32_t jj = 0; jj < RUN_MAX / 2; jj++)
-            {
-                const uint32_t j = half + jj;
-                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
-                const bool have = j < run_len && a0 < n_ax;
-                if (!have) q[j] = 0ull;
-                const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
-                const uint32_t dl[AX_PER_THREAD] = {lo & 0xffu, (lo >> 16) & 0xffu, hi & 0xffu, (hi >> 16) & 0xffu};
-                const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
-                uint32_t pre = (uint32_t) __builtin_amdgcn_readlane((int) pre0_lane, (int) j) + wave_inclusive_scan(lane_d) - lane_d;
-                shifts[jj] = 0;
-#pragma unroll
-                for (int k = 0; k < AX_PER_THREAD; k++)
+            // N = chunk slots compiled in: 8, or 1 for slices so short that every wave takes single chunks (small chips: no
+            // masked-out decode work, no surplus probes)
+            unsigned long long q_single = 0ull; // the records of a single-chunk run, kept for phase C
+            auto phase_a = [&](auto n_slots) {
+                constexpr uint32_t N = decltype(n_slots)::value, H = N >= 2 ? N / 2 : 1;
+                unsigned long long q[N];
+                // pre slot of each chunk's first axon: lane j fetches chunk j's (one load, broadcast by readlane below)
+                const uint32_t n_here = min(run_len, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK); // chunks of this run inside the slice
+                const uint32_t pre0_lane = chunk_pre0[ci0 + min((uint32_t) lane, n_here - 1u)];
+                // one address, eight immediate offsets: the record array ends in 4 KB of padding, reads past the slice stay in
+                // bounds and are zeroed below
+                const unsigned long long *rec_lane = reinterpret_cast<const unsigned long long *>(rec + 2ull * (r0 + (uint32_t) lane * AX_PER_THREAD));
+    #pragma unroll
+                for (uint32_t j = 0; j < N; j++)
                 {
-                    pre += dl[k];
-                    word[jj][k] = bits[pre >> 5]; // pad axons repeat the slot before them: in bounds
-                    shifts[jj] |= (pre & 31u) << (8 * k);
+                    q[j] = rec_lane[j * (WAVE_CHUNK * 2u / 8u)];
+                    keep_load_order();
                 }
-                keep_load_order();
-            }
-#pragma unroll
-            for (uint32_t jj = 0; jj < RUN_MAX / 2; jj++)
-            {
-                const uint32_t j = half + jj;
-                // (an axon of these formats owns at least one synapse: a zero count marks the records past the end)
-                uint32_t amask = 0;
-#pragma unroll
-                for (int k = 0; k < AX_PER_THREAD; k++)
-                    amask |= min((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & 1u, (uint32_t) (q[j] >> (16 * k + 8)) & 0xffu) << k;
-                const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
-                const bool dense = n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
-                dense_mask |= dense ? (1u << j) : 0u;
-                gather_mask |= (!dense && n_act_lanes > 0) ? (1u << j) : 0u;
-                amask_all |= amask << (4 * j);
-                // Bit table: bit 32 + 256 j + a = "axon a of chunk j spiked" (chunks that are not streamed: zeros).  Eight
-                // lanes' masks make one dword: three DPP steps inside the rows, no LDS atomics.
-                if constexpr (BYTE_TABLE)
+                // (N = 8: the bitmap probes in two halves of 16: 32 destination registers at once would spill)
+    #pragma unroll
+                for (uint32_t half = 0; half < N; half += H)
                 {
-                    // byte table: lane L owns axons 4L..4L+3 of the chunk = one dword of the chunk's 256 bytes
-                    w_bits[64u * ((ci0 + j) & 7u) + (uint32_t) lane] = dense ? (amask * 0x00204081u) & 0x01010101u : 0u;
-                }
-                else
+                if (half >= run_len) continue; // short runs (small slices): nothing in the second half
+                uint32_t word[H][AX_PER_THREAD], shifts[H];
+    #pragma unroll
+                for (uint32_t jj = 0; jj < H; jj++)
                 {
-                    uint32_t m8 = dense ? amask : 0u;
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
-                    m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
-                    if ((lane & 7) == 0) w_bits[1u + 8u * j + ((uint32_t) lane >> 3)] = m8;
-                }
-                if (dense)
-                {
-                    // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
-                    // in integers here, priced once at the end of the slice
-                    // (a 4 x 8-bit dot product: the synapse counts of the spiking axons)
+                    const uint32_t j = half + jj;
+                    const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                    const bool have = j < run_len && a0 < n_ax;
+                    if (!have) q[j] = 0ull;
                     const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
-                    const uint32_t counts = __builtin_amdgcn_perm(hi, lo, 0x07050301u); // bytes 1, 3 of lo and of hi
-                    stream_events = __builtin_amdgcn_udot4(counts, (amask * 0x00204081u) & 0x01010101u, stream_events, false);
-                    stream_msgs += (uint32_t) __popc(amask);
+                    const uint32_t dl[AX_PER_THREAD] = {lo & 0xffu, (lo >> 16) & 0xffu, hi & 0xffu, (hi >> 16) & 0xffu};
+                    const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+                    uint32_t pre = (uint32_t) __builtin_amdgcn_readlane((int) pre0_lane, (int) j) + wave_inclusive_scan(lane_d) - lane_d;
+                    shifts[jj] = 0;
+    #pragma unroll
+                    for (int k = 0; k < AX_PER_THREAD; k++)
+                    {
+                        pre += dl[k];
+                        word[jj][k] = bits[pre >> 5]; // pad axons repeat the slot before them: in bounds
+                        shifts[jj] |= (pre & 31u) << (8 * k);
+                    }
+                    keep_load_order();
                 }
-            }
-            }
+    #pragma unroll
+                for (uint32_t jj = 0; jj < H; jj++)
+                {
+                    const uint32_t j = half + jj;
+                    // (an axon of these formats owns at least one synapse: a zero count marks the records past the end)
+                    uint32_t amask = 0;
+    #pragma unroll
+                    for (int k = 0; k < AX_PER_THREAD; k++)
+                        amask |= min((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & 1u, (uint32_t) (q[j] >> (16 * k + 8)) & 0xffu) << k;
+                    const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
+                    const bool dense = n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
+                    dense_mask |= dense ? (1u << j) : 0u;
+                    gather_mask |= (!dense && n_act_lanes > 0) ? (1u << j) : 0u;
+                    amask_all |= amask << (4 * j);
+                    // Bit table: bit 32 + 256 j + a = "axon a of chunk j spiked" (chunks that are not streamed: zeros).  Eight
+                    // lanes' masks make one dword: three DPP steps inside the rows, no LDS atomics.
+                    if constexpr (BYTE_TABLE)
+                    {
+                        // byte table: lane L owns axons 4L..4L+3 of the chunk = one dword of the chunk's 256 bytes
+                        w_bits[64u * ((ci0 + j) & 7u) + (uint32_t) lane] = dense ? (amask * 0x00204081u) & 0x01010101u : 0u;
+                    }
+                    else
+                    {
+                        uint32_t m8 = dense ? amask : 0u;
+                        m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x101, 0xf, 0xf, true) << 4;  // row_shl:1
+                        m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x102, 0xf, 0xf, true) << 8;  // row_shl:2
+                        m8 |= (uint32_t) __builtin_amdgcn_update_dpp(0, (int) m8, 0x104, 0xf, 0xf, true) << 16; // row_shl:4
+                        if ((lane & 7) == 0) w_bits[1u + 8u * j + ((uint32_t) lane >> 3)] = m8;
+                    }
+                    if (dense)
+                    {
+                        // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
+                        // in integers here, priced once at the end of the slice
+                        // (a 4 x 8-bit dot product: the synapse counts of the spiking axons)
+                        const uint32_t lo = (uint32_t) q[j], hi = (uint32_t) (q[j] >> 32);
+                        const uint32_t counts = __builtin_amdgcn_perm(hi, lo, 0x07050301u); // bytes 1, 3 of lo and of hi
+                        stream_events = __builtin_amdgcn_udot4(counts, (amask * 0x00204081u) & 0x01010101u, stream_events, false);
+                        stream_msgs += (uint32_t) __popc(amask);
+                    }
+                }
+                }
+                if (N == 1) q_single = q[0];
+            };
+            if (run_len == 1) phase_a(std::integral_constant<uint32_t, 1>{});
+            else phase_a(std::integral_constant<uint32_t, RUN_MAX>{});
             if (dense_mask != 0u)
             {
                 // ---- Phase B: stream the words of chunks first_dense .. last_dense ----
@@ -1298,28 +1281,33 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 }
                 else
                 {
-                    // 4 words per lane and group: the word's low 11 bits index the byte table, the next bits ARE the LDS
-                    // accumulator index (lost charge lands in the trash entry)
+                    // 4 words per lane and group: the word's low 11 bits (format 3: its low 8 bits + the chunk of its group)
+                    // index the byte table, the next bits ARE the LDS accumulator index (lost charge lands in the trash entry)
                     const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_bits);
                     const int acc_bias = 1 << im.acc_shift; // integer accumulators: every event adds weight + 2^acc_shift
-                    auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
+                    // format 3: where the chunks of the run end, in groups (lane j: chunk first_dense + j), and the chunk the
+                    // current group-row starts in (scalars)
+                    const uint32_t n_run = last_dense - first_dense + 1u;
+                    const uint32_t end_lane = CODE11 ? 0u : (chunk_syn0[ci0 + first_dense + min((uint32_t) lane, n_run - 1u) + 1u] - run_pos0) / GROUP_WORDS;
+                    uint32_t cur = 0, cur_end = CODE11 ? 0u : (uint32_t) __builtin_amdgcn_readlane((int) end_lane, 0);
+                    auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */, uint32_t tab) {
                         const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
                         const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
                         uint32_t fired[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0x7ffu];
+                        for (int u = 0; u < 4; u++) fired[u] = spiked[CODE11 ? (w4[u] & 0x7ffu) : ((w4[u] & 0xffu) | tab)];
 #pragma unroll
                         for (int u = 0; u < 4; u++)
                             if (fired[u])
                             {
-                                const uint32_t idx = (w4[u] >> 11) & (SYN_FMT == 0 ? 0x1fffu : 0x7fffu);
+                                const uint32_t idx = SYN_FMT == 3 ? (w4[u] >> 8) & 0xfffu : (w4[u] >> 11) & (SYN_FMT == 0 ? 0x1fffu : 0x7fffu);
                                 if (LAST && last_mode)
                                 {
                                     atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
                                     continue;
                                 }
-                                if (INT_ACC) atomicAdd(&acc32[idx], (uint32_t) (((int) w4[u] >> 24) + acc_bias)); // ds_add_u32
-                                else atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> 24));   // ds_add_f64
+                                if (INT_ACC) atomicAdd(&acc32[idx], (uint32_t) (((int) w4[u] >> (SYN_FMT == 3 ? 20 : 24)) + acc_bias)); // ds_add_u32
+                                else atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 3 ? 20 : 24))); // ds_add_f64
                                 if (TOUCH_BYTES) touched[idx] = 1;
                             }
                     };
@@ -1329,8 +1317,22 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         for (int u = 0; u < SDEPTH; u++)
                         {
                             // add, then refill the same registers (the other groups of the window are still in flight)
-                            const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
-                            if (g < run_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], run_pos0 + 4u * g);
+                            const uint32_t r = row + (uint32_t) u * WAVE; // first group of this row (scalar)
+                            const uint32_t g = r + (uint32_t) lane;
+                            uint32_t tab = 0; // format 3: byte-table offset of the group's chunk
+                            if (!CODE11 && r < run_groups)
+                            {
+                                while (r >= cur_end) cur_end = (uint32_t) __builtin_amdgcn_readlane((int) end_lane, (int) ++cur); // (chunks hold words: it ends)
+                                tab = ((ci0 + first_dense + cur) & 7u) << 8;
+                                // chunks that begin inside this row
+                                for (uint32_t c = cur, e = cur_end; e < r + WAVE && c + 1u < n_run;)
+                                {
+                                    c++;
+                                    tab = (g >= e) ? ((ci0 + first_dense + c) & 7u) << 8 : tab;
+                                    e = (uint32_t) __builtin_amdgcn_readlane((int) end_lane, (int) c);
+                                }
+                            }
+                            if (g < run_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], run_pos0 + 4u * g, tab);
                             const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
                             const uint32_t nxt = nxt_g < run_groups ? nxt_g : run_groups - 1u;
                             sq[u] = load_stream16(src + nxt);
@@ -1352,7 +1354,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 gather_mask &= gather_mask - 1u;
                 const uint32_t cg = r0 + j * WAVE_CHUNK;
                 const uint32_t a0 = cg + (uint32_t) lane * AX_PER_THREAD;
-                const unsigned long long qq = (a0 < n_ax) ? *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0) : 0ull;
+                // (longer runs do not keep their records in registers: one more load, L2-hot)
+                const unsigned long long qq = (run_len == 1) ? q_single : (a0 < n_ax) ? *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0) : 0ull;
                 const uint32_t lo = (uint32_t) qq, hi = (uint32_t) (qq >> 32);
                 const uint32_t nsyn[AX_PER_THREAD] = {(lo >> 8) & 0xffu, lo >> 24, (hi >> 8) & 0xffu, hi >> 24};
                 const uint32_t lcls[AX_PER_THREAD] = {0u, 0u, 0u, 0u};
@@ -1365,7 +1368,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     {
         // ---- this chunk: take over what the previous iteration decoded and probed ----
         uint32_t amask = 0, nsyn[AX_PER_THREAD], lcls[AX_PER_THREAD];
-        bool dense = false; // wave-uniform: enough spiking axons to stream the chunk
         if (c0 < n_ax)
         {
 #pragma unroll
@@ -1383,76 +1385,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 const uint32_t c2 = next_c(c1);
                 if (c2 < n_ax) load4(c2 + (uint32_t) lane * AX_PER_THREAD, cur);
             }
-            // STREAM or GATHER?  With many spiking axons nearly every cache line of the chunk's synapses is needed anyway,
-            // so read them all once, in order (16 bytes per lane), and let each word say whether its axon
-            // spiked: no compaction, no ownership search, no per-event address arithmetic.
-            const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
-            dense = STREAMABLE && !RUNS && compact && n_act_lanes >= STREAM_MIN_ACTIVE_LANES;
         }
         if (c0 >= n_ax) break;
         if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
-        if (dense)
-        {
-            {
-                // 256-byte table: byte a = "axon a of the chunk spiked"; lane L owns axons 4L..4L+3 = one dword
-                w_pref[lane] = (amask * 0x00204081u) & 0x01010101u;
-                wave_lds_fence();
-                stream_preload();
-                const uint8_t *spiked = reinterpret_cast<const uint8_t *>(w_pref);
-                const int acc_bias = 1 << im.acc_shift; // integer accumulators: every event adds weight + 2^acc_shift
-                auto add4 = [&](const uint4 &g, const double2 (&wq)[2], uint32_t pos0 /* position of g.x among the core's synapses */) {
-                    const uint32_t w4[4] = {g.x, g.y, g.z, g.w};
-                    const double f4[4] = {wq[0].x, wq[0].y, wq[1].x, wq[1].y};
-                    uint32_t fired[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) fired[u] = spiked[w4[u] & 0xffu];
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (fired[u])
-                        {
-                            const uint32_t idx = (w4[u] >> 8) & 0xfffu; // (format 3: the other streamable formats take runs)
-                            if (LAST && last_mode)
-                            {
-                                atomicMax(&lastv[idx], pos0 + (uint32_t) u + 1u);
-                                continue;
-                            }
-                            // ds_add_u32 / ds_add_f64 (lost charge lands in the trash entry)
-                            if (INT_ACC) atomicAdd(&acc32[idx], (uint32_t) (((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)) + acc_bias));
-                            else atomicAdd(&acc[idx], SYN_FMT == 4 ? f4[u] : (double) ((int) w4[u] >> (SYN_FMT == 0 ? 24 : 20)));
-                            if (TOUCH_BYTES) touched[idx] = 1;
-                        }
-                };
-                // rolling window: SDEPTH 16-byte groups per lane in flight while one is added
-                for (uint32_t row = 0; row < st_groups; row += WAVE * SDEPTH) // row: first group of the wave's group-row (a scalar)
-                {
-#pragma unroll
-                    for (int u = 0; u < SDEPTH; u++)
-                    {
-                        // add, then refill the same registers (the other groups of the window are still in flight)
-                        const uint32_t g = row + (uint32_t) u * WAVE + (uint32_t) lane;
-                        if (g < st_groups) add4(sq[u], sw[FP_WEIGHTS ? u : 0], st_pos0 + 4u * g);
-                        // unconditional refill (past the end: the last group again), so that the loads in flight can be
-                        // counted and a group waits for its own load only
-                        const uint32_t nxt_g = g + (uint32_t) SDEPTH * WAVE;
-                        const uint32_t nxt = nxt_g < st_groups ? nxt_g : st_groups - 1u;
-                        sq[u] = load_stream16(st_src + nxt);
-                        if (SYN_FMT == 4)
-                        {
-                            sw[u][0] = st_wsrc[2 * nxt];
-                            sw[u][1] = st_wsrc[2 * nxt + 1];
-                        }
-                        keep_load_order();
-                    }
-                }
-                // processing delay of the chunk's messages: axon-in latency per message + per-event latency; counted
-                // in integers here, priced once at the end of the slice
-#pragma unroll
-                for (int k = 0; k < AX_PER_THREAD; k++) stream_events += (amask & (1u << k)) ? nsyn[k] : 0u;
-                stream_msgs += (uint32_t) __popc(amask);
-                wave_lds_fence(); // w_pref is rewritten by the next chunk
-                continue;
-            }
-        }
         gather_chunk(c0, amask, nsyn, lcls);
     }
     // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
