@@ -1075,19 +1075,19 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 // one address, eight immediate offsets: the record array ends in 4 KB of padding, reads past the slice stay in
                 // bounds and are zeroed below
                 const unsigned long long *rec_lane = reinterpret_cast<const unsigned long long *>(rec + 2ull * (r0 + (uint32_t) lane * AX_PER_THREAD));
-    #pragma unroll
+#pragma unroll
                 for (uint32_t j = 0; j < N; j++)
                 {
                     q[j] = rec_lane[j * (WAVE_CHUNK * 2u / 8u)];
                     keep_load_order();
                 }
                 // (N = 8: the bitmap probes in two halves of 16: 32 destination registers at once would spill)
-    #pragma unroll
+#pragma unroll
                 for (uint32_t half = 0; half < N; half += H)
                 {
                 if (half >= run_len) continue; // short runs (small slices): nothing in the second half
                 uint32_t word[H][AX_PER_THREAD], shifts[H];
-    #pragma unroll
+#pragma unroll
                 for (uint32_t jj = 0; jj < H; jj++)
                 {
                     const uint32_t j = half + jj;
@@ -1099,7 +1099,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
                     uint32_t pre = (uint32_t) __builtin_amdgcn_readlane((int) pre0_lane, (int) j) + wave_inclusive_scan(lane_d) - lane_d;
                     shifts[jj] = 0;
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < AX_PER_THREAD; k++)
                     {
                         pre += dl[k];
@@ -1108,13 +1108,13 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     }
                     keep_load_order();
                 }
-    #pragma unroll
+#pragma unroll
                 for (uint32_t jj = 0; jj < H; jj++)
                 {
                     const uint32_t j = half + jj;
                     // (an axon of these formats owns at least one synapse: a zero count marks the records past the end)
                     uint32_t amask = 0;
-    #pragma unroll
+#pragma unroll
                     for (int k = 0; k < AX_PER_THREAD; k++)
                         amask |= min((word[jj][k] >> ((shifts[jj] >> (8 * k)) & 31u)) & 1u, (uint32_t) (q[j] >> (16 * k + 8)) & 0xffu) << k;
                     const uint32_t n_act_lanes = (uint32_t) __popcll(__ballot(amask != 0)); // lanes with a spiking axon
