@@ -385,6 +385,14 @@ def test_integer_accumulators_zero_sums_and_sparse_spikes(S, monkeypatch):
         blk[2][:] = rng.choice([-2097152.0, 3.0, 1048576.0], size=len(blk[2]))
     chip, _ = check_stepwise(S, arch, net, steps=8)
     assert chip.device_layout()["syn_format"] == 6  # integers, but no int8/int12 form and outside the bounds of 7
+    # one weight value (a dictionary of one), but 255 x 127 per accumulator needs a 17-bit biased weight: too wide for the
+    # 16-bit table of format 7 -> 4-byte int8 words, still with integer accumulators (shift 16)
+    arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, cores_used=1, out_degree=255, arch_kind="loihi", p_fire=0.4, seed=40)
+    for blk in net._edge_blocks:
+        blk[2][:] = 127.0
+    chip, _ = check_stepwise(S, arch, net, steps=8)
+    lay = chip.device_layout()
+    assert lay["syn_format"] == 0 and lay["acc_shift"] == 16
 
 
 @pytest.mark.parametrize("weights,fmt", [("int12", 3), ("float", 4)])
