@@ -883,7 +883,8 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     try
     {
         // SANAFE_TARGET_SLICES: delivery work items to aim for (tests use it to force multi-slice cores)
-        uint32_t target_slices = 16384; // many more work items than the 2048 resident workgroups: no tail
+        uint32_t target_slices = 8192; // several times the ~1,300 resident workgroups (no tail), few enough that a big core's
+                                       // write-back is shared by 16 slices, not 32 (C3: 8 k 0.303 ms, 16 k 0.308 ms, 4 k 0.306 ms)
         if (const char *env = std::getenv("SANAFE_TARGET_SLICES")) target_slices = static_cast<uint32_t>(std::max(1L, std::atol(env)));
         uint32_t min_slice_axons = 1024; // one 256-axon chunk per wavefront: small chips still spread over many CUs
         if (const char *env = std::getenv("SANAFE_MIN_SLICE_AXONS")) min_slice_axons = static_cast<uint32_t>(std::max(4L, std::atol(env)));

@@ -1450,7 +1450,11 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     // ------------------------------------------------------------------ delivery slices
     {
         const uint64_t A = mc.ax_pre.size();
-        const uint64_t chunk = std::max<uint64_t>(std::max<uint32_t>(4, min_slice_axons & ~3u), ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
+        // Slice size: a multiple of 1,024 axons (one 256-axon chunk per wavefront of the delivery workgroup); large slices
+        // a multiple of 8,192 (one run of 8 chunks per wavefront, deliver_kernel), so that the four wavefronts of a
+        // workgroup finish together -- 17 k-axon slices cost 3 % against 16 k, 10 k-axon ones 8 % against 8 k (measured).
+        uint64_t chunk = std::max<uint64_t>(std::max<uint32_t>(4, min_slice_axons & ~3u), ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
+        if (chunk > 8192) chunk = (chunk + 8191) & ~8191ull;
         for (uint32_t k = 0; k < LC; k++)
         {
             uint64_t b = core_axon_beg[k];
