@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the SANA-FE timestep loop on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N=1 by default)
+    python bench.py --gpus N --steps K --warmup W        (N=1 by default; N>1 launches its own N ranks)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   (N>1, one rank per GPU)
 
 Workload (BASELINE.json configs[2], made concrete in SURVEY 8d): arch/loihi_large.yaml + a synthetic
-random SNN of 262,144 LIF neurons per GPU (512 neurons on each of 512 cores), out-degree 2,621
+random SNN of 262,144 LIF neurons per GPU (256 neurons on each of 1,024 cores), out-degree 2,621
 (1 % of 262,144), integer weights, `loihi_dendrites_delay` dendrites, 10 % of the neurons biased to
 fire every step; `simple` timing model on the device.  With N GPUs the tiles are sharded in
 contiguous blocks, every GPU holds 262,144 neurons (weak scaling) and the only exchange per step is
@@ -141,7 +141,7 @@ def host_info():
 
 def _time_oracle(chip, timing, seconds, repeats=3):
     """`repeats` timed windows of seconds/repeats each; returns the window with the MEDIAN step rate."""
-    for _ in range(3):
+    for _ in range(2):
         chip.step(timing)
     runs = []
     for _ in range(repeats):
@@ -160,28 +160,38 @@ def _time_oracle(chip, timing, seconds, repeats=3):
 
 
 def cpu_baseline_same_net(S, args, arch, net, what):
-    """The oracle on the very network the GPU ran (small configurations), for about --cpu-seconds."""
+    """The oracle on the very network the GPU ran (small configurations), for about --cpu-seconds: single-threaded and
+    with OpenMP over cores on the host's physical cores, like the reference (src/chip.cpp:629-632, 675-678)."""
     from oracle.oracle import OracleChip
     lower = S.cpp.to_desc if isinstance(net, S.cpp.Network) else S.to_desc
     chip = OracleChip(lower(arch, net))
     timing = args.timing
-    m = _time_oracle(chip, timing, args.cpu_seconds)
-    return {"value": m["steps_per_s"], "unit": "timesteps/s", "cores": 1, "kind": "port",
-            "sample": "oracle (scalar C++ port, 1 thread), %s timing, on %s: median of 3 windows (%d steps in %.1f s)"
-                      % (timing, what, m["steps"], m["seconds"]),
-            "host": host_info(),
-            "measured": {"synaptic_events_per_s": m["events_per_s"], "neuron_updates_per_s": m["updates_per_s"],
-                         "timesteps_per_s_windows": m["all_steps_per_s"]}}
+    host = host_info()
+    n_all = max(1, min(host["physical_cores"] or host["usable_cpus"], host["usable_cpus"]))
+    runs = {}
+    for threads in sorted({1, n_all}):
+        chip.set_threads(threads)
+        runs[threads] = _time_oracle(chip, timing, args.cpu_seconds / 2)
+    best_t = max(runs, key=lambda t: runs[t]["steps_per_s"])
+    m = runs[best_t]
+    return {"value": m["steps_per_s"], "unit": "timesteps/s", "cores": best_t, "kind": "port",
+            "sample": "oracle (C++ port of the reference loop, OpenMP over cores), %s timing, on %s: median of 3 windows per thread "
+                      "count; value = the faster one (%d threads: %d steps in %.1f s)" % (timing, what, best_t, m["steps"], m["seconds"]),
+            "host": host,
+            "by_threads": {str(t): {"value": r["steps_per_s"], "synaptic_events_per_s": r["events_per_s"],
+                                    "neuron_updates_per_s": r["updates_per_s"], "timesteps_per_s_windows": r["all_steps_per_s"]}
+                           for t, r in runs.items()}}
 
 
 def cpu_baseline(S, args):
-    """The oracle (a scalar CPU port of the reference loop) on a bounded sample of the same recipe."""
+    """The oracle (a CPU port of the reference loop) on a bounded sample of the same recipe, single-threaded and with
+    the reference's OpenMP-over-cores parallelism (src/chip.cpp:629-632, 675-678) on the host's physical cores."""
     import nets  # noqa: F401
     from oracle.oracle import OracleChip
-    cores, npc = 64, 256
+    cores, npc = 128, 256
     n = cores * npc
     deg = max(8, n // 100)
-    arch = S.presets.loihi_large(n_tiles=16, n_inputs=4, width=4, height=4)
+    arch = S.presets.loihi_large(n_tiles=32, n_inputs=4, width=8, height=4)
     net = S.Network("sample")
     g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
                                 "loihi_dendrites_delay", False, True, "loihi_lif")
@@ -192,14 +202,29 @@ def cpu_baseline(S, args):
     ac = arch.cores()
     for c in range(cores):
         g.map_to_core(ac[c], c * npc, (c + 1) * npc)
+    t0 = time.perf_counter()
     chip = OracleChip(S.cpp.to_desc(arch, net))
-    m = _time_oracle(chip, "simple", args.cpu_seconds)
-    m["sample"] = ("oracle (scalar C++ port, 1 thread) on %d LIF neurons / %d cores, out-degree %d: median of 3 windows "
-                   "(%d steps in %.1f s)" % (n, cores, deg, m["steps"], m["seconds"]))
-    return m
+    build_s = time.perf_counter() - t0
+    host = host_info()
+    n_all = max(1, min(cores, host["physical_cores"] or host["usable_cpus"], host["usable_cpus"]))
+    runs = {}
+    for threads in sorted({1, n_all}):
+        chip.set_threads(threads)
+        # a third of the budget for the single-threaded windows, the rest for all cores (their steps are short)
+        m = _time_oracle(chip, "simple", args.cpu_seconds * (0.6 if threads == 1 else 0.4))
+        m["threads"] = threads
+        runs[threads] = m
+    best = max(runs.values(), key=lambda r: r["events_per_s"])
+    best = dict(best)
+    best["runs"] = runs
+    best["build_s"] = build_s
+    best["sample"] = ("oracle (C++ port of the reference loop, OpenMP over cores like src/chip.cpp:629-632, 675-678) on %d LIF "
+                      "neurons / %d cores, out-degree %d (%d synapses, built in %.1f s): median of 3 windows per thread count"
+                      % (n, cores, deg, n * deg, build_s))
+    return best
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -211,8 +236,8 @@ def main():
     ap.add_argument("--timing", choices=("simple", "detailed"), default="simple",
                     help="detailed: NoC schedule on host scheduler threads (1 GPU; reported, not the line of record)")
     ap.add_argument("--scheduler-threads", type=int, default=8)
-    ap.add_argument("--cores-per-gpu", type=int, default=512)
-    ap.add_argument("--neurons-per-core", type=int, default=512)
+    ap.add_argument("--cores-per-gpu", type=int, default=1024, help="c3: SURVEY 8(d): 256 neurons on each of 1,024 cores")
+    ap.add_argument("--neurons-per-core", type=int, default=256)
     ap.add_argument("--out-degree", type=int, default=2621)
     ap.add_argument("--p-fire", type=float, default=0.1)
     ap.add_argument("--weights", choices=("int8", "int12", "float", "int8wide", "floatwide"), default="int8",
@@ -220,17 +245,125 @@ def main():
                          "~240 distinct integers in +-127, or a different non-integer per synapse")
     ap.add_argument("--device-warmup", type=int, default=64,
                     help="c3: steps simulated and then undone by chip.reset() before the W warm-up steps -- the GPU's clocks "
-                         "need ~30 ms of load to settle (profiles/r02_step_profile.txt); 0 switches it off")
+                         "need ~30 ms of load to settle (profiles/r02_step_profile.txt); 0 switches it off.  The line carries "
+                         "the rate without it as well (value_without_device_warmup)")
     ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--timed-steps", type=int, default=20, help="steps of the event-timed roofline pass")
+    ap.add_argument("--traffic", choices=("inline", "stored", "none"), default="inline",
+                    help="roofline.traffic (HBM bytes from the PMC counters): inline = two rocprofv3 --pmc child runs of this very "
+                         "command (FETCH_SIZE, WRITE_SIZE: separate passes) BEFORE this process touches the GPU; stored = the "
+                         "newest profiles/*/summary.json of the same workload (marked as not from this run); none = null")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)  # the run rocprofv3 --pmc wraps: steps only
     ap.add_argument("--exchange", choices=("nccl", "host"), default="nccl",
                     help="N>1 spike exchange: RCCL all-gather on device buffers (default) or gloo through host memory "
                          "(functional check of the multi-rank path on a single GPU)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use device 0 (with --exchange host)")
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group + exchange) even with one rank")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as CHILD processes (this process has
+    not touched the GPU and never will), relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0 = procs[0].stdout.read()
+    codes = [p.wait() for p in procs]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: ranks failed (rank, exit code): %s\n" % bad)
+        raise SystemExit(1)
+    raise SystemExit(0)
+
+
+def collect_traffic_inline(args, n_launch_tail):
+    """HBM bytes per launch of the two kernels from the PMC counters of THIS command: two child runs under
+    `rocprofv3 --kernel-trace --pmc <counter>` (FETCH_SIZE and WRITE_SIZE do not share a pass; --pmc is never combined
+    with API tracing), each simulating the same steps as this process; averaged over the last `n_launch_tail` launches
+    (the steps the event-timed roofline pass brackets).  gfx950 corrections as MI355X_MICROARCH.md prescribes:
+    FETCH_SIZE in KiB, doubled (128-byte requests tallied at 64); WRITE_SIZE in KiB.  Runs BEFORE this process touches
+    the GPU (children only).  Returns None on any failure (the line then says so)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    total_steps = args.warmup + args.steps + args.timed_steps
+    passthrough = []
+    skip = 0
+    for a in sys.argv[1:]:
+        if skip:
+            skip -= 1
+            continue
+        if a in ("--steps", "--warmup", "--device-warmup", "--timed-steps", "--traffic", "--cpu-seconds"):
+            skip = 1
+            continue
+        if a.startswith(("--steps=", "--warmup=", "--device-warmup=", "--timed-steps=", "--traffic=", "--cpu-seconds=")) \
+                or a == "--no-cpu-baseline":
+            continue
+        passthrough.append(a)
+    res = {}
+    tmp = tempfile.mkdtemp(prefix="sanafe_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--",
+                   sys.executable, os.path.abspath(__file__)] + passthrough + \
+                  ["--pmc-child", "--steps", str(total_steps), "--warmup", "0", "--device-warmup", "0", "--timed-steps", "0",
+                   "--no-cpu-baseline", "--traffic", "none"]
+            try:
+                p = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                   stderr=subprocess.PIPE, timeout=420)
+            except subprocess.TimeoutExpired:
+                return None, "rocprofv3 --pmc %s child timed out" % counter
+            if p.returncode != 0:
+                return None, "rocprofv3 --pmc %s child failed (%d): %s" % (counter, p.returncode, p.stderr.decode()[-300:])
+            rows = {}
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row["Counter_Name"] != counter:
+                            continue
+                        k = "deliver_kernel" if "deliver_kernel" in row["Kernel_Name"] else \
+                            "neuron_kernel" if "neuron_kernel" in row["Kernel_Name"] else None
+                        if k:
+                            rows.setdefault(k, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
+            for k, v in rows.items():
+                v.sort()
+                tail = [x for _, x in v[-n_launch_tail:]]
+                res.setdefault(k, {})[counter + "_KiB_avg"] = sum(tail) / len(tail)
+                res[k][counter + "_launches_averaged"] = len(tail)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    for k, d in res.items():
+        if "FETCH_SIZE_KiB_avg" in d and "WRITE_SIZE_KiB_avg" in d:
+            d["fetch_bytes_corrected"] = 2.0 * 1024.0 * d["FETCH_SIZE_KiB_avg"]
+            d["write_bytes"] = 1024.0 * d["WRITE_SIZE_KiB_avg"]
+            d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected"] + d["write_bytes"]
+    if "deliver_kernel" not in res or "hbm_bytes_per_launch" not in res["deliver_kernel"]:
+        return None, "no deliver_kernel counter rows in the rocprofv3 output"
+    return res, None
+
+
+def main():
+    args = parse_args()
+    if "RANK" not in os.environ and args.gpus > 1 and not args.pmc_child:
+        launch_ranks(args)  # does not return
 
     # Libraries (RCCL's version banner, gloo's connection notes) write to stdout; the contract is ONE
     # JSON line there, so everything else is sent to stderr and the line goes to the saved descriptor.
@@ -247,8 +380,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    multi = world > 1 or args.force_dist
+    want_roof = args.timed_steps > 0 and args.timing == "simple" and not multi and not args.pmc_child
+    # ---- PMC passes first: children only, before this process initialises the GPU ----
+    pmc, pmc_error = None, None
+    if want_roof and args.traffic == "inline":
+        t_pmc = time.perf_counter()
+        pmc, pmc_error = collect_traffic_inline(args, args.timed_steps)
+        t_pmc = time.perf_counter() - t_pmc
     import _sanafe_pkg
     S = _sanafe_pkg.load()
 
@@ -283,7 +423,6 @@ def main():
     dev = chip.device_handle()
 
     dist = None
-    multi = world > 1 or args.force_dist
     if multi:
         # Control plane (rendezvous, barrier, max-over-ranks of the wall time): torch.distributed over gloo.
         # Data plane: the product's own per-step spike exchange inside chip.sim() -- RCCL all-gather on the device
@@ -303,35 +442,50 @@ def main():
     def sync():
         chip.synchronize()
 
+    def timed_region():
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        run_steps(args.warmup)
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        data = run_steps(args.steps)
+        sync()
+        if dist:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist:
+            import torch
+            tmax = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax[0])
+        return data, dt
+
+    if args.pmc_child:  # the run rocprofv3 --pmc wraps: the same steps of the same simulation, nothing else
+        run_steps(args.steps)
+        sync()
+        return
+
     # Device warm-up, NOT part of the workload: the first ~30 ms of load after an idle period run at unsettled clocks
-    # (the same steps repeated after a reset are 10-25 % faster, profiles/r02_step_profile.txt).  Simulate, then put the
-    # chip back into its initial state, so the W warm-up steps and the K timed steps are steps 1..W+K of the simulation.
+    # (the same steps repeated after a reset are 10-25 % faster, profiles/r02_step_profile.txt).  The line carries BOTH
+    # rates: first steps 1..W+K right after load() (value_without_device_warmup), then -- after chip.reset(), the device
+    # warm-up steps and another chip.reset() -- steps 1..W+K of the same simulation again at settled clocks (value).
     device_warmup = args.device_warmup if args.workload == "c3" and args.timing == "simple" else 0
+    cold = None
     if device_warmup > 0:
+        _, cold_elapsed = timed_region()
+        cold = args.steps / cold_elapsed
+        chip.reset()
         run_steps(device_warmup)
         sync()
         chip.reset()
-    run_steps(args.warmup)
-    sync()
-    if dist:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    run_data = run_steps(args.steps)
-    sync()
-    if dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+    run_data, elapsed = timed_region()
     agg = {k: float(run_data[k]) for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired")}
-    if dist:
-        import torch
-        tmax = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax[0])
 
     # ---- roofline pass: HIP events around every kernel on its own stream (one rank, the chip's own stream) ----
     roof = None
-    if args.timed_steps > 0 and args.timing == "simple" and not multi:
+    if want_roof:
         H.sanafe_hip_set_timing(dev, 1)
         b2 = chip.read_totals()
         if H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
@@ -344,14 +498,11 @@ def main():
         msgs = (a2["packets_sent"] - b2["packets_sent"]) / args.timed_steps
         upd = (a2["neurons_updated"] - b2["neurons_updated"]) / args.timed_steps
         fired = (a2["neurons_fired"] - b2["neurons_fired"]) / args.timed_steps
-        # (1) the contract's figure -- SURVEY 8(d): 48 B per neuron update, 28 B per synaptic event, 96 B per message.
-        #     The delivery kernel does the per-event and per-message work, the neuron kernel the per-neuron work.
-        deliver_bytes = 28.0 * ev + 96.0 * msgs
-        achieved = deliver_bytes / (dm.value * 1e-3) / 1e9 if dm.value > 0 else 0.0
-        # (2) what THIS design has to move per launch, from the chip's own layout (sanafe_hip_layout_bytes):
-        #     delivery = synapse words + axon records + chunk tables + slice descriptors + spike bitmap, each read once
-        #     when every chunk is streamed (an upper bound when few axons spike), + one 17-byte write-back per neuron;
-        #     neuron launch = per-slot state read + written, + 40 B per fired neuron.
+        # (1) ALGORITHMIC bytes of one launch = what THIS layout has to move, from the chip's own tables
+        #     (sanafe_hip_layout_bytes): delivery = synapse words + axon records + chunk tables + slice descriptors + spike
+        #     bitmap, each read once when every chunk is streamed (an upper bound when few axons spike), + one 17-byte
+        #     write-back per neuron; neuron launch = per-slot state read + written, + 40 B per fired neuron.  DESIGN.md 5
+        #     states the per-unit figures.  achieved = these bytes / the HIP-event-timed launch duration of THIS run.
         lay = (C.c_uint64 * 8)()
         H.sanafe_hip_layout_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         if H.sanafe_hip_layout_bytes(dev, lay, 8) != 0:
@@ -359,65 +510,92 @@ def main():
         lay = [int(x) for x in lay]
         design_deliver = float(sum(lay[0:5])) + 17.0 * upd
         design_neuron = float(lay[5] + lay[6]) + lay[7] * fired
+        # (2) SURVEY 8(d)'s byte model (48 B per neuron update, 28 B per synaptic event, 96 B per message): it prices
+        #     12-byte synapses, HBM accumulators and materialised 40-byte messages, none of which this design moves, so
+        #     on dense workloads it exceeds 1 -- kept as a secondary figure only (frac_contract_model).
+        contract_deliver = 28.0 * ev + 96.0 * msgs
+
+        def gbps(nbytes, ms):
+            return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+
+        achieved = gbps(design_deliver, dm.value)
         roof = {"bound": "hbm", "kernel": "deliver_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "algorithmic_bytes_per_launch": deliver_bytes, "avg_launch_ms": dm.value,
-                "design_bytes_per_launch": design_deliver,
-                "design_bytes_parts": {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
-                                       "slice_descriptors": lay[3], "spike_bitmap": lay[4], "write_back": 17.0 * upd},
-                "frac_design": design_deliver / (dm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if dm.value > 0 else 0.0,
-                "neuron_kernel": {"avg_launch_ms": nm.value, "algorithmic_bytes_per_launch": 48.0 * upd,
-                                  "achieved_GBps": (48.0 * upd) / (nm.value * 1e-3) / 1e9 if nm.value > 0 else 0.0,
-                                  "frac": (48.0 * upd) / (nm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if nm.value > 0 else 0.0,
-                                  "design_bytes_per_launch": design_neuron,
-                                  "frac_design": design_neuron / (nm.value * 1e-3) / 1e9 / HBM_PEAK_GBS if nm.value > 0 else 0.0},
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_this_run": False,
+                "algorithmic_bytes_per_launch": design_deliver, "avg_launch_ms": dm.value,
+                "algorithmic_bytes_parts": {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
+                                            "slice_descriptors": lay[3], "spike_bitmap": lay[4], "write_back": 17.0 * upd},
+                "units_per_launch": {"synaptic_events": ev, "messages": msgs, "neurons_updated": upd, "neurons_fired": fired,
+                                     "synapses_streamed": int(info["n_synapses"]), "axons_probed": int(info["n_axons"])},
+                "contract_model_bytes_per_launch": contract_deliver,
+                "frac_contract_model": gbps(contract_deliver, dm.value) / HBM_PEAK_GBS,
+                "neuron_kernel": {"avg_launch_ms": nm.value, "algorithmic_bytes_per_launch": design_neuron,
+                                  "achieved_GBps": gbps(design_neuron, nm.value),
+                                  "frac": gbps(design_neuron, nm.value) / HBM_PEAK_GBS,
+                                  "contract_model_bytes_per_launch": 48.0 * upd,
+                                  "frac_contract_model": gbps(48.0 * upd, nm.value) / HBM_PEAK_GBS},
                 "reduce_kernel_avg_ms": rm.value, "launches": ln.value,
-                "whole_step": {"algorithmic_bytes": 48.0 * upd + deliver_bytes,
-                               "achieved_GBps": (48.0 * upd + deliver_bytes) / ((nm.value + dm.value + rm.value) * 1e-3) / 1e9}}
+                "whole_step": {"algorithmic_bytes": design_neuron + design_deliver,
+                               "achieved_GBps": gbps(design_neuron + design_deliver, nm.value + dm.value + rm.value)}}
 
     if roof is not None:
-        # (3) HBM bytes per launch as the PMC counters saw them on this very workload (profiles/collect.sh,
-        #     summarize.py: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, plus WRITE_SIZE; separate
-        #     --pmc passes, so they come from an earlier run of the same command -- source and date are given).
-        import glob
-        newest = -1
-        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
-            try:
-                with open(path) as f:
-                    summ = json.load(f)
-                if summ["bench_line"]["config"]["workload"] == workload and "hbm_bytes_per_launch" in summ["kernels"]["deliver_kernel"] \
-                        and summ.get("collected_unix", 0) > newest:
-                    newest = summ.get("collected_unix", 0)
-                    roof["traffic"] = summ["kernels"]["deliver_kernel"]["hbm_bytes_per_launch"]
-                    roof["traffic_source"] = os.path.relpath(path, ROOT)
-                    roof["traffic_collected_utc"] = time.strftime("%Y-%m-%d %H:%M", time.gmtime(newest)) if newest > 0 else None
-                    nk = summ["kernels"].get("neuron_kernel", {})
-                    if "hbm_bytes_per_launch" in nk:
-                        roof["neuron_kernel"]["traffic"] = nk["hbm_bytes_per_launch"]
-            except (KeyError, TypeError, ValueError, OSError):
-                continue
+        # (3) HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
+        #     plus WRITE_SIZE; separate --pmc passes): collected by this very command in two rocprofv3 child runs
+        #     (--traffic inline, the default), or -- marked as NOT from this run -- read from the newest stored
+        #     profiles/*/summary.json of the same workload.
+        if pmc is not None:
+            roof["traffic"] = pmc["deliver_kernel"]["hbm_bytes_per_launch"]
+            roof["traffic_from_this_run"] = True
+            roof["traffic_source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child runs of this command "
+                                      "(%.0f s), averaged over the last %d launches" % (t_pmc, args.timed_steps))
+            roof["traffic_counters"] = pmc["deliver_kernel"]
+            if "hbm_bytes_per_launch" in pmc.get("neuron_kernel", {}):
+                roof["neuron_kernel"]["traffic"] = pmc["neuron_kernel"]["hbm_bytes_per_launch"]
+        elif args.traffic != "none":
+            if pmc_error:
+                roof["traffic_inline_error"] = pmc_error
+            import glob
+            newest = -1
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "summary.json"))):
+                try:
+                    with open(path) as f:
+                        summ = json.load(f)
+                    if summ["bench_line"]["config"]["workload"] == workload and "hbm_bytes_per_launch" in summ["kernels"]["deliver_kernel"] \
+                            and summ.get("collected_unix", 0) > newest:
+                        newest = summ.get("collected_unix", 0)
+                        roof["traffic"] = summ["kernels"]["deliver_kernel"]["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = "STORED, not from this run: " + os.path.relpath(path, ROOT)
+                        roof["traffic_collected_utc"] = time.strftime("%Y-%m-%d %H:%M", time.gmtime(newest)) if newest > 0 else None
+                        nk = summ["kernels"].get("neuron_kernel", {})
+                        if "hbm_bytes_per_launch" in nk:
+                            roof["neuron_kernel"]["traffic"] = nk["hbm_bytes_per_launch"]
+                except (KeyError, TypeError, ValueError, OSError):
+                    continue
         if roof["traffic"]:
             roof["traffic_GBps"] = roof["traffic"] / (roof["avg_launch_ms"] * 1e-3) / 1e9
             roof["traffic_frac_of_peak"] = roof["traffic_GBps"] / HBM_PEAK_GBS
-        roof["note"] = ("achieved/frac price the launch with SURVEY 8(d)'s byte model (28 B per synaptic event + 96 B per message), "
-                        "which assumes materialised 40-byte messages and 12-byte synapses"
-                        + ("; frac > 1 because this design never materialises messages and packs a synapse in %.1f bytes, so it moves "
-                           "%.1fx fewer bytes than the model" % (lay[0] / max(1.0, float(info["n_synapses"])), deliver_bytes / max(1.0, design_deliver))
-                           if roof["frac"] > 1.0 else "")
-                        + "; frac_design prices the same event-timed launch with the bytes of the chip's own layout "
-                          "(design_bytes_parts); traffic* are the HBM bytes the PMC counters measured for this workload "
-                          "(traffic_source, traffic_collected_utc) over the event-timed duration of this run")
+            roof["traffic_over_algorithmic"] = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+        roof["note"] = ("achieved = algorithmic_bytes_per_launch (the bytes of the chip's own device layout, "
+                        "algorithmic_bytes_parts: %.2f B per synapse word, %.2f B per axon record + tables, 17 B per written-back "
+                        "neuron) / avg_launch_ms (HIP events on the kernels' stream, this run); frac = achieved / peak.  "
+                        "frac_contract_model prices the same launch with SURVEY 8(d)'s model (28 B per synaptic event + 96 B per "
+                        "message: materialised 40-byte messages, 12-byte synapses, HBM accumulators -- %.1fx the bytes this "
+                        "design moves) and is not a roofline fraction.  traffic = FETCH_SIZE x 2 + WRITE_SIZE per launch."
+                        % (lay[0] / max(1.0, float(info["n_synapses"])), (lay[1] + lay[2]) / max(1.0, float(info["n_axons"])),
+                           contract_deliver / max(1.0, design_deliver)))
 
     cpu = None
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3" and args.timing == "simple":
         c = cpu_baseline(S, args)
         events_per_step = agg["spikes"] / args.steps
-        est = c["events_per_s"] / events_per_step if events_per_step > 0 else c["steps_per_s"]
-        cpu = {"value": est, "unit": "timesteps/s", "cores": 1, "kind": "port", "host": host_info(),
-               "sample": c["sample"] + "; value = measured synaptic-events/s (%.3g) / events per step of the GPU workload (%.3g)"
-                         % (c["events_per_s"], events_per_step),
-               "measured": {"timesteps_per_s_on_sample": c["steps_per_s"], "synaptic_events_per_s": c["events_per_s"],
-                            "neuron_updates_per_s": c["updates_per_s"], "timesteps_per_s_windows": c["all_steps_per_s"]}}
+
+        def scaled(m):
+            return m["events_per_s"] / events_per_step if events_per_step > 0 else m["steps_per_s"]
+        cpu = {"value": scaled(c), "unit": "timesteps/s", "cores": c["threads"], "kind": "port", "host": host_info(),
+               "sample": c["sample"] + "; value = synaptic-events/s of the faster thread count (%d threads: %.3g) / events per "
+                         "step of the GPU workload (%.3g)" % (c["threads"], c["events_per_s"], events_per_step),
+               "by_threads": {str(t): {"value": scaled(m), "timesteps_per_s_on_sample": m["steps_per_s"],
+                                       "synaptic_events_per_s": m["events_per_s"], "neuron_updates_per_s": m["updates_per_s"],
+                                       "timesteps_per_s_windows": m["all_steps_per_s"]} for t, m in c["runs"].items()}}
 
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c2":
         cpu = cpu_baseline_same_net(S, args, arch, net, "the same network")
@@ -429,6 +607,7 @@ def main():
     if rank == 0:
         out = {
             "metric": "simulated timesteps/sec", "value": args.steps / elapsed, "unit": "timesteps/s",
+            "value_without_device_warmup": cold,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload,
@@ -443,7 +622,9 @@ def main():
                          "synaptic_events": agg["spikes"] / args.steps, "messages": agg["packets_sent"] / args.steps},
             "setup_s": {"build_network": t_net, "map_and_upload": t_load},
             "device_warmup": {"steps": device_warmup, "then": "chip.reset()",
-                              "note": "clock warm-up before the W warm-up steps; the timed steps are steps W+1..W+K of a fresh simulation"},
+                              "note": "value: clock warm-up steps + chip.reset() before the W warm-up steps, so the timed steps are "
+                                      "steps W+1..W+K of a fresh simulation at settled clocks; value_without_device_warmup: the same "
+                                      "W+K steps timed first, right after load()"},
             "roofline": roof, "cpu_baseline": cpu,
         }
         real_stdout.write(json.dumps(out) + "\n")

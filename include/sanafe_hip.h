@@ -258,9 +258,11 @@ int sanafe_hip_step_deliver_remote(sanafe_hip_chip *chip, int simple_timing);
 int sanafe_hip_slice_split(sanafe_hip_chip *chip, uint32_t *n_local, uint32_t *n_remote);
 /* Simple timing model across GPUs: sim_time of a step = max over ALL cores of the chip + sync delay
  * (src/schedule.cpp:61-102), so each rank logs the largest per-core delay of every step it simulates
- * (entry `timestep % capacity`) and the caller takes the maximum over the ranks.  Allocates / returns the
- * device log; next_index = entry the next simulated step will write. */
-int sanafe_hip_delay_log(sanafe_hip_chip *chip, int64_t capacity, double **device_log, int64_t *next_index);
+ * (entry `timestep % real_capacity`) and the caller takes the maximum over the ranks.  Allocates / returns the
+ * device log: at least `capacity` entries, never shrinking -- real_capacity is what the ring arithmetic uses;
+ * next_index = entry the next simulated step will write. */
+int sanafe_hip_delay_log(sanafe_hip_chip *chip, int64_t capacity, double **device_log, int64_t *real_capacity,
+        int64_t *next_index);
 int sanafe_hip_read_delay_log(sanafe_hip_chip *chip, int64_t first, int64_t count, double *out);
 /* Device address of the run totals (sanafe_hip_totals), for a device-side gather over the ranks. */
 void *sanafe_hip_run_totals_device(sanafe_hip_chip *chip);

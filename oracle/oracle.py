@@ -49,6 +49,7 @@ def lib():
         L.oracle_reset.argtypes = [C.c_void_p]
         L.oracle_set_neuron_attr.argtypes = [C.c_void_p, C.c_int64, C.c_char_p, C.c_int, C.c_double, C.c_char_p,
                                              C.c_void_p, C.c_int64, C.c_int, C.c_char_p, C.c_int]
+        L.oracle_set_threads.argtypes = [C.c_void_p, C.c_int]
         L.oracle_mapped_tiles.restype = C.c_int64
         L.oracle_mapped_tiles.argtypes = [C.c_void_p]
         _lib = L
@@ -73,6 +74,10 @@ class OracleChip:
         if getattr(self, "_h", None):
             lib().oracle_destroy(self._h)
             self._h = None
+
+    def set_threads(self, n):
+        """n > 1: OpenMP over cores like the reference (src/chip.cpp:629-632, 675-678); 1 = serial (the parity mode)."""
+        lib().oracle_set_threads(self._h, int(n))
 
     def step(self, timing="simple"):
         ts = OracleTs()

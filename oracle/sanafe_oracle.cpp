@@ -16,6 +16,8 @@
 //    recorded probe of the reference for example_chip/example_snn;
 //  * the detailed NoC scheduler has no reference-held vector: parity unpinned.
 #include <algorithm>
+#include <atomic>
+#include <exception>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -736,7 +738,10 @@ struct oracle_chip
     std::vector<int64_t> group_ptr;
     std::vector<MappedNeuron *> by_gid;
     size_t mapped_tiles{0}, mapped_cores{0};
-    long total_timesteps{0}, total_messages_sent{0};
+    long total_timesteps{0};
+    std::atomic<long> total_messages_sent{0}; // src/chip.hpp: std::atomic<long>, fetch_add per message (src/chip.cpp:815)
+    int omp_threads{1}; // > 1: OpenMP over cores like the reference (src/chip.cpp:629-632, 675-678, 1398-1401); message
+                        // ids then depend on the thread schedule, exactly as they do there
     unsigned input_instances{0};
     const sanafe_desc *desc{nullptr}; // borrowed: the caller keeps the desc alive with the chip
     Timestep last;
@@ -1213,8 +1218,10 @@ struct oracle_chip
             t.hops = t.north = t.east = t.south = t.west = 0;
             t.messages_received = 0;
         }
-        for (Core &c : cores)
+#pragma omp parallel for schedule(dynamic) if (omp_threads > 1) num_threads(omp_threads)
+        for (size_t ci = 0; ci < cores.size(); ci++)
         {
+            Core &c = cores[ci];
             c.energy = 0.0;
             c.next_delay = 0.0;
             for (auto &a : c.axon_in_hw) a.spike_messages_in = 0;
@@ -1235,8 +1242,12 @@ struct oracle_chip
     void process_neurons(Timestep &ts) // src/chip.cpp:624-654, 710-736, 802-834
     {
         const long t = ts.t.timestep;
-        for (Core &c : cores)
+        std::exception_ptr failure; // an exception must not leave an OpenMP region
+#pragma omp parallel for schedule(dynamic) if (omp_threads > 1) num_threads(omp_threads)
+        for (size_t ci = 0; ci < cores.size(); ci++)
+        try
         {
+            Core &c = cores[ci];
             for (MappedNeuron &n : c.neurons)
             {
                 const bool sim_buf = (c.buffer_pos == SANAFE_BUF_BEFORE_DENDRITE) || (c.buffer_pos == SANAFE_BUF_BEFORE_SOMA);
@@ -1280,6 +1291,12 @@ struct oracle_chip
                 ts.messages.at(c.id).push_back(ph);
             }
         }
+        catch (...)
+        {
+#pragma omp critical(oracle_failure)
+            if (!failure) failure = std::current_exception();
+        }
+        if (failure) std::rethrow_exception(failure);
     }
 
     void process_messages(Timestep &ts) // src/chip.cpp:656-764, 1127-1169
@@ -1319,7 +1336,12 @@ struct oracle_chip
                 m.hops = xh + yh;
                 cores[dest.cores.at(m.dest_core_offset)].messages_in.push_back(&m);
             }
-        for (Core &c : cores)
+        std::exception_ptr failure;
+#pragma omp parallel for schedule(dynamic) if (omp_threads > 1) num_threads(omp_threads)
+        for (size_t ci = 0; ci < cores.size(); ci++)
+        try
+        {
+            Core &c = cores[ci];
             for (Message *mp : c.messages_in)
             {
                 Message &m = *mp;
@@ -1337,6 +1359,13 @@ struct oracle_chip
                 }
                 m.processing_delay += lat;
             }
+        }
+        catch (...)
+        {
+#pragma omp critical(oracle_failure)
+            if (!failure) failure = std::current_exception();
+        }
+        if (failure) std::rethrow_exception(failure);
     }
 
     void forced_updates(Timestep &ts) // src/chip.cpp:975-1026
@@ -1678,6 +1707,8 @@ extern "C" int oracle_step(oracle_chip *chip, int timing_model, oracle_ts *out, 
         return -1;
     }
 }
+
+extern "C" void oracle_set_threads(oracle_chip *chip, int n_threads) { chip->omp_threads = n_threads > 1 ? n_threads : 1; }
 
 extern "C" void oracle_get_status(const oracle_chip *chip, uint8_t *out)
 {

@@ -1,7 +1,8 @@
 /* sanafe_oracle.h -- C API of the CPU oracle.
  *
- * TEST INFRASTRUCTURE ONLY.  The oracle is a scalar, single-threaded CPU
- * restatement of SANA-FE's per-timestep loop used to check the MI355X path.
+ * TEST INFRASTRUCTURE ONLY.  The oracle is a scalar CPU restatement of
+ * SANA-FE's per-timestep loop used to check the MI355X path (single-threaded
+ * unless oracle_set_threads asks for the reference's OpenMP-over-cores mode).
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
  * load this library; the product (sana-fe_amd/) never links or calls it.
  */
@@ -53,6 +54,10 @@ void oracle_destroy(oracle_chip *chip);
 /* One SpikingChip::step(); returns 0 on success, -1 and fills err otherwise. */
 int oracle_step(oracle_chip *chip, int timing_model, oracle_ts *out, char *err,
         int errlen);
+/* n_threads > 1: the two hot loops (and the counter reset) run as OpenMP `parallel for schedule(dynamic)` over cores,
+ * as the reference's do (src/chip.cpp:629-632, 675-678, 1398-1401) -- the multithreaded CPU baseline of bench.py.
+ * Message ids then depend on the thread schedule, as in the reference; parity tests use the default of 1. */
+void oracle_set_threads(oracle_chip *chip, int n_threads);
 /* NeuronStatus of every neuron after the last step, desc (global id) order. */
 void oracle_get_status(const oracle_chip *chip, uint8_t *out);
 /* soma get_potential() of every neuron, desc order. */

@@ -107,6 +107,8 @@ struct sanafe_hip_chip
     DevState st{};
     std::vector<void *> allocs;
     size_t deliver_lds{0};
+    const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
+    uint32_t deliver_block{0};
     uint32_t neuron_grid{0};
     long long rec_host{0};
     bool timing{false};
@@ -177,6 +179,33 @@ template <typename T> int dalloc(sanafe_hip_chip *c, size_t n, T **dst, bool zer
         int rc_ = (expr);    \
         if (rc_ != 0) return rc_; \
     } while (0)
+
+// Every deliver_kernel instantiation the library can launch, in ONE table: sanafe_hip_chip_create picks the chip's
+// kernel from it, opts in to its dynamic LDS and checks its static LDS; launch_deliver launches what was picked.
+struct DeliverVariant
+{
+    int fmt;
+    bool delay, last, iacc;
+    int block;
+    const void *fn;
+};
+#define SANAFE_DV(F, D, L, I, B) {F, D, L, I, B, reinterpret_cast<const void *>(deliver_kernel<F, D, L, I, B>)}
+#define SANAFE_DV_FORMAT(F) SANAFE_DV(F, false, false, false, DELIVER_BLOCK), SANAFE_DV(F, true, false, false, DELIVER_BLOCK), \
+                            SANAFE_DV(F, false, true, false, DELIVER_BLOCK), SANAFE_DV(F, false, false, false, 64)
+#define SANAFE_DV_IACC(F) SANAFE_DV(F, false, false, true, DELIVER_BLOCK), SANAFE_DV(F, true, false, true, DELIVER_BLOCK), \
+                          SANAFE_DV(F, false, true, true, DELIVER_BLOCK)
+const DeliverVariant deliver_variants[] = {
+        SANAFE_DV_FORMAT(0), SANAFE_DV_FORMAT(1), SANAFE_DV_FORMAT(2), SANAFE_DV_FORMAT(3), SANAFE_DV_FORMAT(4), SANAFE_DV_FORMAT(6),
+        SANAFE_DV_FORMAT(7), SANAFE_DV_IACC(0), SANAFE_DV_IACC(3)};
+#undef SANAFE_DV
+#undef SANAFE_DV_FORMAT
+#undef SANAFE_DV_IACC
+const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block)
+{
+    for (const DeliverVariant &v : deliver_variants)
+        if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block) return &v;
+    return nullptr;
+}
 
 int validate(const sanafe_hip_image *im)
 {
@@ -943,31 +972,27 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     im.acc_shift = c->acc_shift;
     if (im.has_last && c->has_delay)
         return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "cores with the buffer before the dendrite unit cannot be mixed with synaptic delays"));
-    if (c->deliver_lds + 9 * 1024 > 160 * 1024)
-        return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu B of LDS (> 160 KiB)",
-                max_pad, im.delay_slots, c->deliver_lds));
-#define SANAFE_SET_LDS(F, DLY) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, DLY, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
-#define SANAFE_SET_LDS_LAST(F) HIPC(hipFuncSetAttribute(reinterpret_cast<const void *>(deliver_kernel<F, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds))
-    SANAFE_SET_LDS_LAST(0);
-    SANAFE_SET_LDS_LAST(1);
-    SANAFE_SET_LDS_LAST(2);
-    SANAFE_SET_LDS_LAST(3);
-    SANAFE_SET_LDS_LAST(4);
-    SANAFE_SET_LDS_LAST(6);
-#undef SANAFE_SET_LDS_LAST
-    SANAFE_SET_LDS(0, true);
-    SANAFE_SET_LDS(0, false);
-    SANAFE_SET_LDS(1, true);
-    SANAFE_SET_LDS(1, false);
-    SANAFE_SET_LDS(2, true);
-    SANAFE_SET_LDS(2, false);
-    SANAFE_SET_LDS(3, true);
-    SANAFE_SET_LDS(3, false);
-    SANAFE_SET_LDS(4, true);
-    SANAFE_SET_LDS(4, false);
-    SANAFE_SET_LDS(6, true);
-    SANAFE_SET_LDS(6, false);
-#undef SANAFE_SET_LDS
+    // The one delivery kernel this chip launches, picked from the table every instantiation lives in (deliver_variants):
+    // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
+    // first launch.
+    {
+        const bool iacc = (c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0;
+        // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
+        //  dictionary accumulators)
+        const bool use_small = c->small_slices && !im.has_last && !c->has_delay && !iacc;
+        const DeliverVariant *v = find_deliver_variant(c->syn_format, !im.has_last && c->has_delay, im.has_last != 0, iacc, use_small ? 64 : DELIVER_BLOCK);
+        if (v == nullptr)
+            return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "no delivery kernel for format %d (delay %d, last %d, integer accumulators %d)",
+                    c->syn_format, (int) c->has_delay, im.has_last, (int) iacc));
+        hipFuncAttributes fa{};
+        HIPC(hipFuncGetAttributes(&fa, v->fn));
+        if (c->deliver_lds + fa.sharedSizeBytes > 160 * 1024)
+            return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "a core with %u neurons x %u delay values needs %zu + %zu B of LDS (> 160 KiB)",
+                    max_pad, im.delay_slots, c->deliver_lds, (size_t) fa.sharedSizeBytes));
+        HIPC(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds));
+        c->deliver_fn = v->fn;
+        c->deliver_block = (uint32_t) v->block;
+    }
     HIPC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -1118,50 +1143,9 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
     if (count > 0)
     {
-        // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
-        //  dictionary accumulators)
-        const bool use_small = c->small_slices && !c->im.has_last && !c->has_delay &&
-                               !((c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0);
-        const dim3 grid(count), block(use_small ? 64 : DELIVER_BLOCK);
-#define SANAFE_LAUNCH_DELIVER(F, DLY) \
-    hipLaunchKernelGGL((deliver_kernel<F, DLY, false>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
-#define SANAFE_LAUNCH_DELIVER_LAST(F) \
-    hipLaunchKernelGGL((deliver_kernel<F, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
-#define SANAFE_LAUNCH_FORMAT(F)                                      \
-    if (c->im.has_last) SANAFE_LAUNCH_DELIVER_LAST(F);               \
-    else if (c->has_delay) SANAFE_LAUNCH_DELIVER(F, true);           \
-    else if (use_small)                                              \
-        hipLaunchKernelGGL((deliver_kernel<F, false, false, false, 64>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first); \
-    else SANAFE_LAUNCH_DELIVER(F, false)
-// formats 0 and 3 with 32-bit integer accumulators (the per-accumulator bounds hold: acc_shift > 0)
-#define SANAFE_LAUNCH_FORMAT_IACC(F)                                                                                                            \
-    if (c->im.has_last)                                                                                                                        \
-        hipLaunchKernelGGL((deliver_kernel<F, false, true, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first);  \
-    else if (c->has_delay)                                                                                                                     \
-        hipLaunchKernelGGL((deliver_kernel<F, true, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first);  \
-    else                                                                                                                                       \
-        hipLaunchKernelGGL((deliver_kernel<F, false, false, true>), grid, block, c->deliver_lds, c->stream, c->im, c->st, c->t_host, first)
-        switch (c->syn_format)
-        {
-        case 0:
-            if (c->acc_shift > 0) { SANAFE_LAUNCH_FORMAT_IACC(0); }
-            else { SANAFE_LAUNCH_FORMAT(0); }
-            break;
-        case 1: SANAFE_LAUNCH_FORMAT(1); break;
-        case 3:
-            if (c->acc_shift > 0) { SANAFE_LAUNCH_FORMAT_IACC(3); }
-            else { SANAFE_LAUNCH_FORMAT(3); }
-            break;
-        case 4: SANAFE_LAUNCH_FORMAT(4); break;
-        case 6: SANAFE_LAUNCH_FORMAT(6); break;
-        case 7: SANAFE_LAUNCH_FORMAT(7); break;
-        default: SANAFE_LAUNCH_FORMAT(2); break;
-        }
-#undef SANAFE_LAUNCH_FORMAT
-#undef SANAFE_LAUNCH_FORMAT_IACC
-#undef SANAFE_LAUNCH_DELIVER
-#undef SANAFE_LAUNCH_DELIVER_LAST
-        HIPCHK(hipGetLastError());
+        long long done = c->t_host;
+        void *args[] = {&c->im, &c->st, &done, &first};
+        HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(count), dim3(c->deliver_block), args, c->deliver_lds, c->stream));
     }
     return 0;
 }
@@ -1375,7 +1359,7 @@ extern "C" int sanafe_hip_slice_split(sanafe_hip_chip *c, uint32_t *n_local, uin
     if (n_remote) *n_remote = c->im.n_slices - c->n_local_slices;
     return 0;
 }
-extern "C" int sanafe_hip_delay_log(sanafe_hip_chip *c, int64_t capacity, double **log, int64_t *next_index)
+extern "C" int sanafe_hip_delay_log(sanafe_hip_chip *c, int64_t capacity, double **log, int64_t *real_capacity, int64_t *next_index)
 {
     if (!c || capacity < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
@@ -1390,6 +1374,7 @@ extern "C" int sanafe_hip_delay_log(sanafe_hip_chip *c, int64_t capacity, double
         c->st.delay_log_cap = capacity;
     }
     if (log) *log = c->st.delay_log;
+    if (real_capacity) *real_capacity = c->st.delay_log_cap; // the log never shrinks: ring arithmetic uses THIS, not the request
     if (next_index) *next_index = c->st.delay_log_cap > 0 ? c->t_host % c->st.delay_log_cap : 0;
     return 0;
 }

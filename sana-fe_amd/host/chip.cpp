@@ -1025,10 +1025,12 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
                         " of a tile-sharded chip: set the spike exchange up first (sanafe_chip_comm_init_rccl / _callback)");
     MappedChip &mc = chip->mc;
     DEV(sanafe_hip_reset_totals(chip->dev));
-    const int64_t cap = std::max<int64_t>(1, std::min<int64_t>(timesteps, 1 << 16));
+    // the device keeps one entry per step in a ring of `cap` entries; the ring never shrinks, so `cap` is what the device
+    // reports, not what this call asked for (a shorter sim() after a longer one)
+    int64_t cap = std::max<int64_t>(1, std::min<int64_t>(timesteps, 1 << 16));
     double *d_log = nullptr;
     int64_t next = 0;
-    DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &next));
+    DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next));
     void *local_bits = nullptr, *global_bits = nullptr;
     uint64_t local_bytes = 0, global_bytes = 0;
     DEV(sanafe_hip_spike_buffers(chip->dev, &local_bits, &local_bytes, &global_bits, &global_bytes));
@@ -1046,7 +1048,7 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
         m = std::min(cap, timesteps - done);
         if (n_ext != 0) m = std::min<int64_t>(m, std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext)));
         if (int rc = chip->queue_ext(m)) return rc;
-        DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &next)); // flushed: `next` is where this chunk starts
+        DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next)); // flushed: `next` is where this chunk starts
         for (int64_t s = 0; s < m; s++)
         {
             DEV(sanafe_hip_step_neurons(chip->dev));

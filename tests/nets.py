@@ -142,6 +142,45 @@ def random_loihi(S, n_tiles=4, neurons_per_core=64, cores_used=None, out_degree=
     return arch, net
 
 
+def c3_delivery_shape(S, cores=512, neurons_per_core=512, dest_cores=8, out_degree=41, p_fire=0.1, seed=1, weights="int",
+                      delays=True):
+    """The per-core DELIVERY shape of config C3 at a size the oracle can follow: all `cores` x `neurons_per_core` source
+    neurons of the bench recipe (512 x 512 = 262,144), but every neuron draws its `out_degree` targets among the neurons
+    of `dest_cores` cores only.  Each of those cores then sees what a core of the full network sees: ~260 k inbound axons
+    with ~5 synapses each from every source core of the chip (16+ delivery slices of >= 8,192 axons with
+    SANAFE_MIN_SLICE_AXONS=16384, runs of 8 chunks, write-back shared between the slices) -- with 10.7 M synapses
+    instead of 687 M."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    n_tiles = (cores + 3) // 4
+    w = max(1, int(np.ceil(np.sqrt(n_tiles))))
+    arch = S.presets.loihi_large(n_tiles=n_tiles, width=w, height=int(np.ceil(n_tiles / w)), n_inputs=4, api=S.description)
+    n = cores * neurons_per_core
+    net = D.Network("c3_shape")
+    g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
+                                "loihi_dendrites_delay", False, True, "loihi_lif")
+    g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128, 0).astype(np.int64), D.ATTR_INT)
+    # destination cores spread over the chip (first, last and in between), so sources come from lower AND higher core ids
+    dcores = np.unique(np.linspace(0, cores - 1, dest_cores).astype(np.int64))
+    pool = (dcores[:, None] * neurons_per_core + np.arange(neurons_per_core)[None, :]).ravel()
+    src = np.repeat(np.arange(n, dtype=np.int64), out_degree)
+    dst = pool[rng.integers(0, len(pool), size=len(src))]  # (repeated targets are separate synapses of the same axon)
+    if weights == "int":
+        wv = (rng.integers(1, 9, size=len(src)) * rng.choice([-1, 1], size=len(src))).astype(np.float64)
+        # keep the targets near threshold instead of saturated: ~27 k spiking sources x 41 / 4096 targets = 270 events each
+        wv = np.where(rng.random(len(src)) < 0.5, wv, -wv)
+    else:
+        wv = rng.normal(size=len(src)) * 4.0
+    at = {"weight": wv}
+    if delays:
+        at["delay"] = rng.integers(0, 6, size=len(src))
+    g.connect_neurons_sparse(g, at, np.stack([src, dst], axis=1), narrow_float=False)
+    ac = arch.cores()
+    for c in range(cores):
+        g.map_to_core(ac[c], c * neurons_per_core, (c + 1) * neurons_per_core)
+    return arch, net
+
+
 def truenorth_net(S, n_tiles=16, neurons_per_core=256, remote_fraction=0.8, seed=1):
     """Config C4-style synthetic SNN (after scripts/tcad2025/compare_nemo_perf.py:52-101):
     `truenorth` neurons, threshold 0, reset -1, leak 0, force_update, weight 1, one out-edge per neuron,

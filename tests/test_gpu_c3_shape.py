@@ -1,0 +1,75 @@
+"""Config C3's per-core delivery shape against the oracle ("what's weak" 1).
+
+The full-size test (test_gpu_fullsize.py) can only compare the device formats with each other; they share the mapper,
+phase A of the delivery kernel, the bitmap and the slice cutter.  Here the HIP path meets the ORACLE on a network whose
+destination cores look exactly like C3's: 262,144 source neurons on 512 cores, ~260 k inbound axons per destination
+core with ~5 synapses each, 16 delivery slices of 16,384 axons per core (runs of 8 chunks per wavefront), write-back
+shared between the slices of a core, delay-line dendrites -- in the headline's format 7 (2-byte dictionary words, integer
+accumulators), format 0 (4-byte int8 words) and format 4 (4-byte words + fp64 weights)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nets  # noqa: E402
+from oracle.oracle import OracleChip  # noqa: E402
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+STEPS = 10
+INT_KEYS = (("spikes", "spike_count"), ("packets_sent", "packets_sent"), ("neurons_updated", "neurons_updated"),
+            ("neurons_fired", "neurons_fired"), ("total_hops", "total_hops"))
+DBL_KEYS = ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy", "network_energy", "sim_time")
+
+
+_cache = {}
+
+
+def c3_shape(S, delays):
+    """(arch, net, the oracle's totals / statuses / potentials of STEPS steps), built once per variant."""
+    if delays not in _cache:
+        _cache.clear()  # one 10.7 M-synapse network at a time
+        arch, net = nets.c3_delivery_shape(S, p_fire=0.3, delays=delays)
+        orc = OracleChip(S.to_desc(arch, net))
+        ref = []
+        for _ in range(STEPS):
+            r = orc.step("simple")
+            ref.append((r, orc.status(), orc.potentials()))
+        del orc
+        _cache[delays] = (arch, net, ref)
+    return _cache[delays]
+
+
+# delays=False is the headline's kernel variant (bench.py's recipe has no synaptic delays: deliver_kernel<7, false, ...>);
+# delays=True adds the six accumulator rows of a delay line that is actually used
+@pytest.mark.parametrize("delays,force,fmt", [(False, None, 7), (False, "0", 0), (False, "4", 4), (True, None, 7)])
+def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt):
+    arch, net, ref = c3_shape(S, delays)
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")  # C3's slices: 133 M axons / 8,192 slices -> 16,384 axons each
+    if force is not None:
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    lay, info = chip.device_layout(), chip.info()
+    assert lay["syn_format"] == fmt
+    assert info["n_neurons"] == 262144 and info["n_synapses"] == 262144 * 41
+    # the C3 delivery shape: every slice on compact records, >= 16 slices on each destination core, ~5 synapses per axon
+    assert lay["n_compact_slices"] == info["n_slices"] >= 8 * 16
+    assert 4.5 < info["n_synapses"] / info["n_axons"] < 5.6
+    fired_any = 0
+    for t in range(STEPS):
+        a = chip.run(1, "simple", record=True)
+        b, st, v = ref[t]
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k)
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.potentials(), v), t  # integer weights: exact in any order
+        fired_any += int((st == 3).sum())
+    # the targets must really be driven by synaptic input, not only by their biases
+    dest = np.unique(np.linspace(0, 511, 8).astype(np.int64))
+    dest_fired = sum(int((ref[t][1].reshape(512, 512)[dest] == 3).sum()) for t in range(STEPS))
+    assert dest_fired > 0.15 * STEPS * len(dest) * 512

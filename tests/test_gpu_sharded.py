@@ -57,7 +57,8 @@ def _sharded(S, arch, net, steps, n_ranks=2, calls=1):
 
     def work(r):
         try:
-            out = [chips[r].run(steps, "simple") for _ in range(calls)]
+            plan = steps if isinstance(steps, (list, tuple)) else [steps] * calls
+            out = [chips[r].run(k, "simple") for k in plan]
             results[r] = out
         except Exception as e:  # noqa: BLE001
             errors.append(e)
@@ -122,6 +123,22 @@ def test_sharded_sim_is_cumulative(S):
         _assert_same(results[1][k], ref[k])
 
 
+def test_sharded_sims_of_unequal_length(S):
+    """The per-step delay log is a ring that never shrinks: a shorter sim() after a longer one must read the entries
+    the device really wrote (run(10), run(7), run(7) used to read stale slots).  Loihi costs, so sim_time
+    depends on every step's largest per-core delay over BOTH ranks."""
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=96, out_degree=48, delays=True, seed=11)
+    plan = [10, 7, 7, 3, 12]
+    ref_chip = S.SpikingChip(arch)
+    ref_chip.load(net)
+    ref = [ref_chip.run(k, "simple") for k in plan]
+    assert len({r["sim_time"] for r in ref}) == len(plan)  # the calls differ: a stale entry cannot go unnoticed
+    _, results = _sharded(S, arch, net, plan)
+    for k in range(len(plan)):
+        _assert_same(results[0][k], ref[k])
+        _assert_same(results[1][k], ref[k])
+
+
 @pytest.mark.parametrize("overlap", ["0", "1"])
 def test_rccl_exchange_world_size_one(S, monkeypatch, overlap):
     monkeypatch.setenv("SANAFE_COMM_OVERLAP", overlap)  # in-line gather / gather beside the local delivery
@@ -135,6 +152,12 @@ def test_rccl_exchange_world_size_one(S, monkeypatch, overlap):
     assert np.array_equal(chip.potentials(), v_ref)
     got2 = chip.run(5, "simple")  # the communicator stays usable
     assert got2["neurons_updated"] == ref["neurons_updated"] // 40 * 5
+    # shorter and longer calls after the first: the delay-log ring keeps its first capacity (40)
+    ref_chip = S.SpikingChip(arch)
+    ref_chip.load(net)
+    ref_chip.run(45, "simple")
+    for k in (7, 33, 50):
+        _assert_same(chip.run(k, "simple"), ref_chip.run(k, "simple"))
 
 
 @pytest.mark.slow
