@@ -286,6 +286,8 @@ int sanafe_hip_reset_totals(sanafe_hip_chip *chip);
 int sanafe_hip_read_step_totals(sanafe_hip_chip *chip, int64_t first, int64_t count, sanafe_hip_totals *out);
 /* Spike bitmap (1 bit per local slot, LSB first) of recorded step `index`. */
 int sanafe_hip_read_step_spikes(sanafe_hip_chip *chip, int64_t index, uint32_t *bits_out);
+/* The bitmaps of recorded steps [first, first + count) in ONE copy: bits_out[count][n_slots / 32]. */
+int sanafe_hip_read_step_spike_rows(sanafe_hip_chip *chip, int64_t first, int64_t count, uint32_t *bits_out);
 /* NeuronStatus (0..3) per local slot after the last step. */
 int sanafe_hip_read_status(sanafe_hip_chip *chip, uint8_t *out);
 /* NeuronStatus of recorded steps [first, first + count) of the last sanafe_hip_step(record & 2): out[count][n_slots] */

@@ -107,6 +107,8 @@ struct sanafe_hip_chip
     DevState st{};
     std::vector<void *> allocs;
     size_t deliver_lds{0};
+    bool ord_dict{false};           // format 8: the entries carry 5-bit codes into weight_lut instead of fp64 weights
+    size_t ord_lds{0};              // format 8: dynamic LDS of ordered_deliver_kernel (the spike bitmap), 0: probe global memory
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     uint32_t deliver_block{0};
     uint32_t neuron_grid{0};
@@ -200,11 +202,138 @@ const DeliverVariant deliver_variants[] = {
 #undef SANAFE_DV
 #undef SANAFE_DV_FORMAT
 #undef SANAFE_DV_IACC
+// ordered delivery (format 8): dictionary entries x bitmap in LDS x per-neuron write-back rules
+struct OrderedVariant
+{
+    bool dict, lds_bits, delay;
+    const void *fn;
+};
+#define SANAFE_OV(D, L, Y) {D, L, Y, reinterpret_cast<const void *>(ordered_deliver_kernel<D, L, Y>)}
+const OrderedVariant ordered_variants[] = {SANAFE_OV(false, false, false), SANAFE_OV(false, false, true), SANAFE_OV(false, true, false),
+        SANAFE_OV(false, true, true), SANAFE_OV(true, false, false), SANAFE_OV(true, false, true), SANAFE_OV(true, true, false),
+        SANAFE_OV(true, true, true)};
+#undef SANAFE_OV
 const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block)
 {
     for (const DeliverVariant &v : deliver_variants)
         if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block) return &v;
     return nullptr;
+}
+
+// Ordered layout (format 8): the image's synapses regrouped per accumulator = (post neuron, delay value), every list in the
+// image's synapse order, which IS the reference's delivery order at the destination core (axons by source core and source
+// neuron, synapses of an axon in connection order; include/sanafe_hip.h "Index spaces").  Accumulators are sorted by list
+// length, longest first, and cut into groups of 64 whose lists lie side by side ([row][lane]), padded to the group's
+// longest list (rounded up to ORD_UNROLL rows) with entries that never fire.
+int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
+{
+    DevImage &im = c->im;
+    // accumulator index space: core by core, (max delay + 1) rows of npad entries
+    uint32_t rows = 1;
+    {
+        std::atomic<uint32_t> md{0};
+        parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
+            uint32_t m = 0;
+            for (uint64_t k = lo; k < hi; k++) m = std::max(m, (h.syn_meta[k] >> 16) & 7u);
+            uint32_t seen = md.load();
+            while (seen < m && !md.compare_exchange_weak(seen, m)) {}
+        });
+        rows = md.load() + 1;
+    }
+    std::vector<uint64_t> acc_base(h.n_cores + 1, 0);
+    for (uint32_t k = 0; k < h.n_cores; k++) acc_base[k + 1] = acc_base[k] + (uint64_t) rows * ((h.core_ncount[k] + 63u) & ~63u);
+    const uint64_t n_acc = acc_base[h.n_cores];
+    if (n_acc >= (1ull << 32)) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "more than 2^32 accumulators");
+    auto core_syn_end = [&](uint32_t k) { return (k + 1 < h.n_cores) ? h.core_syn_base[k + 1] : h.n_synapses; };
+    auto acc_of = [&](uint32_t core, uint32_t meta) {
+        return acc_base[core] + (uint64_t) ((meta >> 16) & 7u) * ((h.core_ncount[core] + 63u) & ~63u) + (meta & 0xffffu);
+    };
+    // the synapses of a core are one contiguous range of the image, in delivery order
+    std::vector<uint32_t> count(n_acc, 0);
+    parallel_for(h.n_cores, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; k++)
+            for (uint64_t q = h.core_syn_base[k]; q < core_syn_end((uint32_t) k); q++)
+                if (!((h.syn_meta[q] >> 19) & 1u)) count[acc_of((uint32_t) k, h.syn_meta[q])]++; // (lost charge: no entry at all)
+    });
+    std::vector<uint32_t> order;
+    for (uint64_t a = 0; a < n_acc; a++)
+        if (count[a] > 0) order.push_back((uint32_t) a);
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return count[a] > count[b]; });
+    const uint32_t n_groups = (uint32_t) ((order.size() + WAVE - 1) / WAVE);
+    std::vector<OrdGroup> groups(n_groups);
+    std::vector<uint32_t> lane_slot((size_t) n_groups * WAVE, 0xffffffffu);
+    std::vector<uint8_t> lane_delay((size_t) n_groups * WAVE, 0);
+    std::vector<uint32_t> place(n_acc, 0xffffffffu); // accumulator -> group * 64 + lane
+    uint64_t n_entries = 0;
+    for (uint32_t g = 0; g < n_groups; g++)
+    {
+        const uint32_t longest = count[order[(size_t) g * WAVE]];
+        groups[g].off = n_entries;
+        groups[g].rows = (longest + ORD_UNROLL - 1) / ORD_UNROLL * ORD_UNROLL;
+        groups[g].pad = 0;
+        n_entries += (uint64_t) groups[g].rows * WAVE;
+        for (uint32_t l = 0; l < (uint32_t) WAVE && (size_t) g * WAVE + l < order.size(); l++)
+            place[order[(size_t) g * WAVE + l]] = g * WAVE + l;
+    }
+    // lane -> (slot, delay)
+    for (uint32_t k = 0; k < h.n_cores; k++)
+    {
+        const uint32_t npad = (h.core_ncount[k] + 63u) & ~63u;
+        for (uint64_t a = acc_base[k]; a < acc_base[k + 1]; a++)
+        {
+            if (place[a] == 0xffffffffu) continue;
+            const uint64_t rel = a - acc_base[k];
+            lane_slot[place[a]] = h.core_nbase[k] + (uint32_t) (rel % npad);
+            lane_delay[place[a]] = (uint8_t) (rel / npad);
+        }
+    }
+    const uint32_t pad_pre = h.n_global_slots; // its bit is always 0 (one spare zero word behind the bitmap)
+    std::vector<uint32_t> pre(n_entries + (size_t) ORD_UNROLL * WAVE, pad_pre);
+    std::vector<double> wts;
+    if (!c->ord_dict) wts.assign(n_entries + (size_t) ORD_UNROLL * WAVE, 0.0);
+    auto lut_code = [&](double w) {
+        for (uint32_t q = 0; q < 32; q++)
+            if (std::memcmp(&c->weight_lut[q], &w, sizeof w) == 0) return q;
+        return 0u;
+    };
+    std::fill(count.begin(), count.end(), 0u); // now: entries written so far
+    std::vector<uint64_t> core_ax_beg(h.n_cores, 0), core_ax_end(h.n_cores, 0); // axons of a core: those of its slices
+    for (uint32_t sl = h.n_slices; sl-- > 0;) core_ax_beg[h.slice_core[sl]] = h.slice_axon_beg[sl];
+    for (uint32_t sl = 0; sl < h.n_slices; sl++) core_ax_end[h.slice_core[sl]] = h.slice_axon_end[sl];
+    parallel_for(h.n_cores, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; k++)
+        {
+            // axon by axon: the pre slot belongs to the axon, its synapses follow in order
+            for (uint64_t a = core_ax_beg[k]; a < core_ax_end[k]; a++)
+            {
+                const uint64_t src = h.core_syn_base[k] + h.ax_syn_beg[a];
+                for (uint32_t q = 0; q < h.ax_nsyn[a]; q++)
+                {
+                    const uint32_t m = h.syn_meta[src + q];
+                    if ((m >> 19) & 1u) continue;
+                    const uint64_t acc = acc_of((uint32_t) k, m);
+                    const uint32_t pl = place[acc], g = pl / WAVE, l = pl % WAVE;
+                    const uint64_t at = groups[g].off + (uint64_t) count[acc]++ * WAVE + l;
+                    pre[at] = c->ord_dict ? (h.ax_pre[a] | (lut_code(h.syn_weight[src + q]) << ORD_PRE_BITS)) : h.ax_pre[a];
+                    if (!c->ord_dict) wts[at] = h.syn_weight[src + q];
+                }
+            }
+        }
+    });
+    // (dictionary: n_global_slots < 2^27, so a padding entry reads as code 0 of a bit that never fires)
+    im.ord_groups = n_groups;
+    im.ord_wgs = (n_groups + 3) / 4;
+    im.ord_dict = c->ord_dict ? 1 : 0;
+    TRY(upload(c, groups.data(), groups.size(), &im.ord_group));
+    TRY(upload(c, lane_slot.data(), lane_slot.size(), &im.ord_lane_slot));
+    TRY(upload(c, lane_delay.data(), lane_delay.size(), &im.ord_lane_delay));
+    TRY(upload(c, pre.data(), pre.size(), &im.ord_pre));
+    im.ord_w = nullptr;
+    if (!c->ord_dict) TRY(upload(c, wts.data(), wts.size(), &im.ord_w));
+    im.weight_lut = nullptr;
+    if (c->ord_dict) TRY(upload(c, c->weight_lut.data(), c->weight_lut.size(), &im.weight_lut));
+    c->layout_bytes[0] = n_entries * (c->ord_dict ? 4ull : 12ull) + (uint64_t) n_groups * (sizeof(OrdGroup) + WAVE * 5ull);
+    return 0;
 }
 
 int validate(const sanafe_hip_image *im)
@@ -521,17 +650,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         else fmt = n_acc <= 32768ull ? 4 : 2;
         // format 6 (2-byte words, dictionary-coded weights): at most 32 distinct weight values on the chip, none of them
         // -0.0 (the untouched-accumulator sentinel), at most 1024 accumulators per core
-        bool dict_ok = n_acc <= 1024ull && h.n_synapses > 0;
-        if (dict_ok) // the words carry no axon code: every axon must own at least one of them
-        {
-            std::atomic<bool> empty_axon{false};
-            parallel_for(h.n_axons, [&](uint64_t lo, uint64_t hi) {
-                for (uint64_t a = lo; a < hi; a++)
-                    if (h.ax_nsyn[a] == 0) empty_axon = true;
-            });
-            dict_ok = !empty_axon.load();
-        }
-        if (dict_ok)
+        // At most 32 distinct weight values on the chip: a dictionary (formats 6, 7; ordered delivery with 4-byte entries)
+        bool lut_ok = h.n_synapses > 0;
         {
             std::mutex lut_mutex;
             std::vector<double> lut;
@@ -558,15 +678,28 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 }
                 if (lut.size() > 32) too_many = true;
             });
-            dict_ok = !too_many.load();
-            for (double w : lut) dict_ok = dict_ok && !(w == 0.0 && std::signbit(w));
-            if (dict_ok)
+            lut_ok = lut_ok && !too_many.load();
+            if (lut_ok)
             {
                 std::sort(lut.begin(), lut.end()); // thread-count independent codes
                 lut.resize(32, 0.0);
                 c->weight_lut = lut;
             }
         }
+        // format 6 (2-byte words, dictionary-coded weights): none of the values -0.0 (the untouched-accumulator sentinel), at
+        // most 1024 accumulators per core
+        bool dict_ok = lut_ok && n_acc <= 1024ull;
+        if (dict_ok) // the words carry no axon code: every axon must own at least one of them
+        {
+            std::atomic<bool> empty_axon{false};
+            parallel_for(h.n_axons, [&](uint64_t lo, uint64_t hi) {
+                for (uint64_t a = lo; a < hi; a++)
+                    if (h.ax_nsyn[a] == 0) empty_axon = true;
+            });
+            dict_ok = !empty_axon.load();
+        }
+        if (dict_ok)
+            for (double w : c->weight_lut) dict_ok = dict_ok && !(w == 0.0 && std::signbit(w));
         // Integer accumulators (format 7; formats 0 and 3 when they can): integer weights, and per slice and accumulator the
         // bounds that keep "events * 2^shift + sum of weights" decodable (see DevImage)
         bool int_ok = dict_ok;
@@ -628,6 +761,21 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             else if (want == 3 && weights <= 1 && n_acc <= 4096ull) fmt = 3;
             else if (want == 4 && n_acc <= 32768ull) fmt = 4;
         }
+        // Non-integer weights: fp64 sums depend on the order of the additions, and only the reference's order gives the
+        // reference's bits -- ordered delivery (format 8, ordered_deliver_kernel).  Integer weights are exact in any order
+        // and keep the streaming formats.  Cores that keep only the LAST event of a step (buffer before the dendrite unit)
+        // are order-free by themselves but share the chip-wide kernel choice: such chips stay on the streaming kernels.
+        bool any_last = false;
+        for (uint32_t g = 0; g < h.n_slots && !any_last; g++)
+            any_last = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE &&
+                       (((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST || ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST_DELAY);
+        bool ordered = weights == 2 && !any_last && h.n_synapses > 0 && std::getenv("SANAFE_SYN_FORMAT") == nullptr;
+        if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // tests: 8 forces the ordered layout on integer weights too
+            if (std::atoi(env) == 8 && !any_last && h.n_synapses > 0) ordered = true;
+        if (const char *env = std::getenv("SANAFE_ORDERED")) // 0: non-integer weights through the streaming kernels (A/B runs)
+            if (std::atoi(env) == 0) ordered = false;
+        if (ordered) fmt = 8;
+        c->ord_dict = ordered && lut_ok && h.n_global_slots < (1u << ORD_PRE_BITS) && std::getenv("SANAFE_ORDERED_NO_DICT") == nullptr;
         c->syn_format = fmt;
         c->acc_shift = (fmt == 7 || ((fmt == 0 || fmt == 3) && weights <= 1)) ? acc_shift : 0;
     }
@@ -719,7 +867,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<double> wdev;   // format 4: the fp64 weights at the device positions of their words
         std::vector<uint16_t> meta16; // formats 6, 7: 2-byte words
         if (dict16) meta16.assign(n_dev_syn + 512, 0);
-        else if (c->syn_format != 2) meta.assign(n_dev_syn + 256, 0u);
+        else if (c->syn_format != 2 && c->syn_format != 8) meta.assign(n_dev_syn + 256, 0u);
         if (c->syn_format == 4) wdev.assign(n_dev_syn + 256, 0.0);
         auto lut_code = [&](double w) {
             for (uint32_t q = 0; q < 32; q++)
@@ -760,7 +908,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                         const unsigned long long r64 = (unsigned long long) h.ax_pre[a] | ((unsigned long long) h.ax_nsyn[a] << 32) | ((unsigned long long) cls << 48);
                         std::memcpy(dst + 8 * rel, &r64, 8);
                     }
-                    if (c->syn_format == 2) continue;
+                    if (c->syn_format == 2 || c->syn_format == 8) continue;
                     // synapse words: image position -> device position (same offset inside the chunk)
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[b0 + (rel / WAVE_CHUNK) * WAVE_CHUNK];
@@ -830,7 +978,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             ordered.reserve(h.n_slices);
             for (uint32_t sl = 0; sl < h.n_slices; sl++)
                 if (local_only[sl]) ordered.push_back(desc[sl]);
-            c->n_local_slices = (uint32_t) ordered.size();
+            c->n_local_slices = (c->syn_format == 8) ? 0u : (uint32_t) ordered.size(); // ordered delivery runs in one launch, after the gather
             for (uint32_t sl = 0; sl < h.n_slices; sl++)
                 if (!local_only[sl]) ordered.push_back(desc[sl]);
             TRYC(upload(c, ordered.data(), ordered.size(), &im.slice_desc));
@@ -848,6 +996,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             if (std::atoi(env) == 0) c->small_slices = false;
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
         c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : dict16 ? 2ull : 4ull);
+        // (format 8: build_ordered below replaces [0] with the bytes of the per-accumulator lists)
         c->layout_bytes[1] = n_bytes;
         c->layout_bytes[2] = n_chunks * 8ull;
         c->layout_bytes[3] = (uint64_t) h.n_slices * sizeof(SliceDesc);
@@ -855,7 +1004,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         im.syn_meta = nullptr;
         im.weight_lut = nullptr;
         im.syn_weight = nullptr;
-        if (c->syn_format == 2)
+        if (c->syn_format == 8)
+        {
+            TRYC(build_ordered(c, h)); // per-accumulator lists instead of per-axon synapse words
+        }
+        else if (c->syn_format == 2)
         {
             TRYC(upload(c, h.syn_meta, h.n_synapses, &im.syn_meta));
             TRYC(upload(c, h.syn_weight, h.n_synapses, &im.syn_weight));
@@ -915,7 +1068,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     }
     // the local spike bitmap is this chip's window of the global one: local delivery can start right after the
     // neuron launch, and the multi-GPU exchange gathers in place
-    TRYC(dalloc(c, h.n_global_slots / 32, &st.bits_global));
+    TRYC(dalloc(c, h.n_global_slots / 32 + 2, &st.bits_global)); // (+ a zero word: the bit padding entries of the ordered layout probe)
     st.bits_local = st.bits_global + h.slot_offset / 32;
     TRYC(dalloc(c, 2 * (size_t) im.n_wgs, &st.wg_part));
     TRYC(dalloc(c, 2 * (size_t) h.n_slices, &st.slice_proc));
@@ -975,6 +1128,18 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // The one delivery kernel this chip launches, picked from the table every instantiation lives in (deliver_variants):
     // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
     // first launch.
+    if (c->syn_format == 8)
+    {
+        // the whole spike bitmap in LDS when it leaves room for four workgroups per CU
+        const size_t bitmap = (size_t) h.n_global_slots / 8 + 16;
+        const bool lds_bits = bitmap <= 36 * 1024;
+        c->ord_lds = lds_bits ? bitmap : 0;
+        for (const OrderedVariant &v : ordered_variants)
+            if (v.dict == c->ord_dict && v.lds_bits == lds_bits && v.delay == c->has_delay) c->deliver_fn = v.fn;
+        if (c->ord_lds > 0) HIPC(hipFuncSetAttribute(c->deliver_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->ord_lds));
+        c->deliver_block = 256;
+    }
+    else
     {
         const bool iacc = (c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0;
         // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
@@ -1141,6 +1306,16 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 // Delivers the slices [first, first + count) of the launch order.
 static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
+    if (c->syn_format == 8)
+    {
+        // ordered delivery: one launch for the whole chip -- accumulator groups first (longest lists first), then the
+        // processing-delay sums of the slices (n_local_slices is 0: nothing runs before the gathered bitmap is there)
+        if (count == 0 || first + count != c->im.n_slices) return 0;
+        long long done = c->t_host;
+        void *args[] = {&c->im, &c->st, &done};
+        HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(c->im.ord_wgs + c->im.n_slices), dim3(256), args, c->ord_lds, c->stream));
+        return 0;
+    }
     if (count > 0)
     {
         long long done = c->t_host;
@@ -1475,6 +1650,13 @@ extern "C" int sanafe_hip_read_step_spikes(sanafe_hip_chip *c, int64_t index, ui
         return fail(SANAFE_HIP_ERR_INVALID, "spike record %lld not available", (long long) index);
     const size_t words = c->im.n_slots / 32;
     return d2h(c, bits_out, c->st.spike_log + (size_t) index * words, words);
+}
+extern "C" int sanafe_hip_read_step_spike_rows(sanafe_hip_chip *c, int64_t first, int64_t count, uint32_t *bits_out)
+{
+    if (!c || !bits_out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.spike_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "spike records [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    const size_t words = c->im.n_slots / 32; // the log is contiguous on the device: one copy for all rows
+    return d2h(c, bits_out, c->st.spike_log + (size_t) first * words, (size_t) count * words);
 }
 extern "C" int sanafe_hip_read_step_status(sanafe_hip_chip *c, int64_t first, int64_t count, uint8_t *out)
 {

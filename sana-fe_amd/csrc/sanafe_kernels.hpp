@@ -129,7 +129,26 @@ struct DevImage
     int syn_format;               // 0 .. 4, 6, 7 as above
     int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
+    // Ordered delivery (syn_format 8, non-integer weights): the synapses regrouped PER ACCUMULATOR (post neuron x delay
+    // value), each list in the reference's delivery order; 64 lists side by side make one group (ordered_deliver_kernel).
+    uint32_t ord_groups, ord_wgs; // groups of 64 accumulators; workgroups (4 groups each)
+    const struct OrdGroup *ord_group;   // [ord_groups], longest lists first
+    const uint32_t *ord_lane_slot;      // [ord_groups * 64] local slot of the lane's post neuron, 0xffffffff: none
+    const uint8_t *ord_lane_delay;      // [ord_groups * 64] delay value (accumulator row) of the lane's list
+    const uint32_t *ord_pre;            // entries [rows][64] per group: GLOBAL pre slot (| weight code << 27 with a dictionary);
+                                        // padding entries point at bit n_global_slots, which never fires
+    const double *ord_w;                // the entries' weights (no dictionary), same indexing
+    int ord_dict;                       // weights are 5-bit codes into weight_lut
 };
+// One group of the ordered layout: 64 accumulators whose lists lie side by side, entry k of lane l at off + 64 k + l.
+struct OrdGroup
+{
+    unsigned long long off; // first entry
+    uint32_t rows;          // entries per lane, padded to a multiple of ORD_UNROLL
+    uint32_t pad;
+};
+constexpr int ORD_UNROLL = 8;
+constexpr uint32_t ORD_PRE_BITS = 27; // dictionary entries: pre slot in 27 bits, weight code above
 
 // The reduction of a step is split in two levels that ride in the leading workgroups of LATER neuron launches,
 // so a timestep stays two launches and no launch waits on a serial reduction:
@@ -1449,6 +1468,176 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         st.ring_valid[gi] = 1;
         if (gated) st.arrived[nbase + n] = 1;
     }
+}
+
+// ---------------------------------------------------------------------------------------
+// K2o: ORDERED spike delivery, for chips with non-integer weights (syn_format 8).
+//
+// fp64 addition does not associate: the reference adds a step's synaptic currents into an accumulator one by one, in
+// delivery order -- source core, source neuron, connection (src/chip.cpp:661-690, 748-761; `value_or(0.0) + current`,
+// src/models.cpp:71-131) -- and any other association can flip a threshold-borderline spike.  The streaming kernel
+// above adds with LDS / global atomics in arrival order, which is exact only for integers.  Here every accumulator
+// (post neuron x delay value) is OWNED BY ONE LANE that walks the accumulator's own list of (pre slot, weight) in the
+// reference's order and folds the weights of the pre neurons that spiked -- starting from the value the delay ring
+// already holds (charge that earlier steps sent to the same future step): the same additions in the same order as the
+// reference, so potentials and spikes are bit-identical to it and from run to run.  No atomics, no slices.
+//
+//   grid = ord_wgs + n_slices, block = 256, dynamic LDS = the whole spike bitmap (LDS_BITS) -- a probe is one ds_read
+//   leading workgroups: 4 groups of 64 accumulators each (one per wavefront), longest lists first.  The 64 lists of a
+//                       group lie side by side ([row][lane]): a row is one coalesced 256-byte (+ 512-byte weight) load,
+//                       ORD_UNROLL rows are in flight while the previous ORD_UNROLL are folded.  HBM-bound: every entry is
+//                       read once per step, 4 bytes with a weight dictionary (<= 32 distinct values), 12 without.
+//   trailing workgroups: one per delivery slice -- the processing-delay sum of the slice's spiking axons (the simple
+//                       timing model's per-core message processing time, src/chip.cpp:738-764) from the axon records,
+//                       reduced in a fixed order like deliver_kernel does.
+// ---------------------------------------------------------------------------------------
+template <bool DICT, bool LDS_BITS, bool HAS_DELAY>
+__global__ void __launch_bounds__(256) ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+{
+    __shared__ double s_red[4];
+    __shared__ double s_lut[DICT ? 32 : 1];
+    uint32_t *sb = reinterpret_cast<uint32_t *>(deliver_lds);
+    const uint32_t n_words = im.n_global_slots / 32;
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    if (DICT && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x];
+    if (LDS_BITS)
+    {
+        for (uint32_t i = threadIdx.x; i < n_words; i += 256) sb[i] = st.bits_global[i];
+        if (threadIdx.x == 0) sb[n_words] = 0u; // the bit padding entries point at
+    }
+    if (DICT || LDS_BITS) __syncthreads();
+    // (bits_global carries one zero word past its end for the same purpose)
+    auto spiked = [&](uint32_t pre) -> bool { return ((LDS_BITS ? sb[pre >> 5] : st.bits_global[pre >> 5]) >> (pre & 31u)) & 1u; };
+    const long long t = done + 1;
+    if (blockIdx.x < im.ord_wgs)
+    {
+        const uint32_t g = blockIdx.x * 4u + (uint32_t) wave;
+        if (g >= im.ord_groups) return;
+        const OrdGroup og = im.ord_group[g];
+        const uint32_t slot = im.ord_lane_slot[(size_t) g * WAVE + lane];
+        const uint32_t d = im.ord_lane_delay[(size_t) g * WAVE + lane];
+        const bool live = slot != 0xffffffffu;
+        const uint32_t kind = (HAS_DELAY && live) ? (im.slot_cls[slot] >> 3) & 7u : (uint32_t) SANAFE_IN_BUFFERED;
+        const bool taps = kind == SANAFE_IN_TAPS, gated = kind == SANAFE_IN_GATED;
+        const uint32_t r0 = (uint32_t) ((t + 1) % (long long) im.ring_slots); // scalar
+        uint32_t wrow = r0 + d + (gated ? 1u : 0u);
+        while (wrow >= im.ring_slots) wrow -= im.ring_slots;
+        const size_t gi = (size_t) wrow * im.n_slots + (live ? slot : 0u);
+        // the accumulator continues what earlier steps sent to the same future step: value_or(0.0) + current
+        // (consumed entries are left at 0.0 by the neuron launch)
+        double acc = (live && !taps) ? st.ring[gi] : 0.0;
+        bool touched = false;
+        const uint32_t *pp = im.ord_pre + og.off + lane;
+        const double *wp = DICT ? nullptr : im.ord_w + og.off + lane;
+        uint32_t e[ORD_UNROLL];
+        double w[DICT ? 1 : ORD_UNROLL];
+#pragma unroll
+        for (int u = 0; u < ORD_UNROLL; u++)
+        {
+            e[u] = __builtin_nontemporal_load(pp + (size_t) u * WAVE);
+            if (!DICT) w[u] = __builtin_nontemporal_load(wp + (size_t) u * WAVE);
+        }
+        for (uint32_t r = 0; r < og.rows; r += ORD_UNROLL)
+        {
+            uint32_t ce[ORD_UNROLL];
+            double cw[DICT ? 1 : ORD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ORD_UNROLL; u++)
+            {
+                ce[u] = e[u];
+                if (!DICT) cw[u] = w[u];
+            }
+            // the next rows, unconditionally (past the end: these again), while the current ones are folded
+            const size_t nr = (size_t) ((r + ORD_UNROLL < og.rows) ? r + ORD_UNROLL : r) * WAVE;
+#pragma unroll
+            for (int u = 0; u < ORD_UNROLL; u++)
+            {
+                e[u] = __builtin_nontemporal_load(pp + nr + (size_t) u * WAVE);
+                if (!DICT) w[u] = __builtin_nontemporal_load(wp + nr + (size_t) u * WAVE);
+            }
+            bool f[ORD_UNROLL];
+            double wv[ORD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ORD_UNROLL; u++)
+            {
+                f[u] = spiked(DICT ? ce[u] & ((1u << ORD_PRE_BITS) - 1u) : ce[u]);
+                wv[u] = DICT ? s_lut[ce[u] >> ORD_PRE_BITS] : cw[u];
+            }
+#pragma unroll
+            for (int u = 0; u < ORD_UNROLL; u++) // the fold itself: strictly in list order
+                if (f[u])
+                {
+                    acc += wv[u];
+                    touched = true;
+                }
+        }
+        if (live && touched)
+        {
+            if (taps)
+            {
+                // row d is tap d of the neuron's dendrite: taps_kernel integrates it after this launch
+                st.tap_in[(size_t) im.slot_aux[slot] * 8u + d] = acc;
+                st.arrived[slot] = 1;
+            }
+            else
+            {
+                st.ring[gi] = acc;
+                st.ring_valid[gi] = 1;
+                if (gated) st.arrived[slot] = 1;
+            }
+        }
+        return;
+    }
+    // ---- processing-delay sum of one delivery slice ----
+    const SliceDesc sd = im.slice_desc[blockIdx.x - im.ord_wgs];
+    const uint32_t n_ax = sd.n_ax;
+    const bool compact = sd.mode != 0;
+    const unsigned char *rec = im.ax_bytes + sd.rec_off;
+    const uint32_t *chunk_pre0 = im.chunk_pre0 + sd.chunk0;
+    double proc = 0.0;
+    for (uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; c0 < n_ax; c0 += 4u * WAVE_CHUNK) // wave-uniform bounds
+    {
+        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
+        if (compact)
+        {
+            unsigned long long q = 0;
+            if (a0 + AX_PER_THREAD <= n_ax) q = *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0);
+            else
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                    if (a0 + k < n_ax) q |= (unsigned long long) *reinterpret_cast<const uint16_t *>(rec + 2ull * (a0 + k)) << (16 * k);
+            uint32_t dl[AX_PER_THREAD];
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++) dl[k] = (uint32_t) (q >> (16 * k)) & 0xffu;
+            const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+            uint32_t pre = chunk_pre0[c0 / WAVE_CHUNK] + wave_inclusive_scan(lane_d) - lane_d;
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+            {
+                pre += dl[k];
+                const uint32_t nsyn = (uint32_t) (q >> (16 * k + 8)) & 0xffu;
+                if (a0 + k < n_ax && spiked(pre)) proc += sd.ain_lat + (double) nsyn * sd.slice_lat;
+            }
+        }
+        else
+        {
+            const unsigned long long *wide = reinterpret_cast<const unsigned long long *>(rec);
+#pragma unroll
+            for (int k = 0; k < AX_PER_THREAD; k++)
+                if (a0 + k < n_ax)
+                {
+                    const unsigned long long r = wide[a0 + k];
+                    const uint32_t nsyn = (uint32_t) ((r >> 32) & 0xffffu), lcls = (uint32_t) ((r >> 48) & 0xffu);
+                    if (spiked((uint32_t) r))
+                        proc += (lcls != 255u) ? sd.ain_lat + (double) nsyn * im.lat_class[lcls] : im.ax_proc_delay[sd.a_beg + a0 + k];
+                }
+        }
+    }
+    proc = wave_sum(proc);
+    if (lane == 0) s_red[wave] = proc;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        st.slice_proc[(size_t) (done & 1) * im.n_slices + sd.slice_id] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
 }
 
 // ---------------------------------------------------------------------------------------

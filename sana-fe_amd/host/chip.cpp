@@ -1192,11 +1192,11 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 chip->rec_totals.resize(done + m);
                 DEV(sanafe_hip_read_step_totals(chip->dev, 0, m, chip->rec_totals.data() + done));
                 chip->rec_spike_bits.resize(done + m);
+                const size_t words = mc.n_slots / 32;
+                std::vector<uint32_t> rows(static_cast<size_t>(m) * words); // the device log is contiguous: one copy per chunk
+                DEV(sanafe_hip_read_step_spike_rows(chip->dev, 0, m, rows.data()));
                 for (int64_t s = 0; s < m; s++)
-                {
-                    chip->rec_spike_bits[done + s].resize(mc.n_slots / 32);
-                    DEV(sanafe_hip_read_step_spikes(chip->dev, s, chip->rec_spike_bits[done + s].data()));
-                }
+                    chip->rec_spike_bits[done + s].assign(rows.begin() + static_cast<size_t>(s) * words, rows.begin() + static_cast<size_t>(s + 1) * words);
             }
         }
         DEV(sanafe_hip_read_totals(chip->dev, &run));

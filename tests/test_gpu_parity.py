@@ -72,7 +72,9 @@ def test_example_chip_simple(S):
 
 
 def test_example_chip_probe_values(S):
-    """The reference's recorded outputs for C1, now from the GPU path, detailed timing."""
+    """The survey-time outputs of the reference for C1 from the GPU path, detailed timing: counters, spike and
+    potential traces are exact pins; the two 3-digit doubles (energy, sim_time) guard against gross errors only --
+    `detailed` timestamps and energies are PARITY UNPINNED."""
     arch, net = nets.example(S)
     chip = S.SpikingChip(arch)
     chip.load(net)
