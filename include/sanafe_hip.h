@@ -248,6 +248,10 @@ int sanafe_hip_layout_bytes(sanafe_hip_chip *chip, uint64_t *out, int n);
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)
  * soma units: neurons -> [exchange spike bitmaps] -> deliver. */
 int sanafe_hip_step_neurons(sanafe_hip_chip *chip);
+/* Records for the split step: the next n_steps split steps keep what sanafe_hip_step's `record` bits keep (bit 0 totals +
+ * spike bitmap, bit 1 the NeuronStatus of every slot, bit 3 the logged state), read back with sanafe_hip_read_step_*;
+ * record 0 switches recording off.  A tile-sharded chip records its own window; the host library gathers the ranks. */
+int sanafe_hip_record_begin(sanafe_hip_chip *chip, int64_t n_steps, int record);
 int sanafe_hip_step_deliver(sanafe_hip_chip *chip, int simple_timing, int record);
 /* Tile-sharded runs overlap the exchange with delivery: the slices whose axons all start on this chip are
  * delivered first (they need only the local window of the bitmap, which the neuron launch wrote in place),

@@ -122,8 +122,11 @@ int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int64_t *neuron
  * form of the reference's serial routing loop, src/chip.cpp:656-692) and returns the RunData of the WHOLE chip on
  * every rank: counters and energies summed over the ranks in rank order, sim_time from the per-step maximum over
  * all cores of all ranks (simple timing model, src/schedule.cpp:61-102).  The exchange must be set up first;
- * without one, sim() on a sharded chip fails.  `detailed` timing, traces and plugin units need the whole chip in
- * one process and are refused.
+ * without one, sim() on a sharded chip fails.  Recorded runs (SANAFE_RECORD_STEPS: spike and perf traces) gather the
+ * ranks' per-step records once per chunk of steps.  `detailed` timing and message traces are whole-chip host
+ * algorithms (one global event queue): after sanafe_chip_attach_whole every rank gathers the NeuronStatus of all
+ * neurons per chunk and replays the whole chip's messages on a mapped-only twin, as the reference does in its one
+ * process.  Potential / neuron traces, optional perf columns and plugin units are refused on sharded chips.
  *   RCCL:     rank 0 calls sanafe_comm_unique_id, ships the 128 bytes to the others by whatever channel launched
  *             them, and every rank calls sanafe_chip_comm_init_rccl (collective: ncclCommInitRank).  The all-gather
  *             runs on a communication stream directly on the device bitmap, overlapped with the delivery of the
@@ -135,6 +138,10 @@ typedef int (*sanafe_allgather_fn)(void *ctx, const void *send, uint64_t bytes, 
 int sanafe_comm_unique_id(uint8_t id[SANAFE_COMM_ID_BYTES]);
 int sanafe_chip_comm_init_rccl(sanafe_chip *chip, const uint8_t id[SANAFE_COMM_ID_BYTES]);
 int sanafe_chip_comm_init_callback(sanafe_chip *chip, sanafe_allgather_fn fn, void *ctx);
+/* Maps the WHOLE chip a second time on the host (no device, one rank) from the complete description -- the tables the
+ * detailed NoC schedule and the message trace of a tile-sharded chip run on (src/schedule.cpp:208-620 is one global
+ * event queue over all messages of a step).  `desc` must describe every neuron and edge of the chip. */
+int sanafe_chip_attach_whole(sanafe_chip *chip, const sanafe_desc *desc);
 
 /* Split step for callers that drive the exchange themselves. */
 int sanafe_chip_step_neurons(sanafe_chip *chip);

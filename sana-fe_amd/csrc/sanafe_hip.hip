@@ -96,6 +96,8 @@ struct sanafe_hip_chip
     uint32_t n_log_v{0}, n_log_u{0};
     double *d_state_log{nullptr}; // [state_log_cap][n_log_v + n_log_u]
     long long state_log_cap{0};
+    int split_record{0};        // record bits of the split step (sanafe_hip_record_begin)
+    long long split_index{0};   // record slot the next split step writes
     uint32_t n_local_slices{0}; // leading slice descriptors whose axons all start on this chip
     int neuron_model{0};      // soma model every live slot runs (SANAFE_SOMA_LIF / _TRUENORTH), 0 when they differ
     bool uni{false};          // every live slot carries the class word us.cls (UniformSoma)
@@ -108,6 +110,7 @@ struct sanafe_hip_chip
     std::vector<void *> allocs;
     size_t deliver_lds{0};
     bool ord_dict{false};           // format 8: the entries carry 5-bit codes into weight_lut instead of fp64 weights
+    int ord_debug{0};               // SANAFE_ORDERED_ROLE=1/2: launch one role of ordered_deliver_kernel only (profiling)
     size_t ord_lds{0};              // format 8: dynamic LDS of ordered_deliver_kernel (the spike bitmap), 0: probe global memory
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     uint32_t deliver_block{0};
@@ -269,7 +272,8 @@ int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
     {
         const uint32_t longest = count[order[(size_t) g * WAVE]];
         groups[g].off = n_entries;
-        groups[g].rows = (longest + ORD_UNROLL - 1) / ORD_UNROLL * ORD_UNROLL;
+        const uint32_t quantum = c->ord_dict ? ORD_DICT_ROWS : (uint32_t) ORD_UNROLL;
+        groups[g].rows = (longest + quantum - 1) / quantum * quantum;
         groups[g].pad = 0;
         n_entries += (uint64_t) groups[g].rows * WAVE;
         for (uint32_t l = 0; l < (uint32_t) WAVE && (size_t) g * WAVE + l < order.size(); l++)
@@ -288,7 +292,7 @@ int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
         }
     }
     const uint32_t pad_pre = h.n_global_slots; // its bit is always 0 (one spare zero word behind the bitmap)
-    std::vector<uint32_t> pre(n_entries + (size_t) ORD_UNROLL * WAVE, pad_pre);
+    std::vector<uint32_t> pre(n_entries + (size_t) ORD_DICT_ROWS * WAVE, pad_pre);
     std::vector<double> wts;
     if (!c->ord_dict) wts.assign(n_entries + (size_t) ORD_UNROLL * WAVE, 0.0);
     auto lut_code = [&](double w) {
@@ -313,7 +317,9 @@ int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
                     if ((m >> 19) & 1u) continue;
                     const uint64_t acc = acc_of((uint32_t) k, m);
                     const uint32_t pl = place[acc], g = pl / WAVE, l = pl % WAVE;
-                    const uint64_t at = groups[g].off + (uint64_t) count[acc]++ * WAVE + l;
+                    const uint32_t row = count[acc]++;
+                    const uint64_t at = c->ord_dict ? groups[g].off + (uint64_t) (row / 4u) * (4u * WAVE) + 4u * l + (row & 3u)
+                                                    : groups[g].off + (uint64_t) row * WAVE + l;
                     pre[at] = c->ord_dict ? (h.ax_pre[a] | (lut_code(h.syn_weight[src + q]) << ORD_PRE_BITS)) : h.ax_pre[a];
                     if (!c->ord_dict) wts[at] = h.syn_weight[src + q];
                 }
@@ -322,7 +328,9 @@ int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
     });
     // (dictionary: n_global_slots < 2^27, so a padding entry reads as code 0 of a bit that never fires)
     im.ord_groups = n_groups;
-    im.ord_wgs = (n_groups + 3) / 4;
+    // one wavefront per group; at least enough wavefronts to spread the slices' processing-delay walk over the chip
+    im.ord_wgs = std::max<uint32_t>((n_groups + 3) / 4, std::min<uint32_t>((h.n_slices + 3) / 4, 1024u));
+    im.ord_walk_slices = h.n_slices;
     im.ord_dict = c->ord_dict ? 1 : 0;
     TRY(upload(c, groups.data(), groups.size(), &im.ord_group));
     TRY(upload(c, lane_slot.data(), lane_slot.size(), &im.ord_lane_slot));
@@ -1132,8 +1140,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     {
         // the whole spike bitmap in LDS when it leaves room for four workgroups per CU
         const size_t bitmap = (size_t) h.n_global_slots / 8 + 16;
-        const bool lds_bits = bitmap <= 36 * 1024;
+        bool lds_bits = bitmap <= 36 * 1024;
+        if (const char *env = std::getenv("SANAFE_ORDERED_LDS_BITS")) // tests: 0 probes the bitmap in global memory
+            if (std::atoi(env) == 0) lds_bits = false;
         c->ord_lds = lds_bits ? bitmap : 0;
+        if (const char *env = std::getenv("SANAFE_ORDERED_ROLE")) c->ord_debug = std::atoi(env);
         for (const OrderedVariant &v : ordered_variants)
             if (v.dict == c->ord_dict && v.lds_bits == lds_bits && v.delay == c->has_delay) c->deliver_fn = v.fn;
         if (c->ord_lds > 0) HIPC(hipFuncSetAttribute(c->deliver_fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->ord_lds));
@@ -1308,12 +1319,15 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
     if (c->syn_format == 8)
     {
-        // ordered delivery: one launch for the whole chip -- accumulator groups first (longest lists first), then the
-        // processing-delay sums of the slices (n_local_slices is 0: nothing runs before the gathered bitmap is there)
+        // ordered delivery: one launch for the whole chip -- every wavefront folds an accumulator group, then walks
+        // delivery slices for their processing-delay sums (n_local_slices is 0: nothing runs before the gathered bitmap is there)
         if (count == 0 || first + count != c->im.n_slices) return 0;
         long long done = c->t_host;
-        void *args[] = {&c->im, &c->st, &done};
-        HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(c->im.ord_wgs + c->im.n_slices), dim3(256), args, c->ord_lds, c->stream));
+        DevImage im = c->im;
+        if (c->ord_debug == 1) im.ord_walk_slices = 0; // measurements only (SANAFE_ORDERED_ROLE): accumulator groups alone
+        else if (c->ord_debug == 2) im.ord_groups = 0; // ... or the processing-delay walk alone
+        void *args[] = {&im, &c->st, &done};
+        HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(im.ord_wgs), dim3(256), args, c->ord_lds, c->stream));
         return 0;
     }
     if (count > 0)
@@ -1476,14 +1490,36 @@ static int timed_event(sanafe_hip_chip *c)
     return 0;
 }
 
+extern "C" int sanafe_hip_record_begin(sanafe_hip_chip *c, int64_t n_steps, int record)
+{
+    if (!c || n_steps < 0) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    c->split_record = 0;
+    c->split_index = 0;
+    if (record == 0) return 0;
+    TRY(flush_pending(c)); // an earlier step's record must not land in the resized log
+    TRY(ensure_log(c, std::max<int64_t>(n_steps, 1), (record & 2) != 0));
+    if (record & 8) TRY(ensure_state_log(c, std::max<int64_t>(n_steps, 1)));
+    HIPCHK(hipMemsetAsync(c->st.rec, 0, sizeof(long long), c->stream));
+    c->split_record = record;
+    return 0;
+}
+
 extern "C" int sanafe_hip_step_neurons(sanafe_hip_chip *c)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     HIPCHK(hipSetDevice(c->device));
-    if (!c->timing) return launch_neurons(c, 0, 0);
+    if (c->split_record && c->split_index >= c->st.log_cap) return fail(SANAFE_HIP_ERR_INVALID, "more split steps than sanafe_hip_record_begin announced");
+    if (!c->timing)
+    {
+        TRY(launch_neurons(c, c->split_record, c->split_index));
+        if (c->split_record & 8) TRY(launch_state_log(c, c->split_index));
+        return 0;
+    }
     TRY(flush_pending(c));
     TRY(timed_event(c));
-    TRY(launch_neurons(c, 0, 0));
+    TRY(launch_neurons(c, c->split_record, c->split_index));
+    if (c->split_record & 8) TRY(launch_state_log(c, c->split_index));
     return timed_event(c);
 }
 
@@ -1500,14 +1536,16 @@ extern "C" int sanafe_hip_step_deliver(sanafe_hip_chip *c, int simple_timing, in
     {
         TRY(launch_deliver(c, 0, c->im.n_slices));
         TRY(launch_taps(c));
-        finish_step(c, simple_timing, 0, 0);
+        finish_step(c, simple_timing, c->split_record, c->split_index);
+        if (c->split_record) c->split_index++;
         return 0;
     }
     TRY(timed_event(c));
     TRY(launch_deliver(c, 0, c->im.n_slices));
     TRY(launch_taps(c));
     TRY(timed_event(c));
-    finish_step(c, simple_timing, 0, 0);
+    finish_step(c, simple_timing, c->split_record, c->split_index);
+    if (c->split_record) c->split_index++;
     TRY(flush_pending(c));
     return timed_event(c);
 }
@@ -1524,7 +1562,8 @@ extern "C" int sanafe_hip_step_deliver_remote(sanafe_hip_chip *c, int simple_tim
     HIPCHK(hipSetDevice(c->device));
     TRY(launch_deliver(c, c->n_local_slices, c->im.n_slices - c->n_local_slices));
     TRY(launch_taps(c));
-    finish_step(c, simple_timing, 0, 0);
+    finish_step(c, simple_timing, c->split_record, c->split_index);
+    if (c->split_record) c->split_index++;
     return 0;
 }
 extern "C" int sanafe_hip_slice_split(sanafe_hip_chip *c, uint32_t *n_local, uint32_t *n_remote)

@@ -131,7 +131,8 @@ struct DevImage
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
     // Ordered delivery (syn_format 8, non-integer weights): the synapses regrouped PER ACCUMULATOR (post neuron x delay
     // value), each list in the reference's delivery order; 64 lists side by side make one group (ordered_deliver_kernel).
-    uint32_t ord_groups, ord_wgs; // groups of 64 accumulators; workgroups (4 groups each)
+    uint32_t ord_groups, ord_wgs; // groups of 64 accumulators; workgroups of the launch (4 wavefronts: a group each, then slices)
+    uint32_t ord_walk_slices;     // n_slices (0: profiling without the processing-delay walk)
     const struct OrdGroup *ord_group;   // [ord_groups], longest lists first
     const uint32_t *ord_lane_slot;      // [ord_groups * 64] local slot of the lane's post neuron, 0xffffffff: none
     const uint8_t *ord_lane_delay;      // [ord_groups * 64] delay value (accumulator row) of the lane's list
@@ -144,10 +145,12 @@ struct DevImage
 struct OrdGroup
 {
     unsigned long long off; // first entry
-    uint32_t rows;          // entries per lane, padded to a multiple of ORD_UNROLL
+    uint32_t rows;          // entries per lane, padded to a multiple of ORD_UNROLL (dictionary: ORD_DICT_ROWS); with a dictionary
+                            // entry k of lane l sits at off + 256 (k / 4) + 4 l + k % 4 (four rows per 16-byte load)
     uint32_t pad;
 };
-constexpr int ORD_UNROLL = 8;
+constexpr int ORD_UNROLL = 8;                         // loads in flight per lane while the previous ORD_UNROLL are folded
+constexpr uint32_t ORD_DICT_ROWS = 4 * ORD_UNROLL;    // dictionary entries: four rows per 16-byte load
 constexpr uint32_t ORD_PRE_BITS = 27; // dictionary entries: pre slot in 27 bits, weight code above
 
 // The reduction of a step is split in two levels that ride in the leading workgroups of LATER neuron launches,
@@ -1482,19 +1485,20 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 // already holds (charge that earlier steps sent to the same future step): the same additions in the same order as the
 // reference, so potentials and spikes are bit-identical to it and from run to run.  No atomics, no slices.
 //
-//   grid = ord_wgs + n_slices, block = 256, dynamic LDS = the whole spike bitmap (LDS_BITS) -- a probe is one ds_read
-//   leading workgroups: 4 groups of 64 accumulators each (one per wavefront), longest lists first.  The 64 lists of a
-//                       group lie side by side ([row][lane]): a row is one coalesced 256-byte (+ 512-byte weight) load,
-//                       ORD_UNROLL rows are in flight while the previous ORD_UNROLL are folded.  HBM-bound: every entry is
-//                       read once per step, 4 bytes with a weight dictionary (<= 32 distinct values), 12 without.
-//   trailing workgroups: one per delivery slice -- the processing-delay sum of the slice's spiking axons (the simple
-//                       timing model's per-core message processing time, src/chip.cpp:738-764) from the axon records,
-//                       reduced in a fixed order like deliver_kernel does.
+//   grid = ord_wgs, block = 256 = 4 independent wavefronts (no barrier after the staging), dynamic LDS = the whole spike
+//   bitmap (LDS_BITS) -- a probe is one ds_read.  Every wavefront
+//     1. folds ONE group of 64 accumulators, longest lists first.  The 64 lists of a group lie side by side
+//        ([row][lane]): a row is one coalesced load, ORD_UNROLL loads are in flight while the previous ORD_UNROLL are
+//        folded.  HBM-bound: every entry is read once per step, 4 bytes with a weight dictionary (<= 32 distinct
+//        values; four rows per 16-byte load), 12 without;
+//     2. then takes whole delivery slices (its number, + the wavefronts of the launch, ...): the processing-delay sum of
+//        the slice's spiking axons (the simple timing model's per-core message processing time, src/chip.cpp:738-764)
+//        from the axon records, runs of 8 chunks in flight, summed in a fixed order.
 // ---------------------------------------------------------------------------------------
 template <bool DICT, bool LDS_BITS, bool HAS_DELAY>
-__global__ void __launch_bounds__(256) ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8))) // (4 workgroups per CU hold the bitmap in LDS)
+ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
-    __shared__ double s_red[4];
     __shared__ double s_lut[DICT ? 32 : 1];
     uint32_t *sb = reinterpret_cast<uint32_t *>(deliver_lds);
     const uint32_t n_words = im.n_global_slots / 32;
@@ -1510,10 +1514,10 @@ __global__ void __launch_bounds__(256) ordered_deliver_kernel(DevImage im, DevSt
     // (bits_global carries one zero word past its end for the same purpose)
     auto spiked = [&](uint32_t pre) -> bool { return ((LDS_BITS ? sb[pre >> 5] : st.bits_global[pre >> 5]) >> (pre & 31u)) & 1u; };
     const long long t = done + 1;
-    if (blockIdx.x < im.ord_wgs)
+    const uint32_t gw = blockIdx.x * 4u + (uint32_t) wave; // this wavefront among all of the launch
+    if (gw < im.ord_groups)
     {
-        const uint32_t g = blockIdx.x * 4u + (uint32_t) wave;
-        if (g >= im.ord_groups) return;
+        const uint32_t g = gw;
         const OrdGroup og = im.ord_group[g];
         const uint32_t slot = im.ord_lane_slot[(size_t) g * WAVE + lane];
         const uint32_t d = im.ord_lane_delay[(size_t) g * WAVE + lane];
@@ -1528,49 +1532,87 @@ __global__ void __launch_bounds__(256) ordered_deliver_kernel(DevImage im, DevSt
         // (consumed entries are left at 0.0 by the neuron launch)
         double acc = (live && !taps) ? st.ring[gi] : 0.0;
         bool touched = false;
-        const uint32_t *pp = im.ord_pre + og.off + lane;
-        const double *wp = DICT ? nullptr : im.ord_w + og.off + lane;
-        uint32_t e[ORD_UNROLL];
-        double w[DICT ? 1 : ORD_UNROLL];
-#pragma unroll
-        for (int u = 0; u < ORD_UNROLL; u++)
+        if constexpr (DICT)
         {
-            e[u] = __builtin_nontemporal_load(pp + (size_t) u * WAVE);
-            if (!DICT) w[u] = __builtin_nontemporal_load(wp + (size_t) u * WAVE);
-        }
-        for (uint32_t r = 0; r < og.rows; r += ORD_UNROLL)
-        {
-            uint32_t ce[ORD_UNROLL];
-            double cw[DICT ? 1 : ORD_UNROLL];
+            // 4-byte entries (pre slot | weight code << 27), four consecutive rows of a lane side by side: one 16-byte load per
+            // lane brings four entries, ORD_UNROLL loads = ORD_DICT_ROWS rows are in flight while the previous ones are folded
+            const uint4 *pp = reinterpret_cast<const uint4 *>(im.ord_pre + og.off) + lane; // block b of 4 rows: pp[b * 64]
+            uint4 e[ORD_UNROLL];
 #pragma unroll
-            for (int u = 0; u < ORD_UNROLL; u++)
+            for (int u = 0; u < ORD_UNROLL; u++) e[u] = load_stream16(pp + (size_t) u * WAVE);
+            for (uint32_t r = 0; r < og.rows; r += ORD_DICT_ROWS)
             {
-                ce[u] = e[u];
-                if (!DICT) cw[u] = w[u];
-            }
-            // the next rows, unconditionally (past the end: these again), while the current ones are folded
-            const size_t nr = (size_t) ((r + ORD_UNROLL < og.rows) ? r + ORD_UNROLL : r) * WAVE;
+                uint4 ce[ORD_UNROLL];
 #pragma unroll
-            for (int u = 0; u < ORD_UNROLL; u++)
-            {
-                e[u] = __builtin_nontemporal_load(pp + nr + (size_t) u * WAVE);
-                if (!DICT) w[u] = __builtin_nontemporal_load(wp + nr + (size_t) u * WAVE);
-            }
-            bool f[ORD_UNROLL];
-            double wv[ORD_UNROLL];
+                for (int u = 0; u < ORD_UNROLL; u++) ce[u] = e[u];
+                // the next rows, unconditionally (past the end: these again)
+                const size_t nb = (size_t) (((r + ORD_DICT_ROWS < og.rows) ? r + ORD_DICT_ROWS : r) / 4u) * WAVE;
 #pragma unroll
-            for (int u = 0; u < ORD_UNROLL; u++)
-            {
-                f[u] = spiked(DICT ? ce[u] & ((1u << ORD_PRE_BITS) - 1u) : ce[u]);
-                wv[u] = DICT ? s_lut[ce[u] >> ORD_PRE_BITS] : cw[u];
-            }
+                for (int u = 0; u < ORD_UNROLL; u++) e[u] = load_stream16(pp + nb + (size_t) u * WAVE);
+                // eight entries at a time: their bitmap probes and dictionary reads in flight together, then the fold
 #pragma unroll
-            for (int u = 0; u < ORD_UNROLL; u++) // the fold itself: strictly in list order
-                if (f[u])
+                for (int h = 0; h < ORD_UNROLL; h += 2)
                 {
-                    acc += wv[u];
-                    touched = true;
+                    const uint32_t q[8] = {ce[h].x, ce[h].y, ce[h].z, ce[h].w, ce[h + 1].x, ce[h + 1].y, ce[h + 1].z, ce[h + 1].w};
+                    bool f[8];
+                    double wv[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                    {
+                        f[j] = spiked(q[j] & ((1u << ORD_PRE_BITS) - 1u));
+                        wv[j] = s_lut[q[j] >> ORD_PRE_BITS];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) // the fold itself: strictly in list order
+                        if (f[j])
+                        {
+                            acc += wv[j];
+                            touched = true;
+                        }
                 }
+            }
+        }
+        else
+        {
+            const uint32_t *pp = im.ord_pre + og.off + lane;
+            const double *wp = im.ord_w + og.off + lane;
+            uint32_t e[ORD_UNROLL];
+            double w[ORD_UNROLL];
+#pragma unroll
+            for (int u = 0; u < ORD_UNROLL; u++)
+            {
+                e[u] = __builtin_nontemporal_load(pp + (size_t) u * WAVE);
+                w[u] = __builtin_nontemporal_load(wp + (size_t) u * WAVE);
+            }
+            for (uint32_t r = 0; r < og.rows; r += ORD_UNROLL)
+            {
+                uint32_t ce[ORD_UNROLL];
+                double cw[ORD_UNROLL];
+#pragma unroll
+                for (int u = 0; u < ORD_UNROLL; u++)
+                {
+                    ce[u] = e[u];
+                    cw[u] = w[u];
+                }
+                // the next rows, unconditionally (past the end: these again), while the current ones are folded
+                const size_t nr = (size_t) ((r + ORD_UNROLL < og.rows) ? r + ORD_UNROLL : r) * WAVE;
+#pragma unroll
+                for (int u = 0; u < ORD_UNROLL; u++)
+                {
+                    e[u] = __builtin_nontemporal_load(pp + nr + (size_t) u * WAVE);
+                    w[u] = __builtin_nontemporal_load(wp + nr + (size_t) u * WAVE);
+                }
+                bool f[ORD_UNROLL];
+#pragma unroll
+                for (int u = 0; u < ORD_UNROLL; u++) f[u] = spiked(ce[u]);
+#pragma unroll
+                for (int u = 0; u < ORD_UNROLL; u++) // the fold itself: strictly in list order
+                    if (f[u])
+                    {
+                        acc += cw[u];
+                        touched = true;
+                    }
+            }
         }
         if (live && touched)
         {
@@ -1587,57 +1629,86 @@ __global__ void __launch_bounds__(256) ordered_deliver_kernel(DevImage im, DevSt
                 if (gated) st.arrived[slot] = 1;
             }
         }
-        return;
     }
-    // ---- processing-delay sum of one delivery slice ----
-    const SliceDesc sd = im.slice_desc[blockIdx.x - im.ord_wgs];
+    // ---- processing-delay sums: every wavefront takes whole delivery slices, gw, gw + (waves of the launch), ... ----
+    for (uint32_t sl = gw; sl < im.ord_walk_slices; sl += gridDim.x * 4u)
+    {
+    const SliceDesc sd = im.slice_desc[sl];
     const uint32_t n_ax = sd.n_ax;
     const bool compact = sd.mode != 0;
     const unsigned char *rec = im.ax_bytes + sd.rec_off;
     const uint32_t *chunk_pre0 = im.chunk_pre0 + sd.chunk0;
     double proc = 0.0;
-    for (uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; c0 < n_ax; c0 += 4u * WAVE_CHUNK) // wave-uniform bounds
+    if (compact)
     {
-        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
-        if (compact)
+        // runs of 8 consecutive 256-axon chunks per wave, their record loads in flight together (one address, eight
+        // immediate offsets; the record array ends in 4 KB of padding, reads past the slice are masked below).  One latency
+        // class per compact slice: messages and events are counted in integers and priced once.
+        constexpr uint32_t RUN = 8;
+        uint32_t n_msgs = 0, n_events = 0;
+        // (the records and first pre slots of the NEXT run are loaded before this run is decoded: two runs in flight)
+        auto load_run = [&](uint32_t r0, unsigned long long (&qq)[RUN], uint32_t &pre0) {
+            const uint32_t n_here = min(RUN, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK);
+            pre0 = chunk_pre0[r0 / WAVE_CHUNK + min((uint32_t) lane, n_here - 1u)]; // lane j: first pre slot of chunk j
+            const unsigned long long *rec_lane = reinterpret_cast<const unsigned long long *>(rec + 2ull * (r0 + (uint32_t) lane * AX_PER_THREAD));
+#pragma unroll
+            for (uint32_t j = 0; j < RUN; j++) qq[j] = rec_lane[j * (WAVE_CHUNK * 2u / 8u)];
+        };
+        unsigned long long qn[RUN];
+        uint32_t pre0_next = 0;
+        if (n_ax > 0) load_run(0u, qn, pre0_next);
+        for (uint32_t r0 = 0; r0 < n_ax; r0 += RUN * WAVE_CHUNK) // wave-uniform bounds
         {
-            unsigned long long q = 0;
-            if (a0 + AX_PER_THREAD <= n_ax) q = *reinterpret_cast<const unsigned long long *>(rec + 2ull * a0);
-            else
-                for (int k = 0; k < AX_PER_THREAD; k++)
-                    if (a0 + k < n_ax) q |= (unsigned long long) *reinterpret_cast<const uint16_t *>(rec + 2ull * (a0 + k)) << (16 * k);
-            uint32_t dl[AX_PER_THREAD];
+            const uint32_t n_here = min(RUN, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK);
+            const uint32_t pre0_lane = pre0_next;
+            unsigned long long q[RUN];
 #pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++) dl[k] = (uint32_t) (q >> (16 * k)) & 0xffu;
-            const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
-            uint32_t pre = chunk_pre0[c0 / WAVE_CHUNK] + wave_inclusive_scan(lane_d) - lane_d;
+            for (uint32_t j = 0; j < RUN; j++) q[j] = qn[j];
+            const uint32_t r1 = r0 + RUN * WAVE_CHUNK;
+            load_run(r1 < n_ax ? r1 : r0, qn, pre0_next); // unconditional (past the end: this run again)
 #pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++)
+            for (uint32_t j = 0; j < RUN; j++)
             {
-                pre += dl[k];
-                const uint32_t nsyn = (uint32_t) (q >> (16 * k + 8)) & 0xffu;
-                if (a0 + k < n_ax && spiked(pre)) proc += sd.ain_lat + (double) nsyn * sd.slice_lat;
+                const uint32_t a0 = r0 + j * WAVE_CHUNK + (uint32_t) lane * AX_PER_THREAD;
+                const uint32_t n_valid = (j < n_here && a0 < n_ax) ? min((uint32_t) AX_PER_THREAD, n_ax - a0) : 0u;
+                if (n_valid < (uint32_t) AX_PER_THREAD) q[j] &= (1ull << (16u * n_valid)) - 1ull; // records past the end: no advance
+                uint32_t dl[AX_PER_THREAD];
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++) dl[k] = (uint32_t) (q[j] >> (16 * k)) & 0xffu;
+                const uint32_t lane_d = dl[0] + dl[1] + dl[2] + dl[3];
+                uint32_t pre = (uint32_t) __builtin_amdgcn_readlane((int) pre0_lane, (int) j) + wave_inclusive_scan(lane_d) - lane_d;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                {
+                    pre += dl[k];
+                    if ((uint32_t) k < n_valid && spiked(pre))
+                    {
+                        n_msgs += 1u;
+                        n_events += (uint32_t) (q[j] >> (16 * k + 8)) & 0xffu;
+                    }
+                }
             }
         }
-        else
-        {
-            const unsigned long long *wide = reinterpret_cast<const unsigned long long *>(rec);
-#pragma unroll
-            for (int k = 0; k < AX_PER_THREAD; k++)
-                if (a0 + k < n_ax)
-                {
-                    const unsigned long long r = wide[a0 + k];
-                    const uint32_t nsyn = (uint32_t) ((r >> 32) & 0xffffu), lcls = (uint32_t) ((r >> 48) & 0xffu);
-                    if (spiked((uint32_t) r))
-                        proc += (lcls != 255u) ? sd.ain_lat + (double) nsyn * im.lat_class[lcls] : im.ax_proc_delay[sd.a_beg + a0 + k];
-                }
-        }
+        proc = (double) n_events * sd.slice_lat + (double) n_msgs * sd.ain_lat;
     }
-    proc = wave_sum(proc);
-    if (lane == 0) s_red[wave] = proc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        st.slice_proc[(size_t) (done & 1) * im.n_slices + sd.slice_id] = ((s_red[0] + s_red[1]) + s_red[2]) + s_red[3];
+    else
+    for (uint32_t c0 = 0; c0 < n_ax; c0 += WAVE_CHUNK) // wave-uniform bounds
+    {
+        const uint32_t a0 = c0 + (uint32_t) lane * AX_PER_THREAD;
+        const unsigned long long *wide = reinterpret_cast<const unsigned long long *>(rec);
+#pragma unroll
+        for (int k = 0; k < AX_PER_THREAD; k++)
+            if (a0 + k < n_ax)
+            {
+                const unsigned long long r = wide[a0 + k];
+                const uint32_t nsyn = (uint32_t) ((r >> 32) & 0xffffu), lcls = (uint32_t) ((r >> 48) & 0xffu);
+                if (spiked((uint32_t) r))
+                    proc += (lcls != 255u) ? sd.ain_lat + (double) nsyn * im.lat_class[lcls] : im.ax_proc_delay[sd.a_beg + a0 + k];
+            }
+    }
+    proc = wave_sum(proc); // fixed order
+    if (lane == 0) st.slice_proc[(size_t) (done & 1) * im.n_slices + sd.slice_id] = proc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------

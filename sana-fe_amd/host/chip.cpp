@@ -326,8 +326,13 @@ struct sanafe_chip
         return 0;
     }
     double total_energy{0.0}, total_sim_time{0.0};
+    // Tile-sharded chips: a mapped-only, single-rank twin of the WHOLE chip (sanafe_chip_attach_whole).  The detailed NoC
+    // schedule and the message trace are whole-chip host algorithms (one global event queue, src/schedule.cpp:208-292): every
+    // rank gathers the statuses of all neurons and runs them on the twin's tables, as the reference runs them in its one process.
+    sanafe_chip *whole{nullptr};
     // records of the last sim()
     bool have_records{false};
+    bool rec_bits_global{false}; // rec_spike_bits rows cover the GLOBAL slots (records gathered from the ranks of a sharded chip)
     int64_t rec_first_timestep{0}, rec_count{0};
     std::vector<sanafe_hip_totals> rec_totals;
     std::vector<std::vector<Msg>> rec_messages; // per recorded step, per-source-core order
@@ -348,6 +353,7 @@ struct sanafe_chip
 
     ~sanafe_chip()
     {
+        delete whole;
         plugin_units.clear(); // destroy the objects before their code is unloaded
         for (void *h : plugin_handles) dlclose(h);
     }
@@ -952,6 +958,22 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     return 0;
 }
 
+extern "C" int sanafe_chip_attach_whole(sanafe_chip *chip, const sanafe_desc *desc)
+{
+    if (!chip || !desc) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (desc->n_neurons != chip->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "the description does not hold the chip's neurons");
+    sanafe_chip *twin = nullptr;
+    if (int rc = sanafe_chip_create(desc, -1, 1, 0, &twin)) return rc; // mapped only: no device, one rank
+    if (twin->mc.n_global_slots != chip->mc.n_global_slots)
+    {
+        delete twin;
+        return fail(SANAFE_HIP_ERR_INVALID, "the description maps to a different slot layout than this chip");
+    }
+    delete chip->whole;
+    chip->whole = twin;
+    return 0;
+}
+
 extern "C" void sanafe_chip_destroy(sanafe_chip *chip)
 {
     if (!chip) return;
@@ -1012,42 +1034,46 @@ static void add_totals(sanafe_hip_totals &a, const sanafe_hip_totals &b)
     a.sim_time += b.sim_time;
 }
 
-// sim() of one rank of a tile-sharded chip: a pure enqueue loop -- neurons, gather of the spike windows (RCCL on
-// its own stream) beside the delivery of the slices fed by local neurons, then the remaining slices.  Counters
-// and energies of the ranks are added in rank order; the simple timing model needs the largest per-core delay
-// over ALL ranks of every step, so each rank logs its own per-step maximum and the logs are max-reduced once
-// per chunk of steps.
-static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &run)
+// One rank of a tile-sharded chip: the enqueue loop of a chunk of timesteps -- neurons, gather of the spike windows (in
+// line, or with RCCL on its own stream beside the delivery of the slices fed by local neurons), then the remaining
+// slices.  The simple timing model needs the largest per-core delay over ALL ranks of every step, so each rank logs its
+// own per-step maximum on the device and the logs are max-reduced once per chunk.
+struct ShardedRun
 {
-    sanafe_amd::Exchange &xc = chip->xc;
-    if (xc.kind == sanafe_amd::Exchange::None)
-        return fail(SANAFE_HIP_ERR_INVALID, "this chip holds rank " + std::to_string(chip->rank) + " of " + std::to_string(chip->n_ranks) +
-                        " of a tile-sharded chip: set the spike exchange up first (sanafe_chip_comm_init_rccl / _callback)");
-    MappedChip &mc = chip->mc;
-    DEV(sanafe_hip_reset_totals(chip->dev));
-    // the device keeps one entry per step in a ring of `cap` entries; the ring never shrinks, so `cap` is what the device
-    // reports, not what this call asked for (a shorter sim() after a longer one)
-    int64_t cap = std::max<int64_t>(1, std::min<int64_t>(timesteps, 1 << 16));
-    double *d_log = nullptr;
-    int64_t next = 0;
-    DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next));
-    void *local_bits = nullptr, *global_bits = nullptr;
-    uint64_t local_bytes = 0, global_bytes = 0;
-    DEV(sanafe_hip_spike_buffers(chip->dev, &local_bits, &local_bytes, &global_bits, &global_bytes));
+    sanafe_chip *chip;
+    sanafe_amd::Exchange &xc;
+    int64_t cap{1}, next{0};
+    double *d_log{nullptr};
+    void *global_bits{nullptr};
     std::vector<uint32_t> h_local, h_global;
-    if (xc.kind == sanafe_amd::Exchange::Callback)
+    std::vector<double> maxima; // [m] of the last chunk: largest per-core delay of every step over all ranks
+
+    explicit ShardedRun(sanafe_chip *c) : chip(c), xc(c->xc) {}
+    int begin(int64_t timesteps)
     {
-        h_local.resize(local_bytes / 4);
-        h_global.resize(global_bytes / 4);
+        if (xc.kind == sanafe_amd::Exchange::None)
+            return fail(SANAFE_HIP_ERR_INVALID, "this chip holds rank " + std::to_string(chip->rank) + " of " + std::to_string(chip->n_ranks) +
+                            " of a tile-sharded chip: set the spike exchange up first (sanafe_chip_comm_init_rccl / _callback)");
+        // the device keeps one entry per step in a ring of `cap` entries; the ring never shrinks, so `cap` is what the
+        // device reports, not what this call asked for (a shorter sim() after a longer one)
+        cap = std::max<int64_t>(1, std::min<int64_t>(timesteps, 1 << 16));
+        DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next));
+        void *local_bits = nullptr;
+        uint64_t local_bytes = 0, global_bytes = 0;
+        DEV(sanafe_hip_spike_buffers(chip->dev, &local_bits, &local_bytes, &global_bits, &global_bytes));
+        if (xc.kind == sanafe_amd::Exchange::Callback)
+        {
+            h_local.resize(local_bytes / 4);
+            h_global.resize(global_bytes / 4);
+        }
+        maxima.assign(static_cast<size_t>(cap), 0.0);
+        return 0;
     }
-    std::vector<double> maxima(cap);
-    double sim_time = 0.0;
-    const size_t n_ext = mc.ext.size();
-    for (int64_t done = 0, m = 0; done < timesteps; done += m)
+    // m <= cap steps; record_bits as sanafe_hip_step's (0: none).  Synchronises; fills maxima[0, m) when simple_timing.
+    int chunk(int64_t m, int simple_timing, int record_bits)
     {
-        m = std::min(cap, timesteps - done);
-        if (n_ext != 0) m = std::min<int64_t>(m, std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext)));
         if (int rc = chip->queue_ext(m)) return rc;
+        DEV(sanafe_hip_record_begin(chip->dev, m, record_bits));
         DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next)); // flushed: `next` is where this chunk starts
         for (int64_t s = 0; s < m; s++)
         {
@@ -1057,7 +1083,7 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
                 if (xc.gather_spikes_rccl(global_bits)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
                 DEV(sanafe_hip_step_deliver_local(chip->dev));
                 if (xc.wait_gathered()) return fail(SANAFE_HIP_ERR_HIP, xc.error);
-                DEV(sanafe_hip_step_deliver_remote(chip->dev, 1));
+                DEV(sanafe_hip_step_deliver_remote(chip->dev, simple_timing));
                 continue;
             }
             if (xc.kind == sanafe_amd::Exchange::Rccl_)
@@ -1070,9 +1096,10 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
                 if (xc.gather_spikes_host(h_local.data(), h_global.data())) return fail(SANAFE_HIP_ERR_INVALID, xc.error);
                 DEV(sanafe_hip_import_spikes(chip->dev, h_global.data()));
             }
-            DEV(sanafe_hip_step_deliver(chip->dev, 1, 0));
+            DEV(sanafe_hip_step_deliver(chip->dev, simple_timing, 0));
         }
         DEV(sanafe_hip_synchronize(chip->dev));
+        if (!simple_timing) return 0;
         // this chunk's per-step maxima sit at [next, next + m) modulo cap: at most two pieces
         for (int64_t at = 0; at < m;)
         {
@@ -1084,8 +1111,82 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
             if (xc.max_over_ranks(d_log + first, maxima.data() + at, static_cast<size_t>(len))) return fail(SANAFE_HIP_ERR_HIP, xc.error);
             at += len;
         }
+        return 0;
+    }
+    int end() { return sanafe_hip_record_begin(chip->dev, 0, 0) != 0 ? fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error()) : 0; }
+};
+
+// sim() of one rank of a tile-sharded chip under the simple timing model: whole chunks stay on the device.  Counters
+// and energies of the ranks are added in rank order.
+static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &run, int record)
+{
+    ShardedRun sr(chip);
+    if (int rc = sr.begin(timesteps)) return rc;
+    sanafe_amd::Exchange &xc = chip->xc;
+    MappedChip &mc = chip->mc;
+    DEV(sanafe_hip_reset_totals(chip->dev));
+    const int64_t cap = sr.cap;
+    std::vector<double> &maxima = sr.maxima;
+    double sim_time = 0.0;
+    const size_t n_ext = mc.ext.size();
+    // Recorded runs (spike / perf traces): every rank records its own window on the device -- per-step totals and spike
+    // bitmap rows -- and the ranks' records of a chunk of steps are gathered once per chunk: counters and energies added in
+    // rank order, sim_time from the per-step maximum over the ranks, bitmap rows laid side by side in global slot order.
+    uint32_t widest = 0;
+    for (int k = 0; k < xc.n_ranks; k++) widest = std::max(widest, xc.slot_begin[k + 1] - xc.slot_begin[k]);
+    const size_t row_words = widest / 32, local_words = mc.n_slots / 32, global_words = mc.n_global_slots / 32;
+    const size_t rec_bytes = sizeof(sanafe_hip_totals) + row_words * sizeof(uint32_t); // per step and rank
+    int64_t rec_cap = record ? std::max<int64_t>(1, (int64_t{64} << 20) / static_cast<int64_t>(rec_bytes * xc.n_ranks)) : cap;
+    std::vector<unsigned char> rec_send, rec_recv;
+    std::vector<sanafe_hip_totals> rec_local;
+    std::vector<uint32_t> rows_local;
+    for (int64_t done = 0, m = 0; done < timesteps; done += m)
+    {
+        m = std::min(std::min(cap, rec_cap), timesteps - done);
+        if (n_ext != 0) m = std::min<int64_t>(m, std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext)));
+        if (int rc = sr.chunk(m, 1, record ? 1 : 0)) return rc;
         for (int64_t s = 0; s < m; s++) sim_time += maxima[s] + mc.sync_delay;
+        if (record)
+        {
+            rec_local.resize(m);
+            rows_local.resize(static_cast<size_t>(m) * local_words);
+            DEV(sanafe_hip_read_step_totals(chip->dev, 0, m, rec_local.data()));
+            DEV(sanafe_hip_read_step_spike_rows(chip->dev, 0, m, rows_local.data()));
+            rec_send.assign(static_cast<size_t>(m) * rec_bytes, 0);
+            for (int64_t s = 0; s < m; s++)
+            {
+                unsigned char *at = rec_send.data() + static_cast<size_t>(s) * rec_bytes;
+                std::memcpy(at, &rec_local[s], sizeof(sanafe_hip_totals));
+                std::memcpy(at + sizeof(sanafe_hip_totals), rows_local.data() + static_cast<size_t>(s) * local_words, local_words * sizeof(uint32_t));
+            }
+            if (xc.gather_bytes(rec_send.data(), rec_send.size(), rec_recv)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+            for (int64_t s = 0; s < m; s++)
+            {
+                sanafe_hip_totals ts{};
+                std::vector<uint32_t> bits(global_words, 0u);
+                for (int k = 0; k < xc.n_ranks; k++) // rank order: reproducible sums
+                {
+                    const unsigned char *at = rec_recv.data() + static_cast<size_t>(k) * rec_send.size() + static_cast<size_t>(s) * rec_bytes;
+                    sanafe_hip_totals part;
+                    std::memcpy(&part, at, sizeof(part));
+                    add_totals(ts, part);
+                    std::memcpy(bits.data() + xc.slot_begin[k] / 32, at + sizeof(sanafe_hip_totals),
+                            static_cast<size_t>(xc.slot_begin[k + 1] - xc.slot_begin[k]) / 8);
+                }
+                ts.timesteps = chip->total_timesteps + s + 1;
+                ts.sim_time = maxima[s] + mc.sync_delay;
+                chip->rec_totals.push_back(ts);
+                chip->rec_spike_bits.push_back(std::move(bits));
+            }
+        }
         chip->total_timesteps += m;
+    }
+    if (int rc = sr.end()) return rc;
+    if (record && timesteps > 0)
+    {
+        chip->have_records = true;
+        chip->rec_bits_global = true;
+        chip->rec_count = timesteps;
     }
     sanafe_hip_totals mine{};
     DEV(sanafe_hip_read_totals(chip->dev, &mine));
@@ -1143,6 +1244,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     MappedChip &mc = chip->mc;
     sanafe_hip_totals run{};
     chip->have_records = false;
+    chip->rec_bits_global = false;
     chip->rec_totals.clear();
     chip->rec_messages.clear();
     chip->rec_spike_bits.clear();
@@ -1152,6 +1254,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     const bool host_units = !chip->mc.host_neurons.empty();
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
     const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
+    if (want_state && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces are not available on a tile-sharded chip");
     if (want_state && chip->log_v_gids.empty() && chip->log_u_gids.empty())
         return fail(SANAFE_HIP_ERR_INVALID, "SANAFE_RECORD_STATE needs the neurons to log (sanafe_chip_set_state_log)");
     record = (record & (SANAFE_RECORD_STEPS | SANAFE_RECORD_MESSAGES | SANAFE_RECORD_STATE)) ? 1 : 0;
@@ -1160,12 +1264,19 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
     if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
     {
-        if (timing_model != SANAFE_TIMING_SIMPLE || record || host_units)
-            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a tile-sharded chip runs the simple timing model without traces or "
-                                                    "plugin units (detailed timing and traces need the whole chip in one process)");
-        if (int rc = sim_sharded(chip, timesteps, run)) return rc;
+        if (want_state || host_units || (record && chip->mc.log.any))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces, optional perf columns and plugin units "
+                                                    "are not available on a tile-sharded chip");
+        if ((timing_model != SANAFE_TIMING_SIMPLE || want_messages) && chip->whole == nullptr)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces on a tile-sharded chip need the whole "
+                                                    "chip's tables on the host: call sanafe_chip_attach_whole with the complete description first");
     }
-    else if (timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages && !(record && chip->mc.log.any))
+    const bool sharded = chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None;
+    if (sharded && timing_model == SANAFE_TIMING_SIMPLE && !want_messages)
+    {
+        if (int rc = sim_sharded(chip, timesteps, run, record)) return rc;
+    }
+    else if (!sharded && timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages && !(record && chip->mc.log.any))
     {
         // Whole run stays on the device; nothing comes back per step unless recorded.  With external value
         // streams the run is cut into chunks whose stream rows fit a bounded upload (<= 64 MiB).
@@ -1214,9 +1325,12 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         // (serial by construction, src/schedule.cpp:234-281), one step at a time.
         // The same stepwise loop serves plugin (host-evaluated) soma units under either timing model.
         const bool detailed = (timing_model == SANAFE_TIMING_DETAILED);
-        if ((detailed || want_messages) && mc.out_ptr.empty())
+        // H: whose tables rebuild and schedule the messages -- the chip itself, or the whole-chip twin of a sharded one
+        sanafe_chip *H = sharded ? chip->whole : chip;
+        const MappedChip &hmc = H->mc;
+        if ((detailed || want_messages) && hmc.out_ptr.empty())
             return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces need a single-rank chip");
-        std::vector<uint8_t> status(mc.n_slots);
+        std::vector<uint8_t> status(hmc.n_slots);
         struct Job
         {
             sanafe_hip_totals ts{};
@@ -1237,15 +1351,15 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 if (want_messages) // the traced record of every message, in scheduling order
                 {
                     thread_local sanafe_chip::SchedScratch<Msg> scratch;
-                    chip->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
-                    job.ts.sim_time = chip->schedule_detailed(scratch.per_core, true, scratch);
+                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    job.ts.sim_time = H->schedule_detailed(scratch.per_core, true, scratch);
                     for (auto &q : scratch.per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
                 }
                 else // only sim_time is wanted: the compact message, queues and NoC state reused by this thread
                 {
                     thread_local sanafe_chip::SchedScratch<SchedMsg> scratch;
-                    chip->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
-                    job.ts.sim_time = chip->schedule_detailed(scratch.per_core, false, scratch);
+                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    job.ts.sim_time = H->schedule_detailed(scratch.per_core, false, scratch);
                 }
             }
             catch (const std::exception &e)
@@ -1298,10 +1412,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             std::vector<uint32_t> bits;
             if (record)
             {
-                bits.assign(mc.n_slots / 32, 0);
-                for (uint32_t k = 0; k < mc.n_slots; k++)
+                bits.assign(hmc.n_slots / 32, 0);
+                for (uint32_t k = 0; k < hmc.n_slots; k++)
                     if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
-                if (mc.log.any) chip->rec_optional.push_back(chip->optional_columns(st_bytes));
+                if (hmc.log.any) chip->rec_optional.push_back(H->optional_columns(st_bytes));
             }
             if (!detailed)
             {
@@ -1314,9 +1428,9 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                     {
                         // schedule_messages_timestep_simple, src/schedule.cpp:61-102: the messages stay in their source
                         // cores' FIFOs; no blocking is modelled and the network delay is the minimum hop delay
-                        std::vector<uint8_t> st_copy(st_bytes, st_bytes + mc.n_slots);
+                        std::vector<uint8_t> st_copy(st_bytes, st_bytes + hmc.n_slots);
                         std::vector<std::vector<Msg>> per_core;
-                        chip->build_messages(ts.timesteps, st_copy, per_core, mid_base);
+                        H->build_messages(ts.timesteps, st_copy, per_core, mid_base);
                         std::vector<Msg> &flat = chip->rec_messages.back();
                         for (auto &q : per_core)
                             for (Msg &m : q)
@@ -1337,7 +1451,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             Job &job = jobs.back();
             job.ts = ts;
             job.mid_base = mid_base;
-            job.status.assign(st_bytes, st_bytes + mc.n_slots);
+            job.status.assign(st_bytes, st_bytes + hmc.n_slots);
             job.bits = std::move(bits);
             if (pool.empty())
             {
@@ -1364,7 +1478,57 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             }
             return 0;
         };
-        if (!host_units)
+        if (sharded)
+        {
+            // Tile-sharded chip: K split steps per chunk with the spike exchange in between, every rank recording the totals
+            // and the NeuronStatus of its own slots; the ranks' records are gathered once per chunk and every rank replays the
+            // whole chip's messages on the twin's tables (the same deterministic schedule on every rank).
+            ShardedRun sr(chip);
+            if (int rc = sr.begin(timesteps)) return rc;
+            sanafe_amd::Exchange &xc = chip->xc;
+            uint32_t widest = 0;
+            for (int k = 0; k < xc.n_ranks; k++) widest = std::max(widest, xc.slot_begin[k + 1] - xc.slot_begin[k]);
+            const size_t rec_bytes = sizeof(sanafe_hip_totals) + widest; // per step and rank: totals + one status byte per slot
+            const int64_t k_cap = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(64, sr.cap), (int64_t{64} << 20) / static_cast<int64_t>(rec_bytes * xc.n_ranks)));
+            std::vector<sanafe_hip_totals> tsv;
+            std::vector<uint8_t> stv, st_global(hmc.n_slots);
+            std::vector<unsigned char> send, recv;
+            for (int64_t s = 0; s < timesteps;)
+            {
+                const int64_t k_steps = std::min(k_cap, timesteps - s);
+                if (int rc = sr.chunk(k_steps, detailed ? 0 : 1, 3)) return rc;
+                tsv.resize(k_steps);
+                stv.resize(static_cast<size_t>(k_steps) * mc.n_slots);
+                DEV(sanafe_hip_read_step_totals(chip->dev, 0, k_steps, tsv.data()));
+                DEV(sanafe_hip_read_step_status(chip->dev, 0, k_steps, stv.data()));
+                send.assign(static_cast<size_t>(k_steps) * rec_bytes, 0);
+                for (int64_t k = 0; k < k_steps; k++)
+                {
+                    unsigned char *at = send.data() + static_cast<size_t>(k) * rec_bytes;
+                    std::memcpy(at, &tsv[k], sizeof(sanafe_hip_totals));
+                    std::memcpy(at + sizeof(sanafe_hip_totals), stv.data() + static_cast<size_t>(k) * mc.n_slots, mc.n_slots);
+                }
+                if (xc.gather_bytes(send.data(), send.size(), recv)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+                for (int64_t k = 0; k < k_steps; k++)
+                {
+                    sanafe_hip_totals ts{};
+                    for (int r = 0; r < xc.n_ranks; r++) // rank order: reproducible sums
+                    {
+                        const unsigned char *at = recv.data() + static_cast<size_t>(r) * send.size() + static_cast<size_t>(k) * rec_bytes;
+                        sanafe_hip_totals part;
+                        std::memcpy(&part, at, sizeof(part));
+                        add_totals(ts, part);
+                        std::memcpy(st_global.data() + xc.slot_begin[r], at + sizeof(sanafe_hip_totals), xc.slot_begin[r + 1] - xc.slot_begin[r]);
+                    }
+                    ts.sim_time = detailed ? 0.0 : sr.maxima[k] + mc.sync_delay;
+                    if (int rc = process_step(ts, st_global.data())) return rc;
+                }
+                s += k_steps;
+            }
+            if (int rc = sr.end()) return rc;
+            if (record) chip->rec_bits_global = true;
+        }
+        else if (!host_units)
         {
             // `detailed` without plugin units: the device runs K steps back to back and logs every step's totals
             // and slot statuses; the host fetches them in one go (no round trip per step) and rebuilds the messages.
@@ -1643,6 +1807,11 @@ extern "C" int sanafe_chip_get_step_fired(sanafe_chip *chip, int64_t index, uint
     for (int64_t g = 0; g < chip->n_neurons; g++)
     {
         const uint32_t s = mc.slot_of_gid[g];
+        if (chip->rec_bits_global) // gathered from all ranks: every neuron of the chip
+        {
+            out[g] = (bits[s >> 5] >> (s & 31u)) & 1u;
+            continue;
+        }
         if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots)
         {
             out[g] = 0;

@@ -163,6 +163,9 @@ void Exchange::close()
         if (ev_gathered) (void) hipEventDestroy(static_cast<hipEvent_t>(ev_gathered));
         if (d_gather) (void) hipFree(d_gather);
     }
+    if (d_stage) (void) hipFree(d_stage);
+    d_stage = nullptr;
+    stage_bytes = 0;
     comm = comm_stream = ev_neurons = ev_gathered = d_gather = nullptr;
     kind = None;
 }
@@ -237,6 +240,35 @@ int Exchange::gather_totals(const sanafe_hip_totals &mine, void *device_totals, 
         return 0;
     }
     if (callback(callback_ctx, &mine, sizeof(mine), all.data()) != 0) return set_error("the all-gather callback failed");
+    return 0;
+}
+
+int Exchange::gather_bytes(const void *send, size_t bytes, std::vector<unsigned char> &recv)
+{
+    recv.assign(bytes * static_cast<size_t>(n_ranks), 0);
+    if (bytes == 0) return 0;
+    if (kind == Rccl_)
+    {
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const size_t need = bytes * static_cast<size_t>(n_ranks + 1);
+        if (need > stage_bytes)
+        {
+            HIPCHK(hipStreamSynchronize(s));
+            if (d_stage) HIPCHK(hipFree(d_stage));
+            d_stage = nullptr;
+            stage_bytes = 0;
+            HIPCHK(hipMalloc(&d_stage, need));
+            stage_bytes = need;
+        }
+        char *d_send = static_cast<char *>(d_stage), *d_recv = d_send + bytes;
+        HIPCHK(hipMemcpyAsync(d_send, send, bytes, hipMemcpyHostToDevice, s));
+        NCCLCHK(rccl().all_gather(d_send, d_recv, bytes, ncclUint8, static_cast<ncclComm_t>(comm), s));
+        HIPCHK(hipMemcpyAsync(recv.data(), d_recv, recv.size(), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+    }
+    if (kind != Callback) return set_error("no exchange set up");
+    if (callback(callback_ctx, send, bytes, recv.data()) != 0) return set_error("the all-gather callback failed");
     return 0;
 }
 

@@ -42,6 +42,11 @@ struct Exchange
     int gather_spikes_host(const uint32_t *local_bits, uint32_t *global_bits);
     int gather_totals(const sanafe_hip_totals &mine, void *device_totals, std::vector<sanafe_hip_totals> &all);
     int max_over_ranks(double *device_values, double *host_values, size_t count);
+    // Host-memory all-gather of `bytes` per rank (records of a chunk of steps: totals, spike rows, status rows): recv holds
+    // n_ranks blocks in rank order.  RCCL stages through device memory; not on the per-step path.
+    int gather_bytes(const void *send, size_t bytes, std::vector<unsigned char> &recv);
+    void *d_stage{nullptr};
+    size_t stage_bytes{0};
     int set_error(const std::string &msg);
 };
 } // namespace sanafe_amd

@@ -133,6 +133,8 @@ public:
     py::object arch;
     std::vector<py::object> nets; // networks loaded so far (load(net, overwrite=False) adds)
     py::object keepalive;         // lowered description (and whatever it borrows from)
+    uintptr_t desc_address_{0};   // the description the chip was created from (kept alive by `keepalive`)
+    bool whole_attached{false};   // tile-sharded chips: the whole-chip twin exists (sanafe_chip_attach_whole)
     sanafe_chip *h{nullptr};
     int device, n_ranks, rank;
     int64_t n_neurons{0};
@@ -164,6 +166,8 @@ public:
         if (rc != 0) raise_last("sanafe_chip_create failed");
         h = out;
         keepalive = std::move(keep);
+        desc_address_ = desc_address;
+        whole_attached = false;
         n_neurons = reinterpret_cast<const sanafe_desc *>(desc_address)->n_neurons;
         group_names.clear();
         group_base.clear();
@@ -242,6 +246,21 @@ public:
         return group_names[g] + "." + std::to_string(gid - group_base[g]);
     }
 
+    // Tile-sharded chips: detailed timing and message traces run on a mapped-only twin of the WHOLE chip
+    // (include/sanafe_host.h: sanafe_chip_attach_whole); built on first use from the description load() was given.
+    void attach_whole()
+    {
+        need_chip();
+        if (whole_attached || n_ranks <= 1) return;
+        int rc = 0;
+        {
+            py::gil_scoped_release release;
+            rc = sanafe_chip_attach_whole(h, reinterpret_cast<const sanafe_desc *>(desc_address_));
+        }
+        if (rc != 0) raise_last("sanafe_chip_attach_whole failed");
+        whole_attached = true;
+    }
+
     std::vector<std::string> perf_columns() const
     {
         const int64_t n = sanafe_chip_perf_columns(h, nullptr, 0);
@@ -288,6 +307,7 @@ public:
         if (neuron_t.on()) cur_gids = trace_order;
         const bool want_state = !pot_gids.empty() || !cur_gids.empty();
         if (want_state) check(sanafe_chip_set_state_log(h, static_cast<int64_t>(pot_gids.size()), pot_gids.data(), static_cast<int64_t>(cur_gids.size()), cur_gids.data()));
+        if (n_ranks > 1 && (timing == SANAFE_TIMING_DETAILED || message_t.on())) attach_whole();
         const bool want_steps = spike_t.on() || perf_t.on() || message_t.on() || want_state;
         const int record = (want_steps ? SANAFE_RECORD_STEPS : 0) | (message_t.on() ? SANAFE_RECORD_MESSAGES : 0) | (want_state ? SANAFE_RECORD_STATE : 0);
         const std::vector<std::string> opt_names = perf_t.on() ? perf_columns() : std::vector<std::string>();
@@ -337,23 +357,39 @@ public:
         std::vector<uint8_t> fired(static_cast<size_t>(n_neurons));
         std::vector<double> state, optional;
         std::vector<sanafe_message> msgs;
-        // chunks: small at first, doubled while a chunk takes under ~0.2 s, so signals are polled a few times a
-        // second whatever the chip's speed; recorded runs are also bounded by what a chunk keeps in memory
+        // chunks: a FIXED schedule (64, 128, 256, ... up to the cap), so the RunData sums -- chunk totals added in chunk
+        // order -- do not depend on the wall clock and are reproducible run to run; signals are polled between chunks;
+        // recorded runs are also bounded by what a chunk keeps in memory
         long chunk = 64;
-        const long chunk_cap = want_steps ? 4096 : (1L << 20);
+        const long chunk_cap = want_steps ? 4096 : 16384;
+        struct CloseTraces // file traces are closed on every exit path (an exception, Ctrl-C between chunks)
+        {
+            std::vector<Trace *> traces;
+            ~CloseTraces()
+            {
+                for (Trace *t : traces)
+                {
+                    try
+                    {
+                        t->close();
+                    }
+                    catch (...)
+                    {
+                    }
+                }
+            }
+        } close_guard{{&spike_t, &potential_t, &neuron_t, &perf_t, &message_t}};
         for (long done = 0; done < timesteps;)
         {
             const long m = std::min(chunk, timesteps - done);
             sanafe_hip_totals part{};
             int rc = 0;
-            const auto t0 = std::chrono::steady_clock::now();
             {
                 py::gil_scoped_release release; // the simulation never touches Python objects
                 rc = sanafe_chip_sim(h, m, timing, record, &part);
             }
             if (rc != 0) raise_last("sanafe_chip_sim failed");
-            const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            if (secs < 0.2 && chunk < chunk_cap) chunk *= 2;
+            if (chunk < chunk_cap) chunk *= 2;
             run.spikes += part.spikes;
             run.packets_sent += part.packets_sent;
             run.neurons_updated += part.neurons_updated;
@@ -649,6 +685,9 @@ void bind_spiking_chip(py::module_ &m)
                             const py::array_t<uint8_t> &ls, const py::array_t<uint8_t> &lp, py::object keep) { c.adopt(address, groups, ls, lp, std::move(keep)); },
                     py::arg("desc_address"), py::arg("groups"), py::arg("log_spikes"), py::arg("log_potential"), py::arg("keepalive"),
                     "Program the chip from an already lowered sanafe_desc (tests: descriptions built by the Python twin).")
+            .def("attach_whole", &Chip::attach_whole,
+                    "Tile-sharded chips: map the whole chip a second time on the host (no device) -- the tables detailed timing "
+                    "and message traces run on; sim() does it on first use")
             .def("sim", &Chip::sim, py::arg("timesteps") = 1, py::arg("timing_model") = "detailed", py::arg("processing_threads") = 0,
                     py::arg("scheduler_threads") = 0, py::arg("spike_trace") = py::none(), py::arg("potential_trace") = py::none(),
                     py::arg("neuron_trace") = py::none(), py::arg("perf_trace") = py::none(), py::arg("message_trace") = py::none(),

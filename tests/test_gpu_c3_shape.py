@@ -5,7 +5,8 @@ phase A of the delivery kernel, the bitmap and the slice cutter.  Here the HIP p
 destination cores look exactly like C3's: 262,144 source neurons on 512 cores, ~260 k inbound axons per destination
 core with ~5 synapses each, 16 delivery slices of 16,384 axons per core (runs of 8 chunks per wavefront), write-back
 shared between the slices of a core, delay-line dendrites -- in the headline's format 7 (2-byte dictionary words, integer
-accumulators), format 0 (4-byte int8 words) and format 4 (4-byte words + fp64 weights)."""
+accumulators), format 0 (4-byte int8 words), format 4 (4-byte words + fp64 weights) and the ordered layout of
+non-integer weights (format 8, forced here onto the integer network: ~2,700 entries per accumulator list)."""
 import os
 import sys
 
@@ -45,7 +46,8 @@ def c3_shape(S, delays):
 # delays=False is the headline's kernel variant (bench.py's recipe has no synaptic delays: deliver_kernel<7, false, ...>);
 # delays=True adds the six accumulator rows of a delay line that is actually used (6 x 513 accumulators per core do not fit
 # the 10-bit index of the dictionary words: format 0 with integer accumulators)
-@pytest.mark.parametrize("delays,force,fmt", [(False, None, 7), (False, "0", 0), (False, "4", 4), (True, None, 0)])
+@pytest.mark.parametrize("delays,force,fmt", [(False, None, 7), (False, "0", 0), (False, "4", 4), (False, "8", 8), (True, None, 0),
+                                              (True, "8", 8)])
 def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt):
     arch, net, ref = c3_shape(S, delays)
     monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")  # C3's slices: 133 M axons / 8,192 slices -> 16,384 axons each
@@ -57,7 +59,7 @@ def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt
     assert lay["syn_format"] == fmt
     assert info["n_neurons"] == 262144 and info["n_synapses"] == 262144 * 41
     # the C3 delivery shape: every slice on compact records, >= 16 slices on each destination core, ~5 synapses per axon
-    assert lay["n_compact_slices"] == info["n_slices"] >= 8 * 16
+    assert lay["n_compact_slices"] == info["n_slices"] >= 8 * 16 or (delays and fmt == 8)
     assert 4.5 < info["n_synapses"] / info["n_axons"] < 5.6
     fired_any = 0
     for t in range(STEPS):

@@ -47,7 +47,8 @@ def test_c3_full_size_properties(S, monkeypatch):
 
     # the same image through the other delivery code paths -- dictionary words with fp64 accumulators (format 6), 4-byte
     # int8 words streamed (format 0), 12-bit weight words gathered (format 1): identical results
-    for force, fmt in (("6", 6), ("0", 0), ("1", 1)):
+    # -- and the ordered per-accumulator layout of non-integer weights (format 8), forced onto this integer network
+    for force, fmt in (("6", 6), ("0", 0), ("1", 1), ("8", 8)):
         monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
         chip2, tot2, recs2, fired2, v2 = _run(S, arch, net)
         assert chip2.device_layout()["syn_format"] == fmt

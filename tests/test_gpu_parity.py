@@ -214,7 +214,7 @@ def test_random_configurations(S, seed, monkeypatch):
         monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
     arch, net = _random_configuration(S, seed)
     chip, orc = make(S, arch, net)
-    exact = chip.device_layout()["syn_format"] not in (2, 4)  # fp64 weights: sums in a different order
+    exact = chip.device_layout()["syn_format"] not in (2, 4, 6)  # streamed non-integer weights: sums in arrival order
     tot = chip.run(14, "simple", record=True)
     recs = chip.step_totals(0, 14)
     for t in range(14):
@@ -263,15 +263,58 @@ def test_truenorth(S, monkeypatch, small):
     check_stepwise(S, *nets.truenorth_net(S, n_tiles=16, neurons_per_core=256), steps=20)
 
 
-@pytest.mark.parametrize("force,fmt", [(None, 4), ("2", 2)])
+@pytest.mark.parametrize("force,fmt", [(None, 8), ("4", 4), ("2", 2)])
 def test_float_weights(S, monkeypatch, force, fmt):
-    """fp64 weights: 4 + 8 bytes per synapse, in the streamable layout (index-coded words, format 4) and in the
-    gather-only fall-back (format 2); p_fire 0.5 makes whole chunks stream."""
+    """Non-integer weights.  Default: ordered delivery (format 8) -- every accumulator folds its events in the reference's
+    order, so potentials are BIT-EQUAL to the oracle's.  Forced: the streaming layouts, 4 + 8 bytes per synapse (index-coded
+    words, format 4) and the gather-only fall-back (format 2), whose atomics add in arrival order (1e-9); p_fire 0.5 makes
+    whole chunks stream."""
     if force:
         monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
     arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=48, arch_kind="loihi", weights="float", p_fire=0.5)
-    chip, _ = check_stepwise(S, arch, net, steps=20, exact_v=False)
+    chip, _ = check_stepwise(S, arch, net, steps=20, exact_v=(force is None))
     assert chip.device_layout()["syn_format"] == fmt
+
+
+@pytest.mark.parametrize("kind", ["loihi", "large_delays", "dictionary", "no_dictionary_forced", "multi_slice", "global_bitmap"])
+def test_ordered_delivery_is_bit_exact_over_200_steps(S, monkeypatch, kind):
+    """VERDICT r2 #1b: with non-integer weights the HIP path adds a step's synaptic currents per accumulator in the
+    reference's order (source core, source neuron, connection: src/chip.cpp:661-690, 748-761), continuing the value the
+    delay line already holds (`value_or(0.0) + current`, src/models.cpp:96-131).  200 steps of spikes AND potentials equal
+    the oracle's bit for bit; a second chip reproduces the run bit for bit."""
+    delays = kind == "large_delays"
+    arch, net = nets.random_loihi(S, n_tiles=3, neurons_per_core=96, out_degree=60, arch_kind="large" if delays else "loihi",
+                                  delays=delays, weights="float", p_fire=0.25, seed=41)
+    if kind in ("dictionary", "no_dictionary_forced"):  # 20 distinct non-integer weights: 4-byte entries with a 5-bit code
+        rng = np.random.default_rng(6)
+        table = rng.normal(size=20) * 3.0
+        for blk in net._edge_blocks:
+            blk[2][:] = table[rng.integers(0, 20, size=len(blk[2]))]
+    if kind == "no_dictionary_forced":
+        monkeypatch.setenv("SANAFE_ORDERED_NO_DICT", "1")
+    if kind == "multi_slice":  # many delivery slices per core: only the processing-delay sums follow the slices here
+        monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "256")
+        monkeypatch.setenv("SANAFE_TARGET_SLICES", "100000")
+    if kind == "global_bitmap":
+        monkeypatch.setenv("SANAFE_ORDERED_LDS_BITS", "0")  # probe the bitmap in global memory (chips beyond ~300 k neurons)
+    chip, orc = make(S, arch, net)
+    assert chip.device_layout()["syn_format"] == 8
+    fired = []
+    for t in range(200):
+        a, b = chip.run(1, "simple"), orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=REL, abs=1e-30), (t, k)
+        st = orc.status()
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t  # bit for bit
+        fired.append(int((st == 3).sum()))
+    assert sum(fired[100:]) > 0
+    chip2 = S.SpikingChip(arch)
+    chip2.load(net)
+    chip2.run(200, "simple")
+    assert np.array_equal(chip2.potentials(), chip.potentials()) and np.array_equal(chip2.status(), chip.status())
 
 
 @pytest.mark.parametrize("force,fmt", [(None, 3), ("1", 1)])
@@ -357,8 +400,10 @@ def test_axons_with_two_hundred_synapses(S, monkeypatch, force):
     assert lay["syn_format"] == {None: 7, "6": 6, "0": 0}[force] and lay["n_compact_slices"] > 0
 
 
-def test_dictionary_coded_float_weights(S):
-    """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well."""
+def test_dictionary_coded_float_weights(S, monkeypatch):
+    """Format 6 is a dictionary, not an integer format: 20 distinct non-integer weights code into it as well (forced: the
+    default for non-integer weights is the ordered layout, format 8)."""
+    monkeypatch.setenv("SANAFE_SYN_FORMAT", "6")
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=150, arch_kind="loihi", p_fire=0.4, seed=31)
     rng = np.random.default_rng(5)
     table = rng.normal(size=20) * 3.0
@@ -398,8 +443,10 @@ def test_integer_accumulators_zero_sums_and_sparse_spikes(S, monkeypatch):
 
 
 @pytest.mark.parametrize("weights,fmt", [("int12", 3), ("float", 4)])
-def test_streamed_delay_lines_other_formats(S, weights, fmt):
+def test_streamed_delay_lines_other_formats(S, monkeypatch, weights, fmt):
     """The stream path of formats 3 / 4 with synaptic delays (several accumulator rows) on dense cores."""
+    if weights == "float":
+        monkeypatch.setenv("SANAFE_SYN_FORMAT", "4")  # (the default for non-integer weights is the ordered layout)
     arch, net = nets.random_loihi(S, n_tiles=1, neurons_per_core=256, out_degree=200, arch_kind="large", delays=True,
                                   weights=weights, p_fire=0.4, seed=13)
     chip, _ = check_stepwise(S, arch, net, steps=10, exact_v=(weights != "float"))

@@ -88,7 +88,7 @@ def test_sharded_chip_needs_an_exchange(S):
         chip.run(3, "simple")
     chip.comm_init_callback(lambda send: np.stack([send, send]))
     with pytest.raises(NotImplementedError):
-        chip.run(3, "detailed")  # the NoC schedule needs the whole chip in one process
+        chip.run(3, "simple", state=True)  # potential traces stay single-rank
 
 
 @pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_unequal"])
@@ -110,6 +110,93 @@ def test_two_ranks_match_one(S, which):
     assert info0["n_slots"] + info1["n_slots"] == info0["n_global_slots"]
     v = chips[0].potentials() + chips[1].potentials()
     assert np.array_equal(v, v_ref)
+
+
+def _sharded_calls(S, arch, net, call, n_ranks=2):
+    """Runs `call(chip)` on every rank's chip concurrently; returns the chips and the per-rank results."""
+    tg = ThreadGather(n_ranks)
+    chips, results, errors = [], [None] * n_ranks, []
+    for r in range(n_ranks):
+        c = S.SpikingChip(arch, device=0, n_ranks=n_ranks, rank=r)
+        c.load(net)
+        c.comm_init_callback(tg.for_rank(r))
+        chips.append(c)
+
+    def work(r):
+        try:
+            results[r] = call(chips[r])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            tg.barrier.abort()
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return chips, results
+
+
+def test_sharded_recorded_run_gathers_spike_and_perf_traces(S):
+    """Spike / perf traces on a tile-sharded chip: every rank records its window on the device; the per-step records
+    are gathered once per chunk -- every rank then holds the per-step totals and the fired neurons of the WHOLE chip."""
+    arch, net = nets.random_loihi(S, n_tiles=5, neurons_per_core=70, out_degree=40, delays=True, seed=16)  # unequal windows: 3 + 2 tiles
+    steps = 30
+    ref = S.SpikingChip(arch)
+    ref.load(net)
+    ref_tot = ref.run(steps, "simple", record=True)
+    ref_recs = ref.step_totals(0, steps)
+    ref_fired = np.stack([ref.step_fired(t) for t in range(steps)])
+
+    def call(chip):
+        tot = chip.run(steps, "simple", record=True)
+        return tot, chip.step_totals(0, steps), np.stack([chip.step_fired(t) for t in range(steps)])
+
+    _, results = _sharded_calls(S, arch, net, call)
+    assert ref_fired.sum() > 0
+    for tot, recs, fired in results:
+        _assert_same(tot, ref_tot)
+        assert np.array_equal(fired, ref_fired)
+        for k in INT_KEYS:
+            assert np.array_equal(recs[k], ref_recs[k]), k
+        for k in DBL_KEYS:
+            assert np.allclose(recs[k], ref_recs[k], rtol=1e-12, atol=0), k
+        assert np.array_equal(recs["timesteps"], ref_recs["timesteps"])
+
+
+@pytest.mark.parametrize("timing", ["detailed", "simple"])
+def test_sharded_detailed_timing_and_message_trace(S, timing):
+    """`detailed` timing and the message trace on a tile-sharded chip: the ranks gather the NeuronStatus of all neurons
+    per chunk of steps and every rank replays the whole chip's messages on a mapped-only twin of the whole chip
+    (sanafe_chip_attach_whole) -- the same messages, timestamps and sim_time as one rank, bit for bit."""
+    arch, net = nets.random_loihi(S, n_tiles=6, neurons_per_core=50, out_degree=16, arch_kind="loihi", seed=3)
+    steps = 9
+    ref = S.SpikingChip(arch)
+    ref.load(net)
+    ref_tot = ref.run(steps, timing, record=True, messages=True)
+    ref_msgs = [ref.step_messages(t) for t in range(steps)]
+    ref_recs = ref.step_totals(0, steps)
+
+    def call(chip):
+        tot = chip.run(steps, timing, record=True, messages=True)
+        return tot, chip.step_totals(0, steps), [chip.step_messages(t) for t in range(steps)], \
+            np.stack([chip.step_fired(t) for t in range(steps)])
+
+    _, results = _sharded_calls(S, arch, net, call)
+    ref_fired = np.stack([ref.step_fired(t) for t in range(steps)])
+    assert sum(len(m) for m in ref_msgs) > 100
+    for tot, recs, msgs, fired in results:
+        for k in INT_KEYS:
+            assert tot[k] == ref_tot[k], k
+        assert tot["sim_time"] == ref_tot["sim_time"] if timing == "detailed" else tot["sim_time"] == pytest.approx(ref_tot["sim_time"], rel=1e-12)
+        assert np.array_equal(fired, ref_fired)
+        if timing == "detailed":
+            assert np.array_equal(recs["sim_time"], ref_recs["sim_time"])  # the same serial algorithm on identical inputs
+        for t in range(steps):
+            assert len(msgs[t]) == len(ref_msgs[t])
+            for name in msgs[t].dtype.names:
+                assert np.array_equal(msgs[t][name], ref_msgs[t][name]), (t, name)
 
 
 def test_sharded_sim_is_cumulative(S):
