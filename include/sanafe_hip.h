@@ -323,6 +323,26 @@ int sanafe_hip_read_host_inputs(sanafe_hip_chip *chip, uint32_t count, const uin
 int sanafe_hip_write_host_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status,
         const uint32_t *core, const double *energy, const double *latency);
 
+/* Cores that run on the HOST (the soma is part of the message pipeline -- `buffer_position: soma` inside the unit, or
+ * `axon_out`, src/mapped.cpp:27-58 -- or a synapse / dendrite unit is a plugin, src/plugins.cpp:45-98): their neurons are
+ * SANAFE_SOMA_HOST slots and they have no inbound axons in the image; the host replays their pipelines per timestep.
+ *   write_host_core_status  between step_neurons and step_deliver: NeuronStatus of the listed slots and their local
+ *                           cores; sets the spike bits and adds the static totals of the spikes (messages, hops,
+ *                           events, network energy) -- nothing else
+ *   write_host_core_costs   after step_deliver of the SAME step, before anything else is launched: per core, what its
+ *                           units returned in the step (energies by role, soma-activity counters, the neuron pipelines'
+ *                           latency sum = message generation delay, the messages' processing-delay sum) */
+typedef struct sanafe_hip_host_core_costs
+{
+    uint32_t core, pad;       /* local core */
+    double synapse_energy, dendrite_energy, soma_energy;
+    double neuron_latency, processing_delay;
+    int64_t neurons_updated, neurons_fired;
+} sanafe_hip_host_core_costs;
+int sanafe_hip_write_host_core_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core);
+int sanafe_hip_write_host_core_costs(sanafe_hip_chip *chip, uint32_t count, const sanafe_hip_host_core_costs *costs);
+
 /* SpikingChip::reset: potentials, input currents and buffers to zero. */
 int sanafe_hip_reset(sanafe_hip_chip *chip);
 

@@ -126,6 +126,8 @@ struct sanafe_hip_chip
     uint8_t *d_host_status{nullptr};
     double *d_host_a{nullptr}, *d_host_b{nullptr};
     uint32_t host_cap{0};
+    sanafe_hip_host_core_costs *d_host_costs{nullptr};
+    uint32_t host_cost_cap{0};
     uint32_t *d_in_beg{nullptr}, *d_in_len{nullptr}, *d_in_bits{nullptr}; // input tables rewritten after create
     long long *d_in_period{nullptr};
     uint64_t in_bits_cap{0};
@@ -624,17 +626,22 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     //   streamable: 0 int8 weights, 3 12-bit integer weights, 4 fp64 weights; gather-only fall-backs: 1 (12-bit), 2 (fp64)
     {
         std::atomic<int> need{0};
+        std::atomic<bool> fractional{false}; // some weight is not an integer (of moderate size): fp64 sums depend on their order
         parallel_for(h.n_synapses, [&](uint64_t lo, uint64_t hi) {
             int fmt = 0;
-            for (uint64_t k = lo; k < hi && fmt < 2; k++)
+            bool frac = false;
+            for (uint64_t k = lo; k < hi && !(fmt == 2 && frac); k++)
             {
                 const double w = h.syn_weight[k];
                 const bool integral = (w >= -2048.0 && w <= 2047.0 && w == (double) (int) w && !(w == 0.0 && std::signbit(w)));
                 if (!integral) fmt = 2;
                 else if (w < -128.0 || w > 127.0) fmt = std::max(fmt, 1);
+                // sums of integers below 2^40 stay exact in fp64 whatever the order (2^13 events per accumulator and step)
+                if (!(std::fabs(w) <= 1099511627776.0 && w == std::nearbyint(w))) frac = true;
             }
             int seen = need.load();
             while (seen < fmt && !need.compare_exchange_weak(seen, fmt)) {}
+            if (frac) fractional = true;
         });
         int fmt = need.load();
         // format 0 addresses the LDS accumulators with 15 bits: (max delay + 1) rows of npad + 1 entries
@@ -777,7 +784,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         for (uint32_t g = 0; g < h.n_slots && !any_last; g++)
             any_last = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE &&
                        (((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST || ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST_DELAY);
-        bool ordered = weights == 2 && !any_last && h.n_synapses > 0 && std::getenv("SANAFE_SYN_FORMAT") == nullptr;
+        bool ordered = fractional.load() && !any_last && h.n_synapses > 0 && std::getenv("SANAFE_SYN_FORMAT") == nullptr;
         if (const char *env = std::getenv("SANAFE_SYN_FORMAT")) // tests: 8 forces the ordered layout on integer weights too
             if (std::atoi(env) == 8 && !any_last && h.n_synapses > 0) ordered = true;
         if (const char *env = std::getenv("SANAFE_ORDERED")) // 0: non-integer weights through the streaming kernels (A/B runs)
@@ -1083,6 +1090,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     TRYC(dalloc(c, 2 * (size_t) im.n_groups, &st.group_part));
     st.delay_log = nullptr;
     st.delay_log_cap = 0;
+    st.host_proc = nullptr;
     TRYC(dalloc(c, 1, &st.t));
     TRYC(dalloc(c, 1, &st.rec));
     TRYC(dalloc(c, 1, &st.run));
@@ -1187,7 +1195,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     for (void *p : {(void *) c->d_log_slots_v, (void *) c->d_log_slots_u, (void *) c->d_state_log})
         if (p) (void) hipFree(p);
     for (void *p : {(void *) c->d_host_slots, (void *) c->d_host_core, (void *) c->d_host_status, (void *) c->d_host_a,
-                 (void *) c->d_host_b, (void *) c->d_ext, (void *) c->d_soma_classes,
+                 (void *) c->d_host_b, (void *) c->d_host_costs, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
         if (p) (void) hipFree(p);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
@@ -1907,7 +1915,54 @@ extern "C" int sanafe_hip_write_host_status(sanafe_hip_chip *c, uint32_t count, 
     HIPCHK(hipMemcpyAsync(c->d_host_a, energy, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     HIPCHK(hipMemcpyAsync(c->d_host_b, latency, (size_t) count * sizeof(double), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
-            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b, (int) (c->t_host & 1));
+            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b, (int) (c->t_host & 1), 0);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_write_host_core_status(sanafe_hip_chip *c, uint32_t count, const uint32_t *slots, const uint8_t *status,
+        const uint32_t *core)
+{
+    if (!c || (count > 0 && (!slots || !status || !core))) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++)
+        if (slots[i] >= c->im.n_slots || status[i] > 3 || core[i] >= c->im.n_cores || (c->im.slot_cls == nullptr))
+            return fail(SANAFE_HIP_ERR_INVALID, "bad host status entry %u", i);
+    TRY(ensure_host_staging(c, count));
+    HIPCHK(hipMemcpyAsync(c->d_host_slots, slots, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_host_core, core, (size_t) count * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_host_status, status, (size_t) count, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(host_status_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count,
+            c->d_host_slots, c->d_host_status, c->d_host_core, c->d_host_a, c->d_host_b, (int) (c->t_host & 1), 1);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_write_host_core_costs(sanafe_hip_chip *c, uint32_t count, const sanafe_hip_host_core_costs *costs)
+{
+    if (!c || (count > 0 && !costs)) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    if (count == 0) return 0;
+    if (c->t_host == 0) return fail(SANAFE_HIP_ERR_INVALID, "no timestep has been launched yet");
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < count; i++)
+        if (costs[i].core >= c->im.n_cores) return fail(SANAFE_HIP_ERR_INVALID, "bad host core entry %u", i);
+    if (c->pend1.valid == 0) return fail(SANAFE_HIP_ERR_INVALID, "the step's reduction has already run: write the host cores' costs right after its delivery");
+    if (c->st.host_proc == nullptr) TRY(dalloc(c, 2 * (size_t) c->im.n_cores, &c->st.host_proc));
+    if (count > c->host_cost_cap)
+    {
+        if (c->d_host_costs) HIPCHK(hipFree(c->d_host_costs));
+        c->d_host_costs = nullptr;
+        c->host_cost_cap = 0;
+        HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->d_host_costs), (size_t) count * sizeof(sanafe_hip_host_core_costs)));
+        c->host_cost_cap = count;
+    }
+    HIPCHK(hipMemcpyAsync(c->d_host_costs, costs, (size_t) count * sizeof(sanafe_hip_host_core_costs), hipMemcpyHostToDevice, c->stream));
+    // the step just launched: its partials live in the half t_host - 1 selects
+    hipLaunchKernelGGL(host_core_costs_kernel, dim3((count + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, count, c->d_host_costs,
+            (int) ((c->t_host - 1) & 1));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;

@@ -192,6 +192,7 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
+    double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
     long long delay_log_cap;
 };
@@ -1768,6 +1769,8 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
                 if (s + j < s1) a[j] += sp[s + j];
             proc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
         }
+        // a core that runs on the host has no delivery slices: its message-processing delay comes from the host's replay
+        if (st.host_proc != nullptr) proc += st.host_proc[(size_t) parity * im.n_cores + c];
     }
     e_soma = wave_sum(e_soma);
     e_dend = wave_sum(e_dend);
@@ -2000,25 +2003,30 @@ __global__ void host_input_kernel(DevImage im, DevState st, uint32_t count, cons
 // first neuron workgroup of each neuron's core.  The neuron kernel skipped these slots entirely, so the
 // dendrite's per-update cost of the neuron-processing pipeline (buffer before or inside the dendrite unit,
 // src/pipeline.hpp:574-629) is added here as well.
+// RAW (neurons of cores that run on the host, host/host_cores.cpp): only the status, the spike bit and the static totals of
+// the spike; the core's unit energies, latencies and soma-activity counters arrive per core with host_core_costs_kernel.
 __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, const uint32_t *slots, const uint8_t *status,
-        const uint32_t *core, const double *energy, const double *latency, int parity)
+        const uint32_t *core, const double *energy, const double *latency, int parity, int raw)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t g = slots[i];
     const uint8_t s = status[i];
     st.status[g] = s;
-    const sanafe_hip_cost_class &cc = im.cost_classes[(im.slot_cls[g] >> 6) & 1023u];
     WgPart *cp = st.wg_part + (size_t) parity * im.n_wgs + im.core_wg_beg[core[i]];
-    atomicAdd(&cp->e_soma, energy[i]);
-    atomicAdd(&cp->e_dend, cc.dendrite_energy);
-    atomicAdd(&cp->lat, (0.0 + cc.dendrite_latency) + latency[i]);
-    if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
+    if (!raw)
+    {
+        const sanafe_hip_cost_class &cc = im.cost_classes[(im.slot_cls[g] >> 6) & 1023u];
+        atomicAdd(&cp->e_soma, energy[i]);
+        atomicAdd(&cp->e_dend, cc.dendrite_energy);
+        atomicAdd(&cp->lat, (0.0 + cc.dendrite_latency) + latency[i]);
+        if (s >= 2) atomicAdd((unsigned long long *) &cp->updated, 1ull);
+    }
     if (s == 3)
     {
         const SpikeStatic ss = im.slot_spike[g];
         atomicOr(&st.bits_local[g >> 5], 1u << (g & 31u));
-        atomicAdd((unsigned long long *) &cp->fired, 1ull);
+        if (!raw) atomicAdd((unsigned long long *) &cp->fired, 1ull);
         atomicAdd((unsigned long long *) &cp->packets, (unsigned long long) ss.packets);
         atomicAdd((unsigned long long *) &cp->hops, (unsigned long long) ss.hops);
         atomicAdd((unsigned long long *) &cp->events, (unsigned long long) ss.events);
@@ -2026,4 +2034,22 @@ __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, con
         atomicAdd(&cp->e_syn, ss.e_syn);
         atomicAdd(&cp->e_dend, ss.e_dend);
     }
+}
+
+// What one timestep of a core that runs on the host adds to the step's totals (include/sanafe_hip.h:
+// sanafe_hip_host_core_costs), after the delivery launch of the step: unit energies by role, the neuron pipelines' latency
+// sum (generation delay), the soma-activity counters, and the core's message-processing delay for the simple timing model.
+__global__ void host_core_costs_kernel(DevImage im, DevState st, uint32_t count, const sanafe_hip_host_core_costs *costs, int parity)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const sanafe_hip_host_core_costs k = costs[i];
+    WgPart *cp = st.wg_part + (size_t) parity * im.n_wgs + im.core_wg_beg[k.core];
+    cp->e_syn += k.synapse_energy; // (one thread per core; the neuron launch of the step wrote the partial long before)
+    cp->e_dend += k.dendrite_energy;
+    cp->e_soma += k.soma_energy;
+    cp->lat += k.neuron_latency;
+    cp->updated += k.neurons_updated;
+    cp->fired += k.neurons_fired;
+    st.host_proc[(size_t) parity * im.n_cores + k.core] = k.processing_delay;
 }

@@ -31,6 +31,7 @@
 
 #include "../../include/sanafe_host.h"
 #include "comm.hpp"
+#include "host_cores.hpp"
 #include "mapper.hpp"
 #include "plugin_abi/pipeline.hpp"
 
@@ -344,6 +345,10 @@ struct sanafe_chip
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
 
+    // ---- cores that run on the host: soma inside the message pipeline, plugin synapse / dendrite units (host/host_cores.hpp) ----
+    std::unique_ptr<sanafe_amd::HostCores> hcores;
+    std::vector<uint32_t> hc_bits;                       // the step's spike bitmap for the replay of their message pipelines
+    std::vector<sanafe_hip_host_core_costs> hc_costs;
     // ---- host-evaluated (plugin) soma units: plugin_get_hw, src/plugins.cpp:45-98 ----
     std::vector<std::unique_ptr<sanafe::PipelineUnit>> plugin_units; // parallel to mc.host_units
     std::vector<void *> plugin_handles;
@@ -941,6 +946,19 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
             for (int k = 0; k < 3; k++) chip->slot_lat[k][s] = (0.0 + cc.dendrite_latency) + cc.soma_latency[k];
         }
     }
+    if (!chip->mc.host_cores.empty())
+    {
+        try
+        {
+            chip->hcores = std::make_unique<sanafe_amd::HostCores>(chip->mc, *desc);
+        }
+        catch (const std::exception &e)
+        {
+            sanafe_hip_chip_destroy(chip->dev);
+            chip->dev = nullptr;
+            return fail(SANAFE_HIP_ERR_INVALID, e.what());
+        }
+    }
     if (!chip->mc.host_units.empty())
     {
         try
@@ -1251,7 +1269,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_optional.clear();
     chip->rec_first_timestep = chip->total_timesteps + 1;
     chip->rec_count = 0;
-    const bool host_units = !chip->mc.host_neurons.empty();
+    const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
     const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
     if (want_state && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
@@ -1325,6 +1343,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
         // (serial by construction, src/schedule.cpp:234-281), one step at a time.
         // The same stepwise loop serves plugin (host-evaluated) soma units under either timing model.
         const bool detailed = (timing_model == SANAFE_TIMING_DETAILED);
+        if (chip->hcores && (detailed || want_messages || (record && chip->mc.log.any)))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: cores that run on the host (buffer inside the soma unit / before axon_out, "
+                                                    "plugin synapse or dendrite units) are simulated under the simple timing model, without "
+                                                    "message traces or optional perf columns: their message costs are only known at run time");
         // H: whose tables rebuild and schedule the messages -- the chip itself, or the whole-chip twin of a sharded one
         sanafe_chip *H = sharded ? chip->whole : chip;
         const MappedChip &hmc = H->mc;
@@ -1562,19 +1584,57 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             if (int rc = chip->queue_ext(1)) return rc;
             {
                 const uint32_t n = static_cast<uint32_t>(chip->h_slots.size());
+                const long t_now = static_cast<long>(chip->total_timesteps + 1);
+                sanafe_amd::HostCores *hcs = chip->hcores.get();
                 DEV(sanafe_hip_step_neurons(chip->dev));
-                DEV(sanafe_hip_read_host_inputs(chip->dev, n, chip->h_slots.data(), chip->h_cur.data(), chip->h_has.data()));
                 try
                 {
-                    chip->run_plugins(chip->total_timesteps + 1);
+                    if (n > 0)
+                    {
+                        DEV(sanafe_hip_read_host_inputs(chip->dev, n, chip->h_slots.data(), chip->h_cur.data(), chip->h_has.data()));
+                        chip->run_plugins(chip->total_timesteps + 1);
+                        DEV(sanafe_hip_write_host_status(chip->dev, n, chip->h_slots.data(), chip->h_status.data(), chip->h_cores.data(),
+                                chip->h_energy.data(), chip->h_latency.data()));
+                    }
+                    if (hcs)
+                    {
+                        // neuron pipelines of the cores that run on the host; their statuses complete the step's spike bitmap
+                        hcs->begin_step();
+                        hcs->process_neurons(t_now);
+                        DEV(sanafe_hip_write_host_core_status(chip->dev, static_cast<uint32_t>(hcs->slots().size()), hcs->slots().data(),
+                                hcs->status().data(), hcs->slot_cores().data()));
+                        chip->hc_bits.resize(mc.n_slots / 32);
+                        DEV(sanafe_hip_export_spikes(chip->dev, chip->hc_bits.data()));
+                    }
+                    DEV(sanafe_hip_step_deliver(chip->dev, detailed ? 0 : 1, 0));
+                    if (hcs)
+                    {
+                        // their message pipelines, replayed while the device delivers to its own cores
+                        hcs->process_messages(t_now, chip->hc_bits.data());
+                        hcs->forced_updates(t_now);
+                        hcs->end_step();
+                        chip->hc_costs.resize(hcs->partials().size());
+                        for (size_t k = 0; k < hcs->partials().size(); k++)
+                        {
+                            const sanafe_amd::HostCores::Partial &p = hcs->partials()[k];
+                            sanafe_hip_host_core_costs &o = chip->hc_costs[k];
+                            o.core = hcs->core_ids()[k];
+                            o.pad = 0;
+                            o.synapse_energy = p.e_syn;
+                            o.dendrite_energy = p.e_dend;
+                            o.soma_energy = p.e_soma;
+                            o.neuron_latency = p.neuron_latency;
+                            o.processing_delay = p.processing;
+                            o.neurons_updated = p.updated;
+                            o.neurons_fired = p.fired;
+                        }
+                        DEV(sanafe_hip_write_host_core_costs(chip->dev, static_cast<uint32_t>(chip->hc_costs.size()), chip->hc_costs.data()));
+                    }
                 }
                 catch (const std::exception &e)
                 {
                     return fail(SANAFE_HIP_ERR_INVALID, e.what());
                 }
-                DEV(sanafe_hip_write_host_status(chip->dev, n, chip->h_slots.data(), chip->h_status.data(), chip->h_cores.data(),
-                        chip->h_energy.data(), chip->h_latency.data()));
-                DEV(sanafe_hip_step_deliver(chip->dev, detailed ? 0 : 1, 0));
             }
             sanafe_hip_totals ts{};
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
@@ -1694,6 +1754,7 @@ extern "C" int sanafe_chip_reset(sanafe_chip *chip)
     if (!chip) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
     DEV(sanafe_hip_reset(chip->dev));
     for (auto &u : chip->plugin_units) u->reset();
+    if (chip->hcores) chip->hcores->reset();
     return 0;
 }
 
@@ -1729,6 +1790,12 @@ extern "C" int sanafe_chip_get_potentials(sanafe_chip *chip, double *out)
     if (rc != 0) return rc;
     for (const MappedChip::HostNeuron &hn : chip->mc.host_neurons) // plugin somas keep their own state
         out[hn.gid] = chip->plugin_units[hn.unit]->get_potential(hn.addr);
+    if (chip->hcores) // so do the units of the cores that run on the host
+    {
+        size_t i = 0;
+        for (const MappedChip::HostCore &hc : chip->mc.host_cores)
+            for (const MappedChip::HostCore::Neuron &hn : hc.neurons) out[hn.gid] = chip->hcores->potential(i++);
+    }
     return 0;
 }
 extern "C" int sanafe_chip_get_input_current(sanafe_chip *chip, double *out)
@@ -1905,6 +1972,17 @@ extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, cons
         }
         if (model == SANAFE_SOMA_HOST)
         {
+            if (chip->hcores)
+            {
+                sanafe::ModelAttribute ma;
+                ma.name = key;
+                if (type == SANAFE_ATTR_BOOL) ma.value = (num != 0.0);
+                else if (type == SANAFE_ATTR_INT) ma.value = static_cast<int>(num);
+                else if (type == SANAFE_ATTR_DOUBLE) ma.value = num;
+                else if (type == SANAFE_ATTR_STRING) ma.value = std::string(str ? str : "");
+                else return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: list attributes cannot be patched on a mapped neuron");
+                if (chip->hcores->set_attribute(ls, ma)) return 0;
+            }
             for (const MappedChip::HostNeuron &hn : mc.host_neurons)
                 if (hn.slot == ls)
                 {

@@ -745,6 +745,92 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
         }
     }
+    // `taps` dendrites the device does not cover run on the host instead: more than 8 taps, a buffer position other than
+    // `soma` (outside), or several synapse-receiving neurons on ONE unit -- they then share its RC line, and every call
+    // of any of them advances / charges the same state (MultiTapModel1D keeps no per-neuron state, src/models.hpp:165-198).
+    std::vector<uint8_t> taps_need_host(d.n_cores, 0);
+    {
+        for (const auto &kv : shared_taps)
+        {
+            const int32_t c = kv.first.first;
+            if (kv.second.v.size() > 8 || d.core_buffer_pos[c] != SANAFE_BUF_BEFORE_SOMA) taps_need_host[c] = 1;
+        }
+        if (!shared_taps.empty())
+        {
+            std::map<std::pair<int32_t, int>, int64_t> receiver; // (core, taps unit) -> the neuron that receives synapses
+            for (int64_t e = 0; e < d.n_edges; e++)
+            {
+                const int64_t dst = d.edge_dst[e];
+                if (dst < 0 || dst >= N) continue;
+                const int32_t c = d.neuron_core[dst];
+                if (tmpl_of(c).units[dend_unit[dst]].model != M_TAPS) continue;
+                auto it = receiver.emplace(std::make_pair(c, dend_unit[dst]), dst).first;
+                if (it->second != dst) taps_need_host[c] = 1;
+            }
+        }
+    }
+    // ------------------------------------------------------------------ host cores (MappedChip::HostCore)
+    // A core runs on the host when its soma is part of the MESSAGE pipeline (buffer inside the soma unit or before
+    // axon_out: the soma is called once per synaptic event) or when its template holds a plugin synapse / dendrite unit.
+    std::vector<int32_t> host_core_index(d.n_cores, -1);
+    for (int c = 0; c < d.n_cores; c++)
+    {
+        const Template &t = tmpl_of(c);
+        bool host = d.core_buffer_pos[c] == SANAFE_BUF_INSIDE_SOMA || d.core_buffer_pos[c] == SANAFE_BUF_BEFORE_AXON_OUT;
+        for (const UnitInfo &u : t.units) host = host || (u.model == M_PLUGIN && (u.syn || u.dend));
+        host = host || taps_need_host[c]; // `taps` dendrites beyond what the device kernels cover (see above)
+        if (!host || mc.core_ncount[c] == 0) continue;
+        if (n_ranks != 1) throw UnsupportedError("cores that run on the host (buffer inside the soma unit / before axon_out, plugin synapse or dendrite units) need a single-rank chip");
+        host_core_index[c] = static_cast<int32_t>(mc.host_cores.size());
+        MappedChip::HostCore hc;
+        hc.core = static_cast<uint32_t>(c);
+        hc.bp = d.core_buffer_pos[c];
+        if (t.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
+        hc.ain_latency = t.ain_l[0];
+        for (size_t u = 0; u < t.units.size(); u++)
+        {
+            const UnitInfo &ui = t.units[u];
+            MappedChip::HostCore::Unit hu;
+            hu.desc_unit = d.tmpl_unit_ptr[d.core_template[c]] + static_cast<int>(u);
+            hu.name = ui.name;
+            hu.model = S(d, d.unit_model[hu.desc_unit]);
+            hu.plugin_path = S(d, d.unit_plugin[hu.desc_unit]);
+            hu.syn = ui.syn;
+            hu.dend = ui.dend;
+            hu.soma = ui.soma;
+            hu.update_every_timestep = ui.update_every_timestep;
+            hu.e_spike = ui.e_spike;
+            hu.l_spike = ui.l_spike;
+            hu.e_update = ui.e_update;
+            hu.l_update = ui.l_update;
+            hu.has_soma_e = ui.has_soma_e;
+            hu.has_soma_l = ui.has_soma_l;
+            for (int k = 0; k < 3; k++) hu.se[k] = ui.se[k], hu.sl[k] = ui.sl[k];
+            if (ui.model == M_LIF && !ui.noise_path.empty()) throw UnsupportedError("LIF noise files on a core that runs on the host");
+            hc.units.push_back(std::move(hu));
+        }
+        hc.neurons.resize(mc.core_ncount[c]);
+        mc.host_cores.push_back(std::move(hc));
+    }
+    const bool any_host_core = !mc.host_cores.empty();
+    if (any_host_core)
+    {
+        // per-unit neuron addresses in arrival (mapping) order: Core::map_neuron, src/core.cpp:116-168
+        std::map<std::pair<int32_t, int>, uint32_t> next_addr;
+        for (int64_t gid : order)
+        {
+            const int32_t c = d.neuron_core[gid];
+            if (host_core_index[c] < 0) continue;
+            MappedChip::HostCore::Neuron &hn = mc.host_cores[host_core_index[c]].neurons[offset_in_core[gid]];
+            hn.gid = gid;
+            hn.slot = mc.slot_of_gid[gid] - SO;
+            hn.soma_unit = soma_unit[gid];
+            hn.dend_unit = dend_unit[gid];
+            hn.dend_addr = next_addr[{c, dend_unit[gid]}]++;
+            hn.soma_addr = (soma_unit[gid] != dend_unit[gid]) ? next_addr[{c, soma_unit[gid]}]++ : hn.dend_addr; // combined unit: one address
+        }
+    }
+
     // ---- optional perf-trace columns (MappedChip::LogPlan) ----
     {
         MappedChip::LogPlan &lg = mc.log;
@@ -814,6 +900,20 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         const UnitInfo &du = t.units[dend_unit[gid]];
         const UnitInfo &su = t.units[soma_unit[gid]];
         const int bp = d.core_buffer_pos[c];
+        if (host_core_index[c] >= 0)
+        {
+            // evaluated by the host library every step (host/host_cores.cpp); the device only keeps its status and spike bit
+            const uint32_t hs = mc.slot_of_gid[gid];
+            if (su.model == M_TRUENORTH && random_mask_key >= 0)
+                for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+                    if (d.neuron_attrs.key[i] == random_mask_key && d.neuron_attrs.num[i] != 0.0)
+                        throw UnsupportedError("TrueNorth random_mask on a core that runs on the host");
+            mc.slot_cls[hs - SO] = SANAFE_SOMA_HOST;
+            mc.slot_model[hs - SO] = SANAFE_SOMA_HOST;
+            mc.slot_log_spikes[hs - SO] = d.neuron_log_spikes[gid];
+            mc.slot_log_potential[hs - SO] = d.neuron_log_potential[gid];
+            continue;
+        }
         if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE && bp != SANAFE_BUF_BEFORE_DENDRITE)
             throw UnsupportedError("buffer position " + std::to_string(bp) +
                     " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside, dendrite/outside)");
@@ -1114,13 +1214,24 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
             const int su = memo_unit;
             const UnitInfo &u = tp.units[su];
+            edge_syn_unit[e] = su;
+            if (host_core_index[d.neuron_core[dst]] >= 0) continue; // the host replays this core's message pipeline: any unit goes
             if (u.model != M_CURRENT_BASED) throw UnsupportedError("synapse unit '" + u.name + "' (plugin) is not implemented on the MI355X backend");
             if (!u.e_spike) throw std::runtime_error("Synapse unit does not simulate energy or provide a default energy cost in the architecture description.");
             if (!u.l_spike) throw std::runtime_error("Synapse unit does not simulate latency or provide a default latency cost in the architecture description.");
-            edge_syn_unit[e] = su;
         }
     });
-    if ((d.edge_delay && any_delay_dendrite) || any_taps)
+    // neurons that receive through a synapse unit flagged update_every_timestep (MappedNeuron::
+    // check_for_synapse_updates_every_timestep, src/mapped.cpp:32-40): only host cores' units can make that observable
+    std::vector<uint8_t> receives_forced_synapse;
+    if (any_host_core)
+    {
+        receives_forced_synapse.assign(N, 0);
+        for (int64_t e = 0; e < E; e++)
+            if (tmpl_of(d.neuron_core[d.edge_dst[e]]).units[edge_syn_unit[e]].update_every_timestep) receives_forced_synapse[d.edge_dst[e]] = 1;
+    }
+    std::vector<uint64_t> syn_addr; // per edge: address on its synapse unit = arrival order in map_connections order
+    if ((d.edge_delay && any_delay_dendrite) || any_taps || any_host_core)
     {
         // The delay dendrite stores delays[] indexed by the SYNAPSE unit's address of the
         // connection (src/mapped.cpp:60-89, src/models.cpp:133-152): connections that reach the
@@ -1139,7 +1250,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         eo.release_scratch();
         std::map<std::pair<uint32_t, int>, uint64_t> syn_count;            // (core, synapse unit) -> next address
         std::map<std::pair<uint32_t, int>, std::vector<uint8_t>> delays;   // (core, dendrite unit) -> delays[]
-        std::vector<uint64_t> syn_addr(E);
+        syn_addr.assign(E, 0);
         std::map<std::pair<uint32_t, int>, int64_t> taps_owner; // (core, taps unit) -> the neuron that receives synapses
         for (int64_t pos = 0; pos < E; pos++)
         {
@@ -1230,6 +1341,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     // delivery order, so floating-point sums do not depend on the thread count.
     struct AxonBlock
     {
+        std::vector<int64_t> first; // sorted position of the axon's first edge (host cores list their synapses from it)
         std::vector<uint32_t> pre, nsyn, hops, dc;
         std::vector<uint8_t> uniform;
         std::vector<double> proc, first_lat, min_hop, e_net, e_syn, e_dend, e_hop;
@@ -1260,6 +1372,9 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const Template &dt = tmpl_of(dc);
             const int bp = d.core_buffer_pos[dc];
             const bool local = dc >= mc.first_core && dc < mc.last_core;
+            // a core that runs on the host: its synapse / dendrite / soma costs are whatever its units return at run time
+            // (host/host_cores.cpp adds them per step); nothing of it enters the static per-spike totals or the device image
+            const bool host_dest = host_core_index[dc] >= 0;
             // processing delay of the message: pipeline_process_axon_in + process_message, src/chip.cpp:738-800
             if (dt.ain_l.empty()) throw std::runtime_error("core receives spike messages but has no axon_in unit");
             double proc = dt.ain_l[0];
@@ -1272,6 +1387,15 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 const UnitInfo &su = dt.units[edge_syn_unit[e]];
                 const int64_t dst = d.edge_dst[e];
                 double lat = 0.0; // execute_pipeline: total_latency
+                if (host_dest)
+                {
+                    if (local) // a hole in the image's synapse arrays: no axon refers to it, every scan skips it (lost charge)
+                    {
+                        mc.syn_meta[static_cast<size_t>(k - local_beg)] = 1u << 19;
+                        mc.syn_weight[static_cast<size_t>(k - local_beg)] = 0.0;
+                    }
+                    continue;
+                }
                 lat += *su.l_spike;
                 e_syn += *su.e_spike;
                 if (bp > SANAFE_BUF_BEFORE_DENDRITE)
@@ -1334,6 +1458,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const Template &stt = tmpl_of(sc);
             const double e_aout = stt.aout_e.size() == 1 ? stt.aout_e[0] : 0.0;
             const double e_ain = dt.ain_e.size() == 1 ? dt.ain_e[0] : 0.0;
+            B.first.push_back(i);
             B.pre.push_back(pre);
             B.nsyn.push_back(static_cast<uint32_t>(j - i));
             B.hops.push_back(xh + yh);
@@ -1390,6 +1515,30 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             const uint32_t axon_id = dest_axon_count[dc]++;
             if (dc < mc.first_core || dc >= mc.last_core) continue;
             const uint32_t lc = dc - mc.first_core;
+            if (host_core_index[dc] >= 0)
+            {
+                // the host replays this core: the axon and its synapses go to the core's own tables, in delivery order;
+                // their places in the image's synapse arrays stay holes
+                MappedChip::HostCore &hc = mc.host_cores[host_core_index[dc]];
+                MappedChip::HostCore::Axon ha;
+                ha.pre = pre;
+                ha.syn_beg = static_cast<uint32_t>(hc.synapses.size());
+                ha.n_syn = nsyn;
+                hc.axons.push_back(ha);
+                for (int64_t k = B.first[a]; k < B.first[a] + nsyn; k++)
+                {
+                    const uint64_t e = eo[k];
+                    MappedChip::HostCore::Synapse hs;
+                    hs.unit = edge_syn_unit[e];
+                    hs.addr = static_cast<uint32_t>(syn_addr[e]);
+                    hs.post = offset_in_core[d.edge_dst[e]];
+                    hs.edge = static_cast<int64_t>(e);
+                    hs.pre_checks_synapses = !receives_forced_synapse.empty() && receives_forced_synapse[d.edge_src[e]] != 0;
+                    hc.synapses.push_back(hs);
+                }
+                syn0 += nsyn;
+                continue;
+            }
             if (core_axon_beg[lc + 1] == 0) mc.core_syn_base[lc] = syn0;
             if (syn0 - mc.core_syn_base[lc] > 0xffffffffull) throw UnsupportedError("more than 2^32 synapses on one core");
             mc.ax_pre.push_back(pre);

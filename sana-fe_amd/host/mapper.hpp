@@ -7,6 +7,7 @@
 #define SANAFE_HOST_MAPPER_HPP
 
 #include <cstdint>
+#include <optional>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -154,6 +155,53 @@ struct MappedChip
     };
     std::vector<HostUnit> host_units;
     std::vector<HostNeuron> host_neurons;
+
+    // ---- host cores: cores whose pipeline cannot run on the device by construction -- the soma unit is called once per
+    //      synaptic EVENT (`buffer_position: soma` inside the unit, or `axon_out`; src/mapped.cpp:27-58, 168-188), or a
+    //      synapse / dendrite unit is a plugin (a host C++ object, src/plugins.cpp:45-98).  Their neurons are
+    //      SANAFE_SOMA_HOST slots on the device and their inbound axons are NOT part of the device image: the host library
+    //      replays such a core's neuron and message pipelines per timestep from the chip's spike bitmap (host/host_cores.cpp).
+    struct HostCore
+    {
+        struct Unit
+        {
+            int desc_unit{0};          // index into sanafe_desc::unit_*
+            std::string name, model, plugin_path; // plugin_path empty: a built-in model
+            bool syn{false}, dend{false}, soma{false}, update_every_timestep{false};
+            std::optional<double> e_spike, l_spike, e_update, l_update; // architecture defaults (src/pipeline.cpp:177-266)
+            bool has_soma_e{false}, has_soma_l{false};
+            double se[3]{}, sl[3]{};   // access, update, spike_out
+        };
+        struct Neuron
+        {
+            uint32_t slot{0};          // local slot
+            int64_t gid{0};
+            int32_t soma_unit{0}, dend_unit{0};
+            uint32_t soma_addr{0}, dend_addr{0}; // per-unit addresses: arrival (mapping) order on the unit
+        };
+        struct Synapse
+        {
+            int32_t unit{0};           // synapse unit
+            uint32_t addr{0};          // address on that unit: arrival order in map_connections order
+            uint32_t post{0};          // post neuron, offset within the core
+            int64_t edge{0};           // index into sanafe_desc::edge_*
+            bool pre_checks_synapses{false}; // the SOURCE neuron itself receives through a synapse unit flagged
+                                             // update_every_timestep: forced_updates walks its connections (src/chip.cpp:989-1005)
+        };
+        struct Axon
+        {
+            uint32_t pre{0};           // GLOBAL slot of the source neuron
+            uint32_t syn_beg{0}, n_syn{0};
+        };
+        uint32_t core{0};              // global core id (== local: host cores need a single-rank chip)
+        int bp{0};                     // SANAFE_BUF_*
+        double ain_latency{0.0};
+        std::vector<Unit> units;       // template order
+        std::vector<Neuron> neurons;   // mapped order (offset within the core)
+        std::vector<Synapse> synapses; // delivery order: axon by axon
+        std::vector<Axon> axons;       // delivery order (source core, source neuron): src/chip.cpp:661-690
+    };
+    std::vector<HostCore> host_cores;
 
     // ---- optional perf-trace columns: tiles / cores with log_energy, units with log_energy / log_latency
     //      (sim_trace_get_optional_traces, src/chip.cpp:1541-1579).  Filled only when some flag is set. ----

@@ -257,7 +257,7 @@ def stochastic_truenorth(S, n_tiles=6, neurons_per_core=64, seed=2):
     return arch, net
 
 
-def taps_dendrites(S, n=24, n_in=10, seed=3):
+def taps_dendrites(S, n=24, n_in=10, seed=3, max_taps=5, buffer=("soma", False), neurons_per_unit=1):
     """`taps` dendrites (MultiTapModel1D) in the style of arch/demo_with_dendrites.yaml + snn/dendrite.yaml: one
     dendrite unit per neuron, 1..5 taps with their own time/space constants, synapses that name their tap, inputs
     that spike from trains, recurrent edges between the dendritic neurons."""
@@ -268,12 +268,12 @@ def taps_dendrites(S, n=24, n_in=10, seed=3):
         tile = arch.create_tile("tile[%d]" % t, energy_north_hop=2.0e-12, latency_north_hop=1.4e-9, energy_east_hop=2.5e-12,
                                 latency_east_hop=1.2e-9, energy_south_hop=2.0e-12, latency_south_hop=1.5e-9,
                                 energy_west_hop=1.8e-12, latency_west_hop=2.0e-9)
-        core = arch.create_core("core[0]", tile.id, "soma", False, 100)
+        core = arch.create_core("core[0]", tile.id, buffer[0], buffer[1], 100)
         core.create_axon_in("axon_in", 0.0, 0.0)
         core.create_synapse("synapse", "current_based", {"energy_process_spike": 20.0e-12, "latency_process_spike": 3.0e-9})
         for i in range(n):
-            core.create_dendrite("dendrite[%d]" % i, "taps", {"energy_update": 0.0, "latency_update": 0.0})
-        core.create_dendrite("plain", "accumulator", {"energy_update": 0.0, "latency_update": 0.0})
+            core.create_dendrite("dendrite[%d]" % i, "taps", {"energy_update": 1.0e-12, "latency_update": 0.5e-9})
+        core.create_dendrite("plain", "accumulator", {"energy_update": 1.0e-12, "latency_update": 0.5e-9})
         core.create_soma("soma", "leaky_integrate_fire",
                          {"energy_access_neuron": 20.0e-12, "latency_access_neuron": 3.0e-9, "energy_update_neuron": 10.0e-12,
                           "latency_update_neuron": 1.0e-9, "energy_spike_out": 60.0e-12, "latency_spike_out": 30.0e-9})
@@ -291,14 +291,17 @@ def taps_dendrites(S, n=24, n_in=10, seed=3):
                          attrs={"spikes": ((D.ATTR_LIST, 0.0, None, train), D.FWD_ALL)})
     g = net.create_neuron_group("dendrite", n, {"threshold": 12, "reset": 0, "leak_decay": 0.9}, "synapse", "", True, True,
                                 "soma")
-    taps = rng.integers(1, 6, size=n)
+    taps = rng.integers(1, max_taps + 1, size=n)
+    units = max(1, (n // 2) // neurons_per_unit)  # unit instances per core: neurons i and i + units of a core share one
+    if neurons_per_unit > 1:
+        taps = taps[np.arange(n) % units]          # one RC line: the unit keeps the configuration applied last anyway
     for i in range(n):
         k = int(taps[i])
         attrs = {"taps": ((D.ATTR_INT, float(k), None, None), D.FWD_ALL),
                  "time_constants": ((D.ATTR_LIST, 0.0, None, [float(x) for x in rng.choice([0.5, 0.75, 0.875], size=k)]), D.FWD_ALL),
                  "space_constants": ((D.ATTR_LIST, 0.0, None, [float(x) for x in rng.choice([0.125, 0.25], size=max(k - 1, 0))]),
                                      D.FWD_ALL)}
-        g.apply_config(i, i + 1, dendrite_hw_name="dendrite[%d]" % (i % (n // 2)), attrs=attrs)
+        g.apply_config(i, i + 1, dendrite_hw_name="dendrite[%d]" % (i % units), attrs=attrs)
     # inputs -> dendritic neurons, each synapse naming a tap of its target
     pairs = np.stack([rng.integers(0, n_in, size=90), rng.integers(0, n, size=90)], axis=1)
     gin.connect_neurons_sparse(g, {"weight": rng.integers(2, 9, size=90).astype(np.float64),
@@ -342,6 +345,62 @@ def shared_input_units(S, seed=8):
     for i in (2, 0, 1, 4, 3, 5, 8, 6, 7):
         gin.map_to_core(cores[core_of[i]], i, i + 1)
     g.map_to_core(cores[2], 0, 40)
+    return arch, net
+
+
+def relay_plugin_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", "librelay_units.so")
+
+
+def host_cores(S, position="soma_inside", plugin_units=False, builtin_twin=False, n_per_core=48, out_degree=14, seed=5,
+               soma="truenorth"):
+    """A 6-core chip whose cores 2 and 4 cannot run on the device (mapper.hpp: MappedChip::HostCore) next to cores that can:
+      position "soma_inside" / "axon_out": `buffer_position: soma` with the buffer inside the unit / `axon_out` on those
+               cores -- the soma is called once per synaptic event (src/mapped.cpp:27-58);
+      plugin_units: those cores keep `buffer_position: soma` (outside) but their synapse and dendrite units are plugins
+               (tests/plugins/relay_units.cpp: current_based / accumulator arithmetic behind the plugin interface);
+               builtin_twin=True builds the SAME chip on the built-in units instead (what the oracle and the device run).
+    TrueNorth somas everywhere (the built-in soma that tolerates several updates per step), non-zero costs on every
+    unit, integer weights, traffic in every direction between host and device cores."""
+    D = S.description
+    rng = np.random.default_rng(seed)
+    arch = D.Architecture("mixed", 3, 2, 4, {0: 0.0, 2: 0.9e-6})
+    syn_costs = {"energy_process_spike": 20.0e-12, "latency_process_spike": 3.0e-9}
+    dend_costs = {"energy_update": 7.0e-12, "latency_update": 1.5e-9}
+    soma_costs = {"energy_access_neuron": 20.0e-12, "latency_access_neuron": 3.0e-9, "energy_update_neuron": 10.0e-12,
+                  "latency_update_neuron": 1.0e-9, "energy_spike_out": 60.0e-12, "latency_spike_out": 30.0e-9}
+    for t in range(6):
+        tile = arch.create_tile("tile[%d]" % t, energy_north_hop=2.0e-12, latency_north_hop=1.4e-9, energy_east_hop=2.5e-12,
+                                latency_east_hop=1.2e-9, energy_south_hop=2.0e-12, latency_south_hop=1.5e-9,
+                                energy_west_hop=1.8e-12, latency_west_hop=2.0e-9)
+        special = t in (2, 4)
+        if special and not plugin_units and position == "soma_inside":
+            core = arch.create_core("core[0]", tile.id, "soma", True, 256)
+        elif special and not plugin_units and position == "axon_out":
+            core = arch.create_core("core[0]", tile.id, "axon_out", False, 256)
+        else:
+            core = arch.create_core("core[0]", tile.id, "soma", False, 256)
+        core.create_axon_in("axon_in", 1.0e-12, 2.0e-9)
+        if special and plugin_units and not builtin_twin:
+            core.create_synapse("syn", "test_synapse", dict(syn_costs), plugin=relay_plugin_path())
+            core.create_dendrite("dend", "test_dendrite", dict(dend_costs), plugin=relay_plugin_path())
+        else:
+            core.create_synapse("syn", "current_based", dict(syn_costs))
+            core.create_dendrite("dend", "accumulator", dict(dend_costs))
+        core.create_soma("soma", "truenorth" if soma == "truenorth" else "leaky_integrate_fire", dict(soma_costs))
+        core.create_axon_out("axon_out", 100.0e-12, 5.0e-9)
+    cores = arch.cores()
+    n = 6 * n_per_core
+    net = D.Network("mixed")
+    g = net.create_neuron_group("n", n, {"reset": 0, "leak": 1}, "syn", "dend", False, True, "soma")
+    g.set_attribute_column("threshold", rng.integers(6, 40, size=n).astype(np.int64), D.ATTR_INT)
+    g.set_attribute_column("bias", np.where(rng.random(n) < 0.35, rng.integers(2, 9, size=n), 0).astype(np.int64), D.ATTR_INT)
+    src = np.repeat(np.arange(n, dtype=np.int64), out_degree)
+    dst = rng.integers(0, n, size=len(src))
+    w = (rng.integers(1, 6, size=len(src)) * rng.choice([-1, 1, 1], size=len(src))).astype(np.float64)
+    g.connect_neurons_sparse(g, {"weight": w}, np.stack([src, dst], axis=1), narrow_float=False)
+    for c in range(6):
+        g.map_to_core(cores[c], c * n_per_core, (c + 1) * n_per_core)
     return arch, net
 
 

@@ -1,0 +1,116 @@
+"""Cores that cannot run on the device by construction -- rows a5 (buffer positions `soma`/inside and `axon_out`:
+src/pipeline.cpp:268-310, src/mapped.cpp:27-58, 168-188) and the synapse / dendrite half of the plugin surface
+(src/core.cpp:196-231, src/pipeline.hpp:69-301).
+
+Their soma (or a plugin unit) is called once per synaptic EVENT, in delivery order, so the host library replays such
+cores' neuron and message pipelines per timestep from the chip's spike bitmap (host/host_cores.cpp) while the device
+runs every other core; statuses, spikes, counters, energies and simulated time must equal the oracle's, which runs
+all five buffer positions generically."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nets  # noqa: E402
+from oracle.oracle import OracleChip  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+INT_KEYS = (("spikes", "spike_count"), ("packets_sent", "packets_sent"), ("neurons_updated", "neurons_updated"),
+            ("neurons_fired", "neurons_fired"), ("total_hops", "total_hops"))
+DBL_KEYS = ("total_energy", "synapse_energy", "dendrite_energy", "soma_energy", "network_energy", "sim_time")
+
+
+def _compare(chip, orc, steps):
+    fired = 0
+    for t in range(steps):
+        a, b = chip.run(1, "simple", record=True), orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k, a[k], b[k])
+        st = orc.status()
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
+        assert np.array_equal(chip.step_fired(0), (st == 3).astype(np.uint8)), t
+        fired += int((st == 3).sum())
+    return fired
+
+
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_soma_inside_the_message_pipeline(S, position):
+    """Buffer positions 3 and 4 with TrueNorth somas: the soma updates once per synaptic event (and, inside the unit,
+    once more in the neuron loop); behind the buffer before axon_out a neuron's status persists until the next event."""
+    arch, net = nets.host_cores(S, position=position)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    orc = OracleChip(S.to_desc(arch, net))
+    fired = _compare(chip, orc, 40)
+    host = chip.status().reshape(6, -1)[[2, 4]]
+    assert fired > 200 and (host == 3).sum() + (host == 2).sum() > 0  # the host cores take part
+    # reset() reaches the host units as well
+    chip.reset()
+    orc.reset()
+    _compare(chip, orc, 5)
+
+
+def test_lif_soma_inside_the_message_pipeline_fails_like_the_reference(S):
+    """The built-in LIF refuses a second update in one step (src/models.cpp:502-507): on such a core the first neuron
+    that receives an event AND is updated by the neuron loop raises, exactly as the reference's model does."""
+    arch, net = nets.host_cores(S, position="soma_inside", soma="lif")
+    for grp in net._order:
+        grp.set_attribute_column("leak", np.zeros(grp.count, dtype=np.int64), S.description.ATTR_INT)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    with pytest.raises(RuntimeError, match="multiple updates"):
+        chip.run(6, "simple")
+
+
+def test_plugin_synapse_and_dendrite_units(S):
+    """A synapse plugin and a dendrite plugin (tests/plugins/relay_units.cpp: the arithmetic of the built-in current_based
+    synapse and accumulator behind `create_<model>()`): the host replays their cores per event.  The result equals, bit
+    for bit, the oracle on the twin chip with built-in units -- and the device path on that twin."""
+    arch_p, net_p = nets.host_cores(S, plugin_units=True)
+    arch_b, net_b = nets.host_cores(S, plugin_units=True, builtin_twin=True)
+    chip = S.SpikingChip(arch_p)
+    chip.load(net_p)
+    orc = OracleChip(S.to_desc(arch_b, net_b))
+    assert _compare(chip, orc, 40) > 200
+    twin = S.SpikingChip(arch_b)  # every core on the device
+    twin.load(net_b)
+    chip2 = S.SpikingChip(arch_p)
+    chip2.load(net_p)
+    a, b = chip2.run(30, "simple"), twin.run(30, "simple")
+    for ka, _ in INT_KEYS:
+        assert a[ka] == b[ka], ka
+    for k in DBL_KEYS:
+        assert a[k] == pytest.approx(b[k], rel=1e-9), k
+    assert np.array_equal(chip2.potentials(), twin.potentials())
+
+
+@pytest.mark.parametrize("variant", ["many_taps", "shared_line", "inside_dendrite", "before_dendrite"])
+def test_taps_dendrites_beyond_the_device_kernels(S, variant):
+    """Row a21 in general (MultiTapModel1D, src/models.cpp:167-348): more than 8 taps, several synapse-receiving neurons
+    on ONE unit (they share its RC line: every call of any of them advances / charges the same state), and the buffer
+    inside / before the dendrite unit.  The device kernels cover <= 8 taps, one receiver per unit, `soma`/outside; such
+    cores run on the host instead -- same results as the oracle, step by step."""
+    kw = {"many_taps": dict(max_taps=14), "shared_line": dict(neurons_per_unit=2),
+          "inside_dendrite": dict(buffer=("dendrite", True)), "before_dendrite": dict(buffer=("dendrite", False))}[variant]
+    arch, net = nets.taps_dendrites(S, **kw)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    orc = OracleChip(S.to_desc(arch, net))
+    assert _compare(chip, orc, 45) > 100
+
+
+def test_host_cores_need_simple_timing_and_one_rank(S):
+    arch, net = nets.host_cores(S, position="axon_out")
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    with pytest.raises(NotImplementedError, match="simple timing"):
+        chip.run(2, "detailed")
+    sharded = S.SpikingChip(arch, device=0, n_ranks=2, rank=0)
+    with pytest.raises(NotImplementedError, match="single-rank"):
+        sharded.load(net)
