@@ -346,6 +346,67 @@ int build_ordered(sanafe_hip_chip *c, const sanafe_hip_image &h)
     return 0;
 }
 
+// Push delivery tables (DevImage: push_*): per neuron, the synapses one spike of it reaches, with the post slot, the
+// destination core and the weight -- built only where the push path is exact and cheap (see DevImage).
+int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
+{
+    DevImage &im = c->im;
+    im.push_cap = 0;
+    if (std::getenv("SANAFE_PUSH") != nullptr && std::atoi(std::getenv("SANAFE_PUSH")) == 0) return 0; // tests / A-B runs
+    const bool integer_weights = c->syn_format == 7 || ((c->syn_format == 0 || c->syn_format == 3));
+    if (!integer_weights || h.n_global_slots != h.n_slots || c->has_delay || im.has_last || h.n_taps != 0 || h.n_ext != 0 ||
+            h.n_synapses == 0 || h.n_synapses > (64ull << 20) || h.ax_lat_class == nullptr)
+        return 0;
+    for (uint32_t g = 0; g < h.n_slots; g++)
+        if ((h.slot_cls[g] & 7u) == SANAFE_SOMA_HOST) return 0; // their spikes are set after the neuron launch
+    for (uint64_t k = 0; k < h.n_synapses; k++)
+        if ((h.syn_meta[k] >> 19) & 1u) return 0; // lost charge still counts as an event: keep such chips on the pull path
+    // one latency class per core
+    std::vector<double> ev_lat(h.n_cores, 0.0);
+    std::vector<int> cls(h.n_cores, -1);
+    for (uint32_t sl = 0; sl < h.n_slices; sl++)
+        for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl]; a++)
+        {
+            const uint32_t core = h.slice_core[sl];
+            if (h.ax_lat_class[a] == 255u) return 0;
+            if (cls[core] < 0) cls[core] = h.ax_lat_class[a];
+            else if (cls[core] != (int) h.ax_lat_class[a]) return 0;
+        }
+    for (uint32_t k = 0; k < h.n_cores; k++)
+        if (cls[k] >= 0) ev_lat[k] = h.lat_class_per_event ? h.lat_class_per_event[cls[k]] : 0.0;
+    std::vector<uint32_t> ptr(h.n_slots + 1, 0);
+    for (uint64_t a = 0; a < h.n_axons; a++) ptr[h.ax_pre[a] + 1] += h.ax_nsyn[a];
+    for (uint32_t g = 0; g < h.n_slots; g++) ptr[g + 1] += ptr[g];
+    std::vector<PushEntry> syn(h.n_synapses);
+    std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
+    for (uint32_t sl = 0; sl < h.n_slices; sl++)
+    {
+        const uint32_t core = h.slice_core[sl];
+        for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl]; a++)
+        {
+            const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
+            for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
+            {
+                PushEntry &e = syn[cur[h.ax_pre[a]]++];
+                e.post = h.core_nbase[core] + (h.syn_meta[src + k] & 0xffffu);
+                e.core = core | (k == 0 ? 0x80000000u : 0u);
+                e.w = h.syn_weight[src + k];
+            }
+        }
+    }
+    TRY(upload(c, ptr.data(), ptr.size(), &im.push_ptr));
+    TRY(upload(c, syn.data(), syn.size(), &im.push_syn));
+    TRY(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_ain_lat));
+    TRY(upload(c, ev_lat.data(), ev_lat.size(), &im.core_event_lat));
+    im.push_cap = 65536;
+    im.push_max_events = 49152; // above this the pull path (one probe per inbound axon of the chip) is no slower
+    if (const char *env = std::getenv("SANAFE_PUSH_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0L, std::atol(env));
+    TRY(dalloc(c, 3 * 2, &c->st.push_count));
+    TRY(dalloc(c, 3 * (size_t) im.push_cap, &c->st.push_list));
+    TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
+    return 0;
+}
+
 int validate(const sanafe_hip_image *im)
 {
     if (im->n_cores == 0) return fail(SANAFE_HIP_ERR_INVALID, "image has no cores");
@@ -1177,6 +1238,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->deliver_fn = v->fn;
         c->deliver_block = (uint32_t) v->block;
     }
+    st.push_count = st.push_list = st.push_core_cnt = nullptr;
+    TRYC(build_push(c, h));
     HIPC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -1303,6 +1366,7 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     }
     sa.t = c->t_host + 1;
     sa.parity = (int) (c->t_host & 1);
+    sa.push_buf = (int) (c->t_host % 3);
     const size_t rslot = (size_t) (sa.t % c->im.ring_slots);
     sa.ring = c->st.ring + rslot * c->im.n_slots;
     sa.rvalid = c->st.ring_valid + rslot * c->im.n_slots;
@@ -1360,6 +1424,7 @@ static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long 
     c->pend1.simple_timing = simple_timing;
     c->pend1.record = record;
     c->pend1.parity = (int) (c->t_host & 1);
+    c->pend1.push_buf = (int) (c->t_host % 3);
     c->pend1.rec_index = rec_index;
     c->t_host += 1;
 }

@@ -129,6 +129,18 @@ struct DevImage
     int syn_format;               // 0 .. 4, 6, 7 as above
     int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
+    // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): the neuron launch compacts the
+    // fired neurons into a list and counts the synaptic events they cause; when that count is small the delivery launch
+    // walks the fired neurons' static out-synapse lists instead of probing every inbound axon of the chip (deliver_kernel).
+    // Only built for chips where the result cannot depend on the order of the additions and the per-core message costs are
+    // integers times a constant: integer weights, no synaptic delays / last-event cores / taps / host units, one latency
+    // class per core, one GPU.  push_cap == 0: not built.
+    uint32_t push_cap;            // entries of the fired list (per buffer)
+    uint32_t push_max_events;     // largest event count of a step that is pushed
+    const uint32_t *push_ptr;     // [n_slots + 1] out-synapses of each neuron
+    const struct PushEntry *push_syn; // post slot, destination core | first-synapse-of-its-axon flag, weight
+    const double *core_ain_lat;   // [n_cores] axon-in latency per message
+    const double *core_event_lat; // [n_cores] latency per synaptic event (one latency class per core)
     // Ordered delivery (syn_format 8, non-integer weights): the synapses regrouped PER ACCUMULATOR (post neuron x delay
     // value), each list in the reference's delivery order; 64 lists side by side make one group (ordered_deliver_kernel).
     uint32_t ord_groups, ord_wgs; // groups of 64 accumulators; workgroups of the launch (4 wavefronts: a group each, then slices)
@@ -140,6 +152,12 @@ struct DevImage
                                         // padding entries point at bit n_global_slots, which never fires
     const double *ord_w;                // the entries' weights (no dictionary), same indexing
     int ord_dict;                       // weights are 5-bit codes into weight_lut
+};
+struct PushEntry
+{
+    uint32_t post;  // local slot of the post-synaptic neuron
+    uint32_t core;  // destination core | 0x80000000: first synapse of its axon (= one message)
+    double w;
 };
 // One group of the ordered layout: 64 accumulators whose lists lie side by side, entry k of lane l at off + 64 k + l.
 struct OrdGroup
@@ -165,6 +183,7 @@ struct PendStep
 {
     int valid;          // 0: nothing to do
     int simple_timing, record, parity;
+    int push_buf;        // step number % 3: the push-delivery buffers of that step
     long long rec_index; // record slot of that step
 };
 
@@ -192,6 +211,10 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
+    // push delivery, triple-buffered by step number % 3 (a buffer is zeroed one launch before its step uses it)
+    uint32_t *push_count;         // [3][2]: fired neurons, synaptic events they cause
+    uint32_t *push_list;          // [3][push_cap] local slots of the fired neurons (any order)
+    uint32_t *push_core_cnt;      // [3][n_cores][2]: messages, events delivered to each core by the push path
     double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
     long long delay_log_cap;
@@ -256,7 +279,7 @@ __device__ __forceinline__ double synapse_weight_at(const DevImage &im, unsigned
     return (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
 }
 
-__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group);
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf);
 __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev);
 
 // Per-launch values the host works out (no 64-bit division or row arithmetic on the device).
@@ -269,7 +292,7 @@ struct StepArgs
     const int *ext_row;  // external stream values of this step, or NULL
     long long t;         // Timestep::timestep of this step (steps simulated before it + 1)
     int parity;          // (t - 1) & 1: which half of the partials this step writes
-    int pad;
+    int push_buf;        // (t - 1) % 3: the push-delivery buffers this step fills (the launch zeroes buffer (push_buf + 1) % 3)
 };
 
 // A chip whose neurons all carry the same class word (one soma model, one parameter set, one cost class, one input
@@ -308,9 +331,11 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
     if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
+        if (im.push_cap != 0u && blockIdx.x == 0 && threadIdx.x < 2) // the buffer the NEXT step's launch counts into
+            st.push_count[((sa.push_buf + 1) % 3) * 2 + threadIdx.x] = 0u;
         if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
         const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
-        if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group);
+        if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
         return;
     }
     __shared__ sanafe_hip_soma_class s_soma[UNI ? 1 : SOMA_LDS_MAX];
@@ -637,6 +662,19 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 n_pack = (long long) ((unsigned long long) ph >> 40);
                 n_hops = (long long) ((unsigned long long) ph & ((1ull << 40) - 1ull));
                 n_ev = wave_sum((long long) ss.events);
+                if (im.push_cap != 0u)
+                {
+                    // compact the fired neurons into the step's list (order irrelevant: the push path adds integers)
+                    uint32_t base = 0;
+                    if (lane == 0)
+                    {
+                        base = atomicAdd(&st.push_count[sa.push_buf * 2], (uint32_t) n_fire);
+                        atomicAdd(&st.push_count[sa.push_buf * 2 + 1], (uint32_t) (n_ev > 0xffffffffll ? 0xffffffffll : n_ev));
+                    }
+                    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
+                    const uint32_t rank = base + (uint32_t) __popcll(fired_mask & ((1ull << lane) - 1ull));
+                    if (status == 3 && rank < im.push_cap) st.push_list[(size_t) sa.push_buf * im.push_cap + rank] = c0 + lane;
+                }
                 if (im.spike_energy & 1) e_syn = wave_sum(ss.e_syn);
                 if (im.spike_energy & 2) e_net = wave_sum(ss.e_net);
                 if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
@@ -776,6 +814,34 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
     if (SYN_FMT == 7 && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
+    if (im.push_cap != 0u)
+    {
+        // ---- few spikes: push the fired neurons' out-synapses instead of probing every inbound axon (see DevImage) ----
+        const uint32_t buf = (uint32_t) (done % 3);
+        const uint32_t n_fired = st.push_count[buf * 2], n_events = st.push_count[buf * 2 + 1];
+        if (n_fired <= im.push_cap && n_events <= im.push_max_events) // the same decision in every workgroup and in reduce_l1
+        {
+            const uint32_t gwave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = (gridDim.x * BLOCK) >> 6;
+            const uint32_t pl = threadIdx.x & (WAVE - 1);
+            const size_t row = (size_t) ((done + 2) % (long long) im.ring_slots) * im.n_slots; // (no synaptic delays on push chips)
+            uint32_t *cnt = st.push_core_cnt + (size_t) buf * im.n_cores * 2u;
+            for (uint32_t i = gwave; i < n_fired; i += n_waves) // one wavefront per fired neuron, lanes over its synapses
+            {
+                const uint32_t pre = st.push_list[(size_t) buf * im.push_cap + i];
+                const uint32_t b = im.push_ptr[pre], e = im.push_ptr[pre + 1];
+                for (uint32_t k = b + pl; k < e; k += WAVE)
+                {
+                    const PushEntry pe = im.push_syn[k];
+                    atomicAdd(&st.ring[row + pe.post], pe.w); // integers: exact in any order
+                    st.ring_valid[row + pe.post] = 1;
+                    const uint32_t core = pe.core & 0x7fffffffu;
+                    atomicAdd(&cnt[core * 2u + 1u], 1u);
+                    if (pe.core >> 31) atomicAdd(&cnt[core * 2u], 1u);
+                }
+            }
+            return;
+        }
+    }
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // a scalar: chunk offsets and bases stay in SGPRs
     // Descriptors are in launch order: slices whose axons all start on this GPU first (delivered while the
@@ -1721,7 +1787,7 @@ ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulat
 // partials in workgroup order, the generation-delay sum of its messages incl. the placeholder
 // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81) and the processing-delay sum of its
 // delivery slices in slice (= reference delivery) order.
-__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group)
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t c = group * WAVE + (uint32_t) lane;
@@ -1751,7 +1817,21 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
         gen = lat + (double) packets * out_lat;
         // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
         const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
-        if (s1 - s0 <= 2u)
+        bool pushed = false;
+        if (im.push_cap != 0u)
+        {
+            const uint32_t n_fired = st.push_count[push_buf * 2], n_events = st.push_count[push_buf * 2 + 1];
+            pushed = n_fired <= im.push_cap && n_events <= im.push_max_events; // the delivery launch took the same decision
+        }
+        if (pushed)
+        {
+            // the push path counted this core's messages and events: integers times the core's constants
+            uint32_t *cnt = st.push_core_cnt + ((size_t) push_buf * im.n_cores + c) * 2u;
+            proc = (double) cnt[1] * im.core_event_lat[c] + (double) cnt[0] * im.core_ain_lat[c];
+            cnt[0] = 0u;
+            cnt[1] = 0u;
+        }
+        else if (s1 - s0 <= 2u)
         {
             for (uint32_t s = s0; s < s1; s++) proc += sp[s];
         }
@@ -1894,7 +1974,7 @@ __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevSt
     const int wave = threadIdx.x >> 6;
     if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
     const uint32_t group = blockIdx.x * (REDUCE_BLOCK / WAVE) + (uint32_t) wave;
-    if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group);
+    if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
 }
 
 // `taps` dendrites, after the delivery launch of step t (one thread per neuron): advance the RC line by one step

@@ -1639,6 +1639,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             sanafe_hip_totals ts{};
             DEV(sanafe_hip_read_totals(chip->dev, &ts));
             DEV(sanafe_hip_read_status(chip->dev, status.data()));
+            if (chip->hcores) // the status a neuron of a host core holds at the END of the step (latched by the message pipeline too)
+                for (size_t k = 0; k < chip->hcores->slots().size(); k++) status[chip->hcores->slots()[k]] = chip->hcores->final_status()[k];
             if (want_state) // plugin somas keep their own potentials: sampled on the host
             {
                 std::vector<double> v(static_cast<size_t>(chip->n_neurons)), u(static_cast<size_t>(chip->n_neurons));
@@ -1781,7 +1783,15 @@ template <typename T, typename F> static int gather_by_gid(sanafe_chip *chip, T 
 extern "C" int sanafe_chip_get_status(sanafe_chip *chip, uint8_t *out)
 {
     if (!chip || !out) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
-    return gather_by_gid(chip, out, [&](uint8_t *p) { return sanafe_hip_read_status(chip->dev, p); });
+    const int rc = gather_by_gid(chip, out, [&](uint8_t *p) { return sanafe_hip_read_status(chip->dev, p); });
+    if (rc != 0) return rc;
+    if (chip->hcores) // cores that run on the host: MappedNeuron::status as the END of the step left it
+    {
+        size_t i = 0;
+        for (const MappedChip::HostCore &hc : chip->mc.host_cores)
+            for (const MappedChip::HostCore::Neuron &hn : hc.neurons) out[hn.gid] = chip->hcores->final_status()[i++];
+    }
+    return 0;
 }
 extern "C" int sanafe_chip_get_potentials(sanafe_chip *chip, double *out)
 {

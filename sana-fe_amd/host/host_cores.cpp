@@ -166,6 +166,7 @@ HostCores::HostCores(const MappedChip &mc, const sanafe_desc &d)
         core_ids_.push_back(hc.core - mc.first_core);
     }
     status_.assign(slots_.size(), 0);
+    final_status_.assign(slots_.size(), 0);
     partials_.assign(cores_.size(), Partial{});
 }
 
@@ -346,6 +347,7 @@ void HostCores::end_step()
     for (size_t ci = 0; ci < cores_.size(); ci++)
     {
         Partial &p = partials_[ci];
+        for (size_t k = 0; k < cores_[ci].neurons.size(); k++) final_status_[cores_[ci].first + k] = static_cast<uint8_t>(cores_[ci].neurons[k].status);
         for (const UnitRt &u : cores_[ci].units)
         {
             if (!u.used) continue;

@@ -57,7 +57,10 @@ public:
 
     const std::vector<uint32_t> &slots() const { return slots_; }           // local slots of all host-core neurons
     const std::vector<uint32_t> &slot_cores() const { return slot_cores_; } // local core of each
-    const std::vector<uint8_t> &status() const { return status_; }
+    const std::vector<uint8_t> &status() const { return status_; }            // after the neuron loop: who sends messages this step
+    // MappedNeuron::status at the END of the step: the message pipeline's soma calls latch it too (execute_pipeline,
+    // src/chip.cpp:780-783) -- what get_spikes / the Python spike trace read after step() (src/pytrace.cpp:190-222)
+    const std::vector<uint8_t> &final_status() const { return final_status_; }
     const std::vector<uint32_t> &core_ids() const { return core_ids_; }     // local core id of every host core
     const std::vector<Partial> &partials() const { return partials_; }
     double potential(size_t i) const; // soma get_potential of host neuron i (order of slots())
@@ -95,7 +98,7 @@ private:
     std::vector<CoreRt> cores_;
     std::vector<void *> plugin_handles_;
     std::vector<uint32_t> slots_, slot_cores_, core_ids_;
-    std::vector<uint8_t> status_;
+    std::vector<uint8_t> status_, final_status_;
     std::vector<Partial> partials_;
 };
 } // namespace sanafe_amd
