@@ -235,6 +235,15 @@ int sanafe_hip_get_layout(sanafe_hip_chip *chip, int *syn_format, uint32_t *n_co
  * weight + 2^shift (formats 7, and 0 / 3 when the per-accumulator bounds hold); 0: fp64 accumulators.  The result is the
  * same bit for bit -- sums of integers are exact in any order; SANAFE_INT_ACC=0 keeps the fp64 accumulators (tests). */
 int sanafe_hip_get_acc_shift(sanafe_hip_chip *chip);
+/* Delivery slices whose axon records are a SOURCE BITMAP (format 7, dense fan-in: one bit per source slot of the slice's
+ * 256-slot windows + one synapse-count byte per axon; "which axons spiked" is an AND with the spike bitmap).
+ * SANAFE_AXON_BITMAP=0 keeps the 2-byte delta records (tests, A/B runs). */
+int sanafe_hip_get_bitmap_slices(sanafe_hip_chip *chip);
+/* Push delivery (steps with few spikes walk the fired neurons' out-synapses instead of probing every inbound axon of
+ * the chip -- same result, chosen per step on the device from the events the step's spikes cause): enabled = the chip
+ * qualifies (integer weights, no synaptic delays / last-event cores / taps / host units / lost charge, one latency class
+ * per core, one GPU; SANAFE_PUSH=0 switches it off), pushed_steps = steps delivered that way since create. */
+int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t *pushed_steps);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.
  *   [0] synapse words (+ fp64 weights in format 2)   [1] axon records   [2] chunk tables   [3] slice descriptors
@@ -342,6 +351,26 @@ typedef struct sanafe_hip_host_core_costs
 int sanafe_hip_write_host_core_status(sanafe_hip_chip *chip, uint32_t count, const uint32_t *slots, const uint8_t *status,
         const uint32_t *core);
 int sanafe_hip_write_host_core_costs(sanafe_hip_chip *chip, uint32_t count, const sanafe_hip_host_core_costs *costs);
+
+/* The run-time state of a chip, slot by slot, in caller-owned host buffers -- what `load(net, overwrite=false)` on a chip that
+ * has already simulated timesteps carries from the old lowering into the new one (src/chip.cpp:129-138 maps the new
+ * neurons next to the programmed ones and keeps every unit's state).  Arrays are [n_slots] except ring / ring_valid
+ * ([ring_slots][n_slots]: row (t % ring_slots) is what step t consumes) and in_pos ([n_input] spike-train cursors);
+ * arrived / ring_last may be NULL when the chip has none. */
+typedef struct sanafe_hip_state
+{
+    int64_t timesteps;      /* steps simulated so far (Timestep::timestep of the next step - 1) */
+    double *v, *icur;
+    int32_t *refrac;
+    uint8_t *status;
+    double *ring;
+    uint8_t *ring_valid;
+    uint8_t *arrived;
+    uint32_t *ring_last;
+    uint32_t *in_pos;
+} sanafe_hip_state;
+int sanafe_hip_export_state(sanafe_hip_chip *chip, sanafe_hip_state *out);
+int sanafe_hip_import_state(sanafe_hip_chip *chip, const sanafe_hip_state *in);
 
 /* SpikingChip::reset: potentials, input currents and buffers to zero. */
 int sanafe_hip_reset(sanafe_hip_chip *chip);

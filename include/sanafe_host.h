@@ -57,6 +57,14 @@ sanafe_hip_chip *sanafe_chip_device(sanafe_chip *chip);
 int sanafe_chip_get_image(sanafe_chip *chip, sanafe_hip_image *out);
 int sanafe_chip_get_slot_map(sanafe_chip *chip, uint32_t *slot_of_neuron);
 
+/* `load(net, overwrite=false)` after timesteps have been simulated (src/chip.cpp:129-138): the caller lowers the programmed
+ * networks plus the new one into `to` (ids, mapping order and per-core offsets continue, so the programmed neurons keep
+ * their global ids) and this call moves the run-time state of the programmed neurons from `from` into it -- potentials,
+ * LIF input currents, refractory counters, statuses, pending synaptic input (time-step buffers / delay lines), spike-train
+ * cursors, the step counter and the run totals.  Chips with stochastic value streams, plugin / host-side units or `taps`
+ * dendrites are refused (UnsupportedError). */
+int sanafe_chip_carry_state(sanafe_chip *to, sanafe_chip *from);
+
 /* SpikingChip::sim(timesteps, timing_model): returns the RunData of this call.
  * record bit 0 keeps per-step totals and spike lists for the getters, bit 2 (value 4) also the messages of every
  * step (the message trace, src/chip.cpp:440-460) -- under `detailed` timing with the scheduled timestamps, under

@@ -401,7 +401,13 @@ class SpikingChip(_Base):
         if H.sanafe_hip_get_layout(self.device_handle(), C.byref(fmt), C.byref(n)) != 0:
             raise RuntimeError(H.sanafe_hip_last_error().decode())
         H.sanafe_hip_get_acc_shift.argtypes = [C.c_void_p]
-        return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle()))}
+        en, pushed = C.c_uint32(), C.c_uint32()
+        H.sanafe_hip_get_push_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        H.sanafe_hip_get_push_info(self.device_handle(), C.byref(en), C.byref(pushed))
+        H.sanafe_hip_get_bitmap_slices.argtypes = [C.c_void_p]
+        return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle())),
+                "push_enabled": bool(en.value), "pushed_steps": int(pushed.value),
+                "n_bitmap_slices": int(H.sanafe_hip_get_bitmap_slices(self.device_handle()))}
 
     def step_neurons(self):
         self._check(self._L.sanafe_chip_step_neurons(self._h))

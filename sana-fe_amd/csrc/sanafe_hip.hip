@@ -105,6 +105,7 @@ struct sanafe_hip_chip
     std::vector<sanafe_hip_soma_class> h_soma_classes; // host copy of the class table the device uses
     int syn_format{2};        // 0..4, see DevImage
     uint32_t n_compact_slices{0};
+    uint32_t n_bitmap_slices{0};  // of those: slices on bitmap axon records
     DevImage im{};
     DevState st{};
     std::vector<void *> allocs;
@@ -194,17 +195,27 @@ struct DeliverVariant
     int fmt;
     bool delay, last, iacc;
     int block;
+    bool bitmap, push;
     const void *fn;
 };
-#define SANAFE_DV(F, D, L, I, B) {F, D, L, I, B, reinterpret_cast<const void *>(deliver_kernel<F, D, L, I, B>)}
+#define SANAFE_DV(F, D, L, I, B) {F, D, L, I, B, false, false, reinterpret_cast<const void *>(deliver_kernel<F, D, L, I, B>)}
+#define SANAFE_DVX(F, D, I, B, BM, P) {F, D, false, I, B, BM, P, reinterpret_cast<const void *>(deliver_kernel<F, D, false, I, B, BM, P>)}
 #define SANAFE_DV_FORMAT(F) SANAFE_DV(F, false, false, false, DELIVER_BLOCK), SANAFE_DV(F, true, false, false, DELIVER_BLOCK), \
                             SANAFE_DV(F, false, true, false, DELIVER_BLOCK), SANAFE_DV(F, false, false, false, 64)
 #define SANAFE_DV_IACC(F) SANAFE_DV(F, false, false, true, DELIVER_BLOCK), SANAFE_DV(F, true, false, true, DELIVER_BLOCK), \
                           SANAFE_DV(F, false, true, true, DELIVER_BLOCK)
 const DeliverVariant deliver_variants[] = {
         SANAFE_DV_FORMAT(0), SANAFE_DV_FORMAT(1), SANAFE_DV_FORMAT(2), SANAFE_DV_FORMAT(3), SANAFE_DV_FORMAT(4), SANAFE_DV_FORMAT(6),
-        SANAFE_DV_FORMAT(7), SANAFE_DV_IACC(0), SANAFE_DV_IACC(3)};
+        SANAFE_DV_FORMAT(7), SANAFE_DV_IACC(0), SANAFE_DV_IACC(3),
+        // bitmap axon records (format 7), with and without the push-delivery prologue
+        SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, false), SANAFE_DVX(7, true, false, DELIVER_BLOCK, true, false),
+        SANAFE_DVX(7, false, false, 64, true, false), SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, true),
+        SANAFE_DVX(7, false, false, 64, true, true),
+        // push-delivery prologue on the integer formats (no synaptic delays, no last-event cores)
+        SANAFE_DVX(7, false, false, DELIVER_BLOCK, false, true), SANAFE_DVX(7, false, false, 64, false, true),
+        SANAFE_DVX(0, false, true, DELIVER_BLOCK, false, true), SANAFE_DVX(3, false, true, DELIVER_BLOCK, false, true)};
 #undef SANAFE_DV
+#undef SANAFE_DVX
 #undef SANAFE_DV_FORMAT
 #undef SANAFE_DV_IACC
 // ordered delivery (format 8): dictionary entries x bitmap in LDS x per-neuron write-back rules
@@ -218,10 +229,11 @@ const OrderedVariant ordered_variants[] = {SANAFE_OV(false, false, false), SANAF
         SANAFE_OV(false, true, true), SANAFE_OV(true, false, false), SANAFE_OV(true, false, true), SANAFE_OV(true, true, false),
         SANAFE_OV(true, true, true)};
 #undef SANAFE_OV
-const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block)
+const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block, bool bitmap, bool push)
 {
     for (const DeliverVariant &v : deliver_variants)
-        if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block) return &v;
+        if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block && v.bitmap == bitmap && v.push == push)
+            return &v;
     return nullptr;
 }
 
@@ -353,7 +365,8 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     DevImage &im = c->im;
     im.push_cap = 0;
     if (std::getenv("SANAFE_PUSH") != nullptr && std::atoi(std::getenv("SANAFE_PUSH")) == 0) return 0; // tests / A-B runs
-    const bool integer_weights = c->syn_format == 7 || ((c->syn_format == 0 || c->syn_format == 3));
+    // (the integer formats whose kernels have a PUSH instantiation: 7, and 0 / 3 on integer accumulators)
+    const bool integer_weights = c->syn_format == 7 || ((c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0);
     if (!integer_weights || h.n_global_slots != h.n_slots || c->has_delay || im.has_last || h.n_taps != 0 || h.n_ext != 0 ||
             h.n_synapses == 0 || h.n_synapses > (64ull << 20) || h.ax_lat_class == nullptr)
         return 0;
@@ -398,11 +411,13 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     TRY(upload(c, syn.data(), syn.size(), &im.push_syn));
     TRY(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_ain_lat));
     TRY(upload(c, ev_lat.data(), ev_lat.size(), &im.core_event_lat));
-    im.push_cap = 65536;
-    im.push_max_events = 49152; // above this the pull path (one probe per inbound axon of the chip) is no slower
+    im.push_cap = h.n_slots / WAVE;
+    // a pushed event costs three atomics; the pull path one probe per inbound axon of the chip, whatever the activity
+    im.push_max_events = (uint32_t) std::min<uint64_t>(16384, std::max<uint64_t>(256, h.n_axons / 128));
     if (const char *env = std::getenv("SANAFE_PUSH_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0L, std::atol(env));
-    TRY(dalloc(c, 3 * 2, &c->st.push_count));
-    TRY(dalloc(c, 3 * (size_t) im.push_cap, &c->st.push_list));
+    TRY(dalloc(c, 8, &c->st.push_count)); // [0..2] decisions (0: pull), [6] steps delivered by the push path
+    TRY(dalloc(c, 3 * (size_t) im.push_cap, &c->st.push_nfired));
+    TRY(dalloc(c, 3 * (size_t) im.push_cap * WAVE, &c->st.push_list));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     return 0;
 }
@@ -643,6 +658,19 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 c->us.cpc = cpc;
                 c->us.wpc_shift = 0;
                 while ((1u << c->us.wpc_shift) < wpc) c->us.wpc_shift++;
+                // one bias for every live slot: a kernel argument instead of an 8-byte load per slot
+                bool same_bias = true;
+                double bias0 = 0.0;
+                bool have_bias = false;
+                for (uint32_t k = 0; k < h.n_cores && same_bias; k++)
+                    for (uint32_t q = 0; q < h.core_ncount[k] && same_bias; q++)
+                    {
+                        const double bq = h.slot_bias[h.core_nbase[k] + q];
+                        if (!have_bias) bias0 = bq, have_bias = true;
+                        same_bias = std::memcmp(&bq, &bias0, sizeof bq) == 0;
+                    }
+                c->us.bias_uniform = same_bias ? 1u : 0u;
+                c->us.bias = bias0;
             }
             c->h_soma_classes.assign(h.soma_classes, h.soma_classes + h.n_soma_classes);
         }
@@ -863,9 +891,17 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<unsigned long long> rec_off(h.n_slices, 0);
         std::vector<uint8_t> mode(h.n_slices, 0), slat(h.n_slices, 0);
         std::vector<uint32_t> chunk0(h.n_slices, 0);
+        std::vector<uint64_t> n_slice_chunks(h.n_slices, 0);
         uint64_t n_chunks = 0, n_bytes = 0;
         bool any_exact = false;
+        bool any_last_cores = false;
+        for (uint32_t g = 0; g < h.n_slots && !any_last_cores; g++)
+            any_last_cores = (h.slot_cls[g] & 7u) != SANAFE_SOMA_NONE &&
+                             (((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST || ((h.slot_cls[g] >> 3) & 7u) == SANAFE_IN_LAST_DELAY);
         const bool runs_format = dict16 || c->syn_format == 0 || c->syn_format == 3 || c->syn_format == 4; // deliver_kernel: RUNS
+        bool bitmap_records = c->syn_format == 7 && !any_last_cores; // deliver_kernel: BITMAP_RECORDS
+        if (const char *env = std::getenv("SANAFE_AXON_BITMAP")) // tests / A-B runs: 0 keeps the 2-byte delta records
+            if (std::atoi(env) == 0) bitmap_records = false;
         parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
             for (uint64_t sl = lo; sl < hi; sl++)
             {
@@ -879,16 +915,41 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 }
                 mode[sl] = ok ? 1 : 0;
                 slat[sl] = ok ? h.ax_lat_class[b0] : 0;
+                // bitmap records: compact-eligible, strictly ascending source slots, no lost charge, a quarter of the span in use
+                if (ok && bitmap_records)
+                {
+                    bool bm = true;
+                    for (uint64_t a = b0 + 1; a < e0 && bm; a++) bm = h.ax_pre[a] > h.ax_pre[a - 1];
+                    const uint64_t windows = (uint64_t) (h.ax_pre[e0 - 1] >> 8) - (h.ax_pre[b0] >> 8) + 1ull;
+                    bm = bm && (e0 - b0) * 4ull >= windows * 256ull;
+                    const uint32_t core = h.slice_core[sl];
+                    for (uint64_t a = b0; a < e0 && bm; a++)
+                        for (uint32_t k = 0; k < h.ax_nsyn[a] && bm; k++)
+                            bm = !((h.syn_meta[h.core_syn_base[core] + h.ax_syn_beg[a] + k] >> 19) & 1u);
+                    if (bm) mode[sl] = 2;
+                }
             }
         });
+        // one kernel per chip: bitmap records only when EVERY compact slice can take them (deliver_kernel<..., BITMAP>)
+        if (bitmap_records)
+        {
+            bool all = true;
+            for (uint32_t sl = 0; sl < h.n_slices; sl++) all = all && mode[sl] != 1;
+            if (!all)
+                for (uint32_t sl = 0; sl < h.n_slices; sl++)
+                    if (mode[sl] == 2) mode[sl] = 1;
+        }
         for (uint32_t sl = 0; sl < h.n_slices; sl++)
         {
             const uint64_t n = h.slice_axon_end[sl] - h.slice_axon_beg[sl];
             if (n >= (1ull << 32)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "slice %u holds 2^32 axons or more", sl));
             rec_off[sl] = n_bytes;
-            n_bytes += ((n * (mode[sl] ? 2ull : 8ull)) + 15ull) & ~15ull;
+            // chunks of a slice: 256 consecutive axons -- or, on bitmap records, the 256-slot windows of its source span
+            n_slice_chunks[sl] = (mode[sl] == 2) ? (uint64_t) (h.ax_pre[h.slice_axon_end[sl] - 1] >> 8) - (h.ax_pre[h.slice_axon_beg[sl]] >> 8) + 1ull
+                                                 : (n + WAVE_CHUNK - 1) / WAVE_CHUNK;
+            n_bytes += (((mode[sl] == 2) ? n_slice_chunks[sl] * 32ull + n : n * (mode[sl] ? 2ull : 8ull)) + 15ull) & ~15ull;
             chunk0[sl] = (uint32_t) n_chunks;
-            n_chunks += (n + WAVE_CHUNK - 1) / WAVE_CHUNK + 1; // + end entry: first synapse after the slice
+            n_chunks += n_slice_chunks[sl] + 1; // + end entry: first synapse after the slice
             if (n_chunks >= (1ull << 32)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "too many axon chunks"));
         }
         // Where each chunk's synapses live on the device.  Formats 1 and 2 keep the image's order.  Format 0 gives
@@ -897,9 +958,29 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<uint64_t> chunk_pos(n_chunks, 0);  // absolute device position of the chunk's first synapse
         std::vector<uint64_t> dev_core_base(h.core_syn_base, h.core_syn_base + h.n_cores);
         uint64_t n_dev_syn = h.n_synapses;
+        // first axon of every chunk (+ the end entry of each slice)
+        std::vector<uint64_t> chunk_ax(n_chunks, 0);
+        parallel_for(h.n_slices, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t sl = lo; sl < hi; sl++)
+            {
+                const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl], nck = n_slice_chunks[sl];
+                if (mode[sl] == 2)
+                {
+                    const uint32_t w0 = h.ax_pre[b0] >> 8;
+                    uint64_t a = b0;
+                    for (uint64_t k = 0; k <= nck; k++)
+                    {
+                        while (a < e0 && (uint64_t) (h.ax_pre[a] >> 8) - w0 < k) a++;
+                        chunk_ax[chunk0[sl] + k] = a;
+                    }
+                }
+                else
+                    for (uint64_t k = 0; k <= nck; k++) chunk_ax[chunk0[sl] + k] = std::min<uint64_t>(b0 + k * WAVE_CHUNK, e0);
+            }
+        });
         auto chunk_syn_count = [&](uint32_t sl, uint64_t k) { // synapses of chunk k of slice sl
-            const uint64_t b0 = h.slice_axon_beg[sl], e0 = h.slice_axon_end[sl];
-            const uint64_t a0 = b0 + k * WAVE_CHUNK, a1 = std::min<uint64_t>(a0 + WAVE_CHUNK, e0);
+            const uint64_t a0 = chunk_ax[chunk0[sl] + k], a1 = chunk_ax[chunk0[sl] + k + 1];
+            if (a1 == a0) return uint64_t{0}; // (a window no axon starts in)
             return (uint64_t) (h.ax_syn_beg[a1 - 1] + h.ax_nsyn[a1 - 1] - h.ax_syn_beg[a0]);
         };
         if (stream_layout)
@@ -912,7 +993,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 const uint32_t core = h.slice_core[sl];
                 if (core != prev_core) dev_core_base[core] = pos;
                 prev_core = core;
-                const uint64_t nck = (h.slice_axon_end[sl] - h.slice_axon_beg[sl] + WAVE_CHUNK - 1) / WAVE_CHUNK;
+                const uint64_t nck = n_slice_chunks[sl];
                 for (uint64_t k = 0; k < nck; k++)
                 {
                     chunk_pos[chunk0[sl] + k] = pos;
@@ -957,8 +1038,12 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 const uint32_t core = h.slice_core[sl];
                 const uint32_t trash_post = (h.core_ncount[core] + 63u) & ~63u; // == npad of the core
                 unsigned char *dst = bytes.data() + rec_off[sl];
-                const uint64_t nck = (e0 - b0 + WAVE_CHUNK - 1) / WAVE_CHUNK;
+                const uint64_t nck = n_slice_chunks[sl];
+                const bool bm = mode[sl] == 2;
+                const uint32_t w0 = (bm && e0 > b0) ? h.ax_pre[b0] >> 8 : 0u; // bitmap records: first 256-slot window of the slice
                 for (uint64_t k = 0; k <= nck; k++) csyn[chunk0[sl] + k] = (uint32_t) (chunk_pos[chunk0[sl] + k] - dev_core_base[core]);
+                if (bm) // the chunk table's second column: first axon of each window, relative to the slice (+ the end entry)
+                    for (uint64_t k = 0; k <= nck; k++) cpre[chunk0[sl] + k] = (uint32_t) (chunk_ax[chunk0[sl] + k] - b0);
                 if (stream_layout) // padding words of every chunk: weight 0 into the trash entry
                     for (uint64_t k = 0; k < nck; k++)
                         for (uint64_t q = chunk_pos[chunk0[sl] + k] + chunk_syn_count((uint32_t) sl, k); q < chunk_pos[chunk0[sl] + k + 1]; q++)
@@ -969,9 +1054,18 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 for (uint64_t a = b0; a < e0; a++)
                 {
                     const uint64_t rel = a - b0;
-                    const uint32_t in_chunk = (uint32_t) (rel % WAVE_CHUNK);
-                    if (in_chunk == 0) cpre[chunk0[sl] + rel / WAVE_CHUNK] = h.ax_pre[a];
-                    if (mode[sl])
+                    // the axon's chunk: 256 consecutive axons, or (bitmap records) the 256-slot window its source lies in
+                    const uint64_t chunk_k = bm ? (uint64_t) (h.ax_pre[a] >> 8) - w0 : rel / WAVE_CHUNK;
+                    const uint32_t in_chunk = bm ? (uint32_t) (a - chunk_ax[chunk0[sl] + chunk_k]) : (uint32_t) (rel % WAVE_CHUNK);
+                    if (!bm && in_chunk == 0) cpre[chunk0[sl] + rel / WAVE_CHUNK] = h.ax_pre[a];
+                    if (bm)
+                    {
+                        // one bit per source slot of the slice's windows, then one synapse-count byte per axon
+                        const uint32_t bit = h.ax_pre[a] - (w0 << 8);
+                        reinterpret_cast<uint32_t *>(dst)[bit >> 5] |= 1u << (bit & 31u);
+                        dst[nck * 32ull + rel] = (unsigned char) h.ax_nsyn[a];
+                    }
+                    else if (mode[sl])
                     {
                         const uint32_t delta = (in_chunk == 0) ? 0u : h.ax_pre[a] - h.ax_pre[a - 1];
                         const uint16_t r16 = (uint16_t) (delta | (h.ax_nsyn[a] << 8));
@@ -987,10 +1081,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                     if (c->syn_format == 2 || c->syn_format == 8) continue;
                     // synapse words: image position -> device position (same offset inside the chunk)
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
-                    const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[b0 + (rel / WAVE_CHUNK) * WAVE_CHUNK];
-                    const uint64_t dpos = chunk_pos[chunk0[sl] + rel / WAVE_CHUNK] + (src - chunk_first);
+                    const uint64_t chunk_first = h.core_syn_base[core] + h.ax_syn_beg[chunk_ax[chunk0[sl] + chunk_k]];
+                    const uint64_t dpos = chunk_pos[chunk0[sl] + chunk_k] + (src - chunk_first);
                     // index of the axon inside its 256-axon chunk; formats 0 and 4 add the chunk's place in a run of 8
-                    const uint32_t code = in_chunk | (c->syn_format == 3 ? 0u : (uint32_t) ((rel / WAVE_CHUNK) & 7u) << 8);
+                    const uint32_t code = in_chunk | (c->syn_format == 3 ? 0u : (uint32_t) (chunk_k & 7u) << 8);
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t m = h.syn_meta[src + k];
@@ -1029,10 +1123,12 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 SliceDesc &d = desc[sl];
                 d.rec_off = rec_off[sl];
                 d.syn_base = dev_core_base[core];
-                d.a_beg = h.slice_axon_beg[sl];
+                d.a_beg = (mode[sl] == 2) ? (unsigned long long) (h.ax_pre[h.slice_axon_beg[sl]] >> 8) * 8ull // first 32-slot word of its windows
+                                          : h.slice_axon_beg[sl];
                 d.ain_lat = h.core_axon_in_latency[core];
                 d.slice_lat = lat255[slat[sl]];
-                d.n_ax = (uint32_t) (h.slice_axon_end[sl] - h.slice_axon_beg[sl]);
+                d.n_ax = (mode[sl] == 2) ? (uint32_t) (n_slice_chunks[sl] * WAVE_CHUNK) // 256 source slots per chunk
+                                         : (uint32_t) (h.slice_axon_end[sl] - h.slice_axon_beg[sl]);
                 d.nbase = h.core_nbase[core];
                 d.ncount = h.core_ncount[core];
                 d.chunk0 = chunk0[sl];
@@ -1065,7 +1161,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<double> lat(256, 0.0);
         if (h.lat_class_per_event) std::copy(h.lat_class_per_event, h.lat_class_per_event + 255, lat.begin());
         TRYC(upload(c, lat.data(), lat.size(), &im.lat_class));
-        for (uint8_t m : mode) c->n_compact_slices += m;
+        for (uint8_t m : mode) c->n_compact_slices += (m != 0), c->n_bitmap_slices += (m == 2);
         c->small_slices = h.n_slices > 0;
         for (uint32_t sl = 0; sl < h.n_slices; sl++) c->small_slices = c->small_slices && (h.slice_axon_end[sl] - h.slice_axon_beg[sl]) <= 2 * WAVE_CHUNK;
         if (const char *env = std::getenv("SANAFE_DELIVER_SMALL")) // tests: 0 keeps the 256-thread workgroups
@@ -1144,7 +1240,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     }
     // the local spike bitmap is this chip's window of the global one: local delivery can start right after the
     // neuron launch, and the multi-GPU exchange gathers in place
-    TRYC(dalloc(c, h.n_global_slots / 32 + 2, &st.bits_global)); // (+ a zero word: the bit padding entries of the ordered layout probe)
+    // (+ zero words past the end: the last 256-slot window of bitmap axon records, the bit padding entries of the ordered layout probe)
+    TRYC(dalloc(c, h.n_global_slots / 32 + 16, &st.bits_global));
     st.bits_local = st.bits_global + h.slot_offset / 32;
     TRYC(dalloc(c, 2 * (size_t) im.n_wgs, &st.wg_part));
     TRYC(dalloc(c, 2 * (size_t) h.n_slices, &st.slice_proc));
@@ -1168,7 +1265,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // per neuron slot and step: bytes the neuron kernel reads / writes (see neuron_kernel)
         uint64_t live = 0;
         for (uint32_t k = 0; k < h.n_cores; k++) live += h.core_ncount[k];
-        const uint64_t rd = (c->uni ? 0u : 4u) + 8u + 8u + 8u + 1u + (im.has_lif ? 8u : 0u) + (im.any_refrac ? 4u : 0u) + (h.n_ext ? 4u : 0u);
+        const uint64_t rd = (c->uni ? 0u : 4u) + 8u + ((c->uni && c->us.bias_uniform) ? 0u : 8u) + 8u + 1u + (im.has_lif ? 8u : 0u) + (im.any_refrac ? 4u : 0u) + (h.n_ext ? 4u : 0u);
         const uint64_t wr = 8u + 1u + (im.has_lif ? 8u : 0u) + (im.any_refrac ? 4u : 0u);
         c->layout_bytes[5] = live * rd;
         c->layout_bytes[6] = live * wr;
@@ -1205,6 +1302,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // The one delivery kernel this chip launches, picked from the table every instantiation lives in (deliver_variants):
     // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
     // first launch.
+    st.push_count = st.push_core_cnt = nullptr;
+    st.push_nfired = st.push_list = nullptr;
+    TRYC(build_push(c, h)); // (before the kernel is picked: chips with push tables run the PUSH instantiations)
     if (c->syn_format == 8)
     {
         // the whole spike bitmap in LDS when it leaves room for four workgroups per CU
@@ -1225,7 +1325,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
         //  dictionary accumulators)
         const bool use_small = c->small_slices && !im.has_last && !c->has_delay && !iacc;
-        const DeliverVariant *v = find_deliver_variant(c->syn_format, !im.has_last && c->has_delay, im.has_last != 0, iacc, use_small ? 64 : DELIVER_BLOCK);
+        const DeliverVariant *v = find_deliver_variant(c->syn_format, !im.has_last && c->has_delay, im.has_last != 0, iacc, use_small ? 64 : DELIVER_BLOCK,
+                c->n_bitmap_slices > 0, im.push_cap != 0u);
         if (v == nullptr)
             return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "no delivery kernel for format %d (delay %d, last %d, integer accumulators %d)",
                     c->syn_format, (int) c->has_delay, im.has_last, (int) iacc));
@@ -1238,8 +1339,6 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->deliver_fn = v->fn;
         c->deliver_block = (uint32_t) v->block;
     }
-    st.push_count = st.push_list = st.push_core_cnt = nullptr;
-    TRYC(build_push(c, h));
     HIPC(hipDeviceSynchronize());
     *out = c;
     return 0;
@@ -1525,9 +1624,27 @@ extern "C" int sanafe_hip_write_ext(sanafe_hip_chip *c, int64_t n_steps, const i
     return 0;
 }
 
+extern "C" int sanafe_hip_get_bitmap_slices(sanafe_hip_chip *c) { return c ? (int) c->n_bitmap_slices : 0; }
 extern "C" int sanafe_hip_get_acc_shift(sanafe_hip_chip *c)
 {
     return c ? c->acc_shift : 0;
+}
+extern "C" int sanafe_hip_get_push_info(sanafe_hip_chip *c, uint32_t *enabled, uint32_t *pushed_steps)
+{
+    if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    if (enabled) *enabled = c->im.push_cap != 0u ? 1u : 0u;
+    if (pushed_steps)
+    {
+        *pushed_steps = 0;
+        if (c->im.push_cap != 0u)
+        {
+            HIPCHK(hipSetDevice(c->device));
+            TRY(flush_pending(c));
+            HIPCHK(hipMemcpyAsync(pushed_steps, c->st.push_count + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+    }
+    return 0;
 }
 extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32_t *n_compact_slices)
 {
@@ -1838,6 +1955,7 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
 extern "C" int sanafe_hip_write_bias(sanafe_hip_chip *c, uint32_t first, uint32_t count, const double *bias)
 {
     if (!c || !bias || (uint64_t) first + count > c->im.n_slots) return fail(SANAFE_HIP_ERR_INVALID, "bad slot range");
+    c->us.bias_uniform = 0u; // the per-slot array is read again from now on
     return h2d(c, const_cast<double *>(c->im.slot_bias) + first, bias, count);
 }
 extern "C" int sanafe_hip_write_potential(sanafe_hip_chip *c, uint32_t first, uint32_t count, const double *v)
@@ -2030,6 +2148,49 @@ extern "C" int sanafe_hip_write_host_core_costs(sanafe_hip_chip *c, uint32_t cou
             (int) ((c->t_host - 1) & 1));
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int sanafe_hip_export_state(sanafe_hip_chip *c, sanafe_hip_state *o)
+{
+    if (!c || !o || !o->v || !o->icur || !o->refrac || !o->status || !o->ring || !o->ring_valid || (c->im.n_input > 0 && !o->in_pos))
+        return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
+    const size_t n = c->im.n_slots, r = (size_t) c->im.ring_slots * n;
+    o->timesteps = c->t_host;
+    TRY(d2h(c, o->v, c->st.v, n));
+    TRY(d2h(c, o->icur, c->st.icur, n));
+    TRY(d2h(c, o->refrac, c->st.refrac, n));
+    TRY(d2h(c, o->status, c->st.status, n));
+    TRY(d2h(c, o->ring, c->st.ring, r));
+    TRY(d2h(c, o->ring_valid, c->st.ring_valid, r));
+    if (o->arrived && c->st.arrived) TRY(d2h(c, o->arrived, c->st.arrived, n));
+    if (o->ring_last && c->st.ring_last) TRY(d2h(c, o->ring_last, c->st.ring_last, n));
+    if (c->im.n_input > 0) TRY(d2h(c, o->in_pos, c->st.in_pos, (size_t) c->im.n_input));
+    return 0;
+}
+
+extern "C" int sanafe_hip_import_state(sanafe_hip_chip *c, const sanafe_hip_state *in)
+{
+    if (!c || !in || !in->v || !in->icur || !in->refrac || !in->status || !in->ring || !in->ring_valid || (c->im.n_input > 0 && !in->in_pos) ||
+            in->timesteps < 0)
+        return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    HIPCHK(hipSetDevice(c->device));
+    TRY(flush_pending(c));
+    const size_t n = c->im.n_slots, r = (size_t) c->im.ring_slots * n;
+    TRY(h2d(c, c->st.v, in->v, n));
+    TRY(h2d(c, c->st.icur, in->icur, n));
+    TRY(h2d(c, c->st.refrac, in->refrac, n));
+    TRY(h2d(c, c->st.status, in->status, n));
+    TRY(h2d(c, c->st.ring, in->ring, r));
+    TRY(h2d(c, c->st.ring_valid, in->ring_valid, r));
+    if (in->arrived && c->st.arrived) TRY(h2d(c, c->st.arrived, in->arrived, n));
+    if (in->ring_last && c->st.ring_last) TRY(h2d(c, c->st.ring_last, in->ring_last, n));
+    if (c->im.n_input > 0) TRY(h2d(c, c->st.in_pos, in->in_pos, (size_t) c->im.n_input));
+    const long long t = in->timesteps;
+    TRY(h2d(c, c->st.t, &t, 1));
+    c->t_host = t; // the step numbering (Timestep::timestep, ring rows, step parity) continues from there
     return 0;
 }
 

@@ -50,7 +50,8 @@ struct SliceDesc
     double slice_lat;            // per-event latency of the slice's latency class
     uint32_t n_ax, nbase, ncount, chunk0;
     uint32_t slice_id;           // index of the slice in core order (slice_proc, core_slice_beg); descriptors are in LAUNCH order
-    uint8_t mode;                // 0 wide, 1 compact axon records
+    uint8_t mode;                // 0 wide, 1 compact axon records, 2 bitmap records (a_beg = first 32-slot word of the slice's
+                                 // source windows, n_ax = 256 x windows; see DevImage)
     uint8_t inkind;              // input kind of the core's neurons (the buffer position belongs to the core)
     uint8_t shared;              // the core has more than one slice: write back with atomics
     uint8_t pad;
@@ -94,6 +95,11 @@ struct DevImage
     //           256-axon chunk, whose pre slot is chunk_pre0) | 8-15 synapse count; one latency class per slice.
     //           Used when the slice's axons are dense in pre-slot order (gaps < 256), have < 256 synapses each
     //           and share a latency class -- the normal case of a large recurrent network.
+    //   bitmap  (format 7 only) the slice's source space cut into 256-slot windows (= its chunks): one bit per source
+    //           slot (set: this core has an axon from that neuron; the axon order IS ascending source slot), then one byte
+    //           per axon with its synapse count.  "Which axons spiked" becomes an AND with the spike bitmap, 32 axons per
+    //           instruction.  Used when the slice's axons are compact-eligible, own their synapses (no lost charge) and fill
+    //           at least a quarter of the source span -- large recurrent networks: every core hears from most neurons.
     const unsigned char *ax_bytes;            // all slices' records, each slice 16-byte aligned
     const uint32_t *chunk_syn0;               // per 256-axon chunk: first synapse (relative to the core)
     const uint32_t *chunk_pre0;               // per 256-axon chunk: pre slot of its first axon
@@ -129,14 +135,17 @@ struct DevImage
     int syn_format;               // 0 .. 4, 6, 7 as above
     int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
-    // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): the neuron launch compacts the
-    // fired neurons into a list and counts the synaptic events they cause; when that count is small the delivery launch
-    // walks the fired neurons' static out-synapse lists instead of probing every inbound axon of the chip (deliver_kernel).
+    // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): every wavefront of the neuron
+    // launch leaves the fired neurons of its 64-slot chunk in the chunk's own list segment (no atomics), and when activity is
+    // low the delivery launch walks the fired neurons' static out-synapse lists instead of probing every inbound axon of
+    // the chip (deliver_kernel).  Which path a step takes is decided on the device from the synaptic events of the step
+    // two before it (reduce_l2 leaves the decision for the delivery launch and for reduce_l1 of that step).
     // Only built for chips where the result cannot depend on the order of the additions and the per-core message costs are
     // integers times a constant: integer weights, no synaptic delays / last-event cores / taps / host units, one latency
     // class per core, one GPU.  push_cap == 0: not built.
-    uint32_t push_cap;            // entries of the fired list (per buffer)
-    uint32_t push_max_events;     // largest event count of a step that is pushed
+    uint32_t push_cap;            // 0: not built; else the number of 64-slot neuron chunks (one list segment each)
+    uint32_t push_max_events;     // a step is pushed when the step TWO before it caused at most this many synaptic events
+                                  // (the prediction only picks the faster path: both paths are exact for any activity)
     const uint32_t *push_ptr;     // [n_slots + 1] out-synapses of each neuron
     const struct PushEntry *push_syn; // post slot, destination core | first-synapse-of-its-axon flag, weight
     const double *core_ain_lat;   // [n_cores] axon-in latency per message
@@ -211,9 +220,10 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
-    // push delivery, triple-buffered by step number % 3 (a buffer is zeroed one launch before its step uses it)
-    uint32_t *push_count;         // [3][2]: fired neurons, synaptic events they cause
-    uint32_t *push_list;          // [3][push_cap] local slots of the fired neurons (any order)
+    // push delivery, triple-buffered by step number % 3
+    uint32_t *push_count;         // [0..2]: 1 = the step with that number % 3 is pushed; [6]: steps pushed so far (diagnostics)
+    uint8_t *push_nfired;         // [3][push_cap] fired neurons of each 64-slot chunk
+    uint8_t *push_list;           // [3][push_cap][64] their lanes (any order)
     uint32_t *push_core_cnt;      // [3][n_cores][2]: messages, events delivered to each core by the push path
     double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
@@ -280,7 +290,7 @@ __device__ __forceinline__ double synapse_weight_at(const DevImage &im, unsigned
 }
 
 __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf);
-__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev);
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev, int decide_buf);
 
 // Per-launch values the host works out (no 64-bit division or row arithmetic on the device).
 struct StepArgs
@@ -306,6 +316,8 @@ struct UniformSoma
     uint32_t ncount;     // neurons of every core that has any
     uint32_t cpc;        // 64-slot chunks of such a core
     uint32_t wpc_shift;  // log2(neuron workgroups per core)
+    uint32_t bias_uniform; // every live slot carries the bias `bias`: the per-slot array is not read (C4: no biases at all)
+    double bias;
 };
 
 // ---------------------------------------------------------------------------------------
@@ -331,9 +343,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
     if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
-        if (im.push_cap != 0u && blockIdx.x == 0 && threadIdx.x < 2) // the buffer the NEXT step's launch counts into
-            st.push_count[((sa.push_buf + 1) % 3) * 2 + threadIdx.x] = 0u;
-        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
+        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, sa.push_buf);
         const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
         if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
         return;
@@ -379,7 +389,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         else cls = im.slot_cls[c0 + lane];
         in_valid = p_rvalid[lane];
         in_value = p_ring[lane];
-        bias = p_bias[lane];
+        bias = (UNI && us.bias_uniform) ? us.bias : p_bias[lane];
         v_in = p_v[lane];
         if (MODEL != SANAFE_SOMA_TRUENORTH && im.has_lif) ic_in = p_icur[lane];
         if (MODEL != SANAFE_SOMA_TRUENORTH && im.any_refrac) rc_in = p_refrac[lane];
@@ -600,6 +610,13 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         if (live && model != SANAFE_SOMA_HOST) st.status[c0 + lane] = (uint8_t) status;
         if (sa.stlog != nullptr && live) sa.stlog[c0 + lane] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
+        if (im.push_cap != 0u)
+        {
+            // push delivery: the fired lanes of this chunk, in the chunk's own list segment (no atomics, nothing to zero)
+            const size_t q = (size_t) sa.push_buf * im.push_cap + (c0 >> 6);
+            if (status == 3) st.push_list[q * WAVE + (uint32_t) __popcll(fired_mask & ((1ull << lane) - 1ull))] = (uint8_t) lane;
+            if (lane == 0) st.push_nfired[q] = (uint8_t) __popcll(fired_mask);
+        }
         if (lane == 0)
         {
             const uint32_t w = c0 >> 5;
@@ -662,19 +679,6 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 n_pack = (long long) ((unsigned long long) ph >> 40);
                 n_hops = (long long) ((unsigned long long) ph & ((1ull << 40) - 1ull));
                 n_ev = wave_sum((long long) ss.events);
-                if (im.push_cap != 0u)
-                {
-                    // compact the fired neurons into the step's list (order irrelevant: the push path adds integers)
-                    uint32_t base = 0;
-                    if (lane == 0)
-                    {
-                        base = atomicAdd(&st.push_count[sa.push_buf * 2], (uint32_t) n_fire);
-                        atomicAdd(&st.push_count[sa.push_buf * 2 + 1], (uint32_t) (n_ev > 0xffffffffll ? 0xffffffffll : n_ev));
-                    }
-                    base = (uint32_t) __builtin_amdgcn_readfirstlane((int) base);
-                    const uint32_t rank = base + (uint32_t) __popcll(fired_mask & ((1ull << lane) - 1ull));
-                    if (status == 3 && rank < im.push_cap) st.push_list[(size_t) sa.push_buf * im.push_cap + rank] = c0 + lane;
-                }
                 if (im.spike_energy & 1) e_syn = wave_sum(ss.e_syn);
                 if (im.spike_energy & 2) e_net = wave_sum(ss.e_net);
                 if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
@@ -733,6 +737,9 @@ constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bit
 #ifndef SANAFE_DELIVER_WAVES_PER_EU
 #define SANAFE_DELIVER_WAVES_PER_EU 5
 #endif
+#ifndef SANAFE_BITMAP_WAVES_PER_EU
+#define SANAFE_BITMAP_WAVES_PER_EU 5 // (bitmap axon records leave ~9 registers of headroom: 6 waves per SIMD spill 5 dwords)
+#endif
 constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
 #ifndef SANAFE_STREAM_MIN_ACTIVE_LANES
 #define SANAFE_STREAM_MIN_ACTIVE_LANES 8
@@ -781,19 +788,70 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 #endif
 }
 
+// Push delivery of one step (deliver_kernel<..., PUSH> when the step's decision word says so): one wavefront per 64-slot
+// neuron chunk, all of them -- most are empty -- and one lane per fired neuron of the chunk, walking that neuron's
+// out-synapses.  Kept out of line: the streaming kernel must not pay registers for it.
+// (arguments by value, in registers: a reference to the kernel's by-value image would be copied to the stack)
+__device__ __noinline__ void push_deliver(const uint8_t *nfired /* of this step's buffer */, const uint8_t *list, const uint32_t *push_ptr,
+        const PushEntry *push_syn, double *ring_row, uint8_t *valid_row, uint32_t *cnt, uint32_t push_cap, uint32_t block)
+{
+    const uint32_t gwave = (blockIdx.x * block + threadIdx.x) >> 6, n_waves = (gridDim.x * block) >> 6;
+    const uint32_t pl = threadIdx.x & (WAVE - 1);
+    // every wavefront takes `per` consecutive chunks (all wavefronts of the launch work: C4 has 4 chunks per wavefront);
+    // their fired counts come with ONE load, lane j holding chunk j's
+    const uint32_t per = min((uint32_t) WAVE, (push_cap + n_waves - 1u) / n_waves);
+    for (uint32_t q0 = gwave * per; q0 < push_cap; q0 += n_waves * per)
+    {
+        const uint32_t q = q0 + pl;
+        const uint32_t mine = (pl < per && q < push_cap) ? nfired[q] : 0u;
+        unsigned long long busy = __ballot(mine != 0u);
+        while (busy != 0ull) // chunks with fired neurons (a few per cent of them)
+        {
+            const uint32_t j = (uint32_t) __ffsll((long long) busy) - 1u;
+            busy &= busy - 1ull;
+            const uint32_t chunk = q0 + j, n_fired = (uint32_t) __builtin_amdgcn_readlane((int) mine, (int) j);
+            // the chunk's fired lanes and their synapse ranges, one lane each (one round trip for all of them)
+            uint32_t b = 0, e = 0;
+            if (pl < n_fired)
+            {
+                const uint32_t pre = chunk * WAVE + list[(size_t) chunk * WAVE + pl];
+                b = push_ptr[pre];
+                e = push_ptr[pre + 1];
+            }
+            for (uint32_t i = 0; i < n_fired; i++) // neuron by neuron, the lanes over its out-synapses
+            {
+                const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) b, (int) i), ei = (uint32_t) __builtin_amdgcn_readlane((int) e, (int) i);
+                for (uint32_t k = bi + pl; k < ei; k += WAVE)
+                {
+                    const PushEntry pe = push_syn[k];
+                    atomicAdd(&ring_row[pe.post], pe.w); // integers: exact in any order
+                    valid_row[pe.post] = 1;
+                    const uint32_t core = pe.core & 0x7fffffffu;
+                    atomicAdd(&cnt[core * 2u + 1u], 1u);
+                    if (pe.core >> 31) atomicAdd(&cnt[core * 2u], 1u);
+                }
+            }
+        }
+    }
+}
+
 // LAST: the chip has cores whose time-step buffer sits before the dendrite unit (SANAFE_IN_LAST): for those cores the
 // workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
 // instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
 // (src/chip.cpp:738-764).  Compiled out (LAST = false) for every chip without such cores.
 // BLOCK: 256 threads (4 wavefronts share a slice's chunks), or 64 on chips whose slices hold one or two chunks (TrueNorth:
 // ~256 axons per core) -- most of the four wavefronts would idle and hold wave slots.
-template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false, int BLOCK = DELIVER_BLOCK>
-__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(SANAFE_DELIVER_WAVES_PER_EU, 8)))
+// BITMAP: every compact slice of the chip is on bitmap axon records (SliceDesc::mode 2; format 7 only) -- compiled apart from
+// the 2-byte delta records so that neither phase A pays for the other's registers.  PUSH: the chip has push-delivery tables
+// (DevImage::push_*); the kernel starts with the per-step push / pull decision.
+template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false, int BLOCK = DELIVER_BLOCK, bool BITMAP = false, bool PUSH = false>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BITMAP ? SANAFE_BITMAP_WAVES_PER_EU : SANAFE_DELIVER_WAVES_PER_EU, 8)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, uint32_t first_slice)
 {
     __shared__ uint32_t s_beg[BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
     __shared__ __align__(256) uint32_t s_pref[BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[BLOCK / WAVE];
+    __shared__ long long s_redi[BLOCK / WAVE];
     constexpr bool DICT16 = (SYN_FMT == 6 || SYN_FMT == 7); // 2-byte words, dictionary-coded weights
     constexpr bool INT_ACC = (SYN_FMT == 7) || IACC;        // 32-bit integer accumulators (see DevImage): format 7 always, formats 0 / 3 when the bounds hold
     static_assert(!IACC || SYN_FMT == 0 || SYN_FMT == 3, "integer accumulators: formats 0, 3 and 7");
@@ -809,36 +867,23 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool CODE11 = (SYN_FMT == 0 || SYN_FMT == 4);
     constexpr bool BYTE_TABLE = RUNS && !DICT16;
     constexpr uint32_t RUN_MAX = 8;
+    // Slices on BITMAP axon records (SliceDesc::mode 2): format 7 without last-event cores (see phase A below)
+    constexpr bool BITMAP_RECORDS = BITMAP;
+    static_assert(!BITMAP || (SYN_FMT == 7 && !LAST), "bitmap axon records: format 7 without last-event cores");
     // formats 6, 7: bit 32 + a = "axon a of the run spiked"; formats 0, 4: byte (code11) = "that axon spiked"
     __shared__ uint32_t s_bits[RUNS ? BLOCK / WAVE : 1][BYTE_TABLE ? RUN_MAX * 64 : RUNS ? RUN_MAX * 8 + 8 : 1];
     if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
     if (SYN_FMT == 7 && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
-    if (im.push_cap != 0u)
+    if constexpr (PUSH)
     {
         // ---- few spikes: push the fired neurons' out-synapses instead of probing every inbound axon (see DevImage) ----
         const uint32_t buf = (uint32_t) (done % 3);
-        const uint32_t n_fired = st.push_count[buf * 2], n_events = st.push_count[buf * 2 + 1];
-        if (n_fired <= im.push_cap && n_events <= im.push_max_events) // the same decision in every workgroup and in reduce_l1
+        if (st.push_count[buf] != 0u) // the same decision in every workgroup and in reduce_l1
         {
-            const uint32_t gwave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, n_waves = (gridDim.x * BLOCK) >> 6;
-            const uint32_t pl = threadIdx.x & (WAVE - 1);
             const size_t row = (size_t) ((done + 2) % (long long) im.ring_slots) * im.n_slots; // (no synaptic delays on push chips)
-            uint32_t *cnt = st.push_core_cnt + (size_t) buf * im.n_cores * 2u;
-            for (uint32_t i = gwave; i < n_fired; i += n_waves) // one wavefront per fired neuron, lanes over its synapses
-            {
-                const uint32_t pre = st.push_list[(size_t) buf * im.push_cap + i];
-                const uint32_t b = im.push_ptr[pre], e = im.push_ptr[pre + 1];
-                for (uint32_t k = b + pl; k < e; k += WAVE)
-                {
-                    const PushEntry pe = im.push_syn[k];
-                    atomicAdd(&st.ring[row + pe.post], pe.w); // integers: exact in any order
-                    st.ring_valid[row + pe.post] = 1;
-                    const uint32_t core = pe.core & 0x7fffffffu;
-                    atomicAdd(&cnt[core * 2u + 1u], 1u);
-                    if (pe.core >> 31) atomicAdd(&cnt[core * 2u], 1u);
-                }
-            }
+            push_deliver(st.push_nfired + (size_t) buf * im.push_cap, st.push_list + (size_t) buf * im.push_cap * WAVE, im.push_ptr, im.push_syn,
+                    st.ring + row, st.ring_valid + row, st.push_core_cnt + (size_t) buf * im.n_cores * 2u, im.push_cap, BLOCK);
             return;
         }
     }
@@ -866,6 +911,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     const unsigned long long syn_base = sd.syn_base;
     const double ain_lat = sd.ain_lat;
     const bool compact = sd.mode != 0; // workgroup-uniform
+    const bool bitmap = BITMAP && compact; // (on a BITMAP chip every compact slice keeps its records as a source bitmap)
     const unsigned char *rec = im.ax_bytes + sd.rec_off;
     const uint32_t *chunk_syn0 = im.chunk_syn0 + sd.chunk0;
     const uint32_t *chunk_pre0 = im.chunk_pre0 + sd.chunk0;
@@ -1240,8 +1286,81 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 }
                 if (N == 1) q_single = q[0];
             };
-            if (run_len == 1) phase_a(std::integral_constant<uint32_t, 1>{});
-            else phase_a(std::integral_constant<uint32_t, RUN_MAX>{});
+            uint32_t before_bm = 0;                  // bitmap records: axons of the run before its first dense chunk
+            // bitmap records: this lane's source word, its spiking axons, the axons of the run before it (phase C loads them
+            // again rather than keeping three registers alive across the stream)
+            auto bitmap_words = [&](uint32_t &bm_src, uint32_t &bm_f, uint32_t &bm_excl, uint32_t &fincl) {
+                const uint32_t n_here = min(run_len, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK);
+                const bool have = (uint32_t) lane < n_here * 8u;
+                const uint32_t *srcw = reinterpret_cast<const uint32_t *>(rec) + (size_t) ci0 * 8u;
+                bm_src = have ? srcw[lane] : 0u;
+                const uint32_t spk = have ? bits[(uint32_t) a_beg + ci0 * 8u + (uint32_t) lane] : 0u;
+                bm_f = spk & bm_src;
+                const uint32_t cnt = (uint32_t) __popc(bm_src);
+                bm_excl = wave_inclusive_scan(cnt) - cnt;
+                fincl = wave_inclusive_scan((uint32_t) __popc(bm_f));
+                return n_here;
+            };
+            if (BITMAP_RECORDS && bitmap)
+            {
+                uint32_t bm_src, bm_f, bm_excl, fincl;
+                // ---- Phase A on BITMAP records (slice mode 2): a chunk is a 256-slot window of the source space, one 32-bit
+                //      word per lane, a run = 8 windows = the 64 lanes.  "Which axons spiked" is ONE AND of two coalesced
+                //      loads -- the slice's source bitmap (bit = this core has an axon from that neuron) and the global spike
+                //      bitmap at the same position -- instead of a record decode, a prefix sum and a random probe per axon.
+                const uint32_t n_here = bitmap_words(bm_src, bm_f, bm_excl, fincl);
+                stream_msgs += (uint32_t) __popc(bm_f);
+                // per chunk (8 lanes): spiking axons -> stream (many), gather (few) or nothing
+#pragma unroll
+                for (uint32_t j = 0; j < RUN_MAX; j++)
+                {
+                    if (j >= n_here) break;
+                    const uint32_t hi8 = (uint32_t) __builtin_amdgcn_readlane((int) fincl, (int) (8u * j + 7u));
+                    const uint32_t lo8 = j == 0u ? 0u : (uint32_t) __builtin_amdgcn_readlane((int) fincl, (int) (8u * j - 1u));
+                    const uint32_t n_spiking = hi8 - lo8;
+                    dense_mask |= (n_spiking >= STREAM_MIN_ACTIVE_LANES) ? (1u << j) : 0u;
+                    gather_mask |= (n_spiking > 0u && n_spiking < STREAM_MIN_ACTIVE_LANES) ? (1u << j) : 0u;
+                }
+                if (dense_mask != 0u)
+                {
+                    // bit table for phase B: bit 32 + a = "axon a (counted from the first dense chunk) spiked".  The spiking
+                    // bits of a lane are its word compressed by its source mask, placed at the lane's first axon.
+                    const uint32_t first_dense = (uint32_t) __builtin_ctz(dense_mask);
+                    before_bm = (uint32_t) __builtin_amdgcn_readlane((int) bm_excl, (int) (8u * first_dense));
+                    w_bits[lane] = 0u;
+                    if (lane < 8) w_bits[64 + lane] = 0u;
+                    wave_lds_fence();
+                    const bool my_dense = (dense_mask >> ((uint32_t) lane >> 3)) & 1u;
+                    uint32_t x = my_dense ? bm_f : 0u;
+                    if (x != 0u)
+                    {
+                        // compress x by the mask bm_src (Hacker's Delight 7-4: five parallel-suffix rounds)
+                        uint32_t m = bm_src, mk = ~m << 1;
+#pragma unroll
+                        for (int i = 0; i < 5; i++)
+                        {
+                            uint32_t mp = mk ^ (mk << 1);
+                            mp ^= mp << 2;
+                            mp ^= mp << 4;
+                            mp ^= mp << 8;
+                            mp ^= mp << 16;
+                            const uint32_t mv = mp & m;
+                            m = (m ^ mv) | (mv >> (1 << i));
+                            const uint32_t tt = x & mv;
+                            x = (x ^ tt) | (tt >> (1 << i));
+                            mk &= ~mp;
+                        }
+                        const uint32_t pos = 32u + bm_excl - before_bm, sh = pos & 31u;
+                        atomicOr(&w_bits[pos >> 5], x << sh);
+                        if (sh != 0u && (x >> (32u - sh)) != 0u) atomicOr(&w_bits[(pos >> 5) + 1u], x >> (32u - sh));
+                    }
+                }
+            }
+            else if constexpr (!BITMAP)
+            {
+                if (run_len == 1) phase_a(std::integral_constant<uint32_t, 1>{});
+                else phase_a(std::integral_constant<uint32_t, RUN_MAX>{});
+            }
             if (dense_mask != 0u)
             {
                 // ---- Phase B: stream the words of chunks first_dense .. last_dense ----
@@ -1274,7 +1393,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 // per group the lanes count their bits, one DPP prefix sum orders the lanes, a scalar carries the count
                 // from group to group.  The eight axons of a lane are consecutive, so ONE 32-bit window of the bit
                 // table (two dwords, funnel-shifted) answers "spiked?" for all eight words.
-            uint32_t before = first_dense * WAVE_CHUNK; // first-synapse bits of the run before the current group-instruction (wave-uniform)
+            uint32_t before = (BITMAP_RECORDS && bitmap) ? 0u : first_dense * WAVE_CHUNK; // first-synapse bits of the run before the current group-instruction (wave-uniform); bitmap records count axons from the first dense chunk
             // LDS address of the accumulators, hidden from constant folding: the compiler then forms
             // base + (index << 2) in one instruction instead of rebuilding it from shifted masks
             typedef __attribute__((address_space(3))) uint32_t lds_u32;
@@ -1437,6 +1556,60 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 wave_lds_fence(); // the table is rewritten by the next run
             }
             // ---- Phase C: chunks with a few spiking axons ----
+            if (BITMAP_RECORDS && bitmap && gather_mask != 0u) // wave-uniform
+            {
+            uint32_t bm_src, bm_f, bm_excl, fincl_unused;
+            bitmap_words(bm_src, bm_f, bm_excl, fincl_unused);
+            while (gather_mask != 0u)
+            {
+                // bitmap records: a window with fewer than STREAM_MIN_ACTIVE_LANES spiking axons.  The whole wave takes them
+                // one by one: first synapse = the chunk's first + the synapse counts of the axons before it (one byte per axon
+                // behind the slice's bitmap words), then one lane per synapse.
+                const uint32_t j = (uint32_t) __builtin_ctz(gather_mask);
+                gather_mask &= gather_mask - 1u;
+                const uint32_t ci = ci0 + j;
+                const uint32_t ax0 = chunk_pre0[ci], axc = chunk_pre0[ci + 1u] - ax0; // first axon of the window (within the slice), axons in it
+                const uint8_t *nsyn8 = rec + (size_t) (n_ax / WAVE_CHUNK) * 32u + ax0;
+                uint32_t mine[AX_PER_THREAD], lane_sum = 0;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                {
+                    const uint32_t a = (uint32_t) lane * AX_PER_THREAD + (uint32_t) k;
+                    mine[k] = a < axc ? nsyn8[a] : 0u;
+                    lane_sum += mine[k];
+                }
+                uint32_t run_sum = wave_inclusive_scan(lane_sum) - lane_sum;
+#pragma unroll
+                for (int k = 0; k < AX_PER_THREAD; k++)
+                {
+                    w_beg[(uint32_t) lane * AX_PER_THREAD + (uint32_t) k] = run_sum | (mine[k] << 24); // first synapse (in the chunk) | count
+                    run_sum += mine[k];
+                }
+                wave_lds_fence();
+                const uint32_t chunk_first = chunk_syn0[ci];
+                const uint32_t excl0 = (uint32_t) __builtin_amdgcn_readlane((int) bm_excl, (int) (8u * j));
+                for (uint32_t wv = 0; wv < 8u; wv++)
+                {
+                    uint32_t fw = (uint32_t) __builtin_amdgcn_readlane((int) bm_f, (int) (8u * j + wv));
+                    const uint32_t sw = (uint32_t) __builtin_amdgcn_readlane((int) bm_src, (int) (8u * j + wv));
+                    const uint32_t ex = (uint32_t) __builtin_amdgcn_readlane((int) bm_excl, (int) (8u * j + wv)) - excl0;
+                    while (fw != 0u) // scalar loop over the spiking axons of this word
+                    {
+                        const uint32_t b = (uint32_t) __builtin_ctz(fw);
+                        fw &= fw - 1u;
+                        const uint32_t a = ex + (uint32_t) __builtin_popcount(sw & ((1u << b) - 1u)); // axon within the window
+                        const uint32_t e = w_beg[a];
+                        const uint32_t first = chunk_first + (e & 0xffffffu), n = e >> 24;
+                        for (uint32_t k = (uint32_t) lane; k < n; k += WAVE)
+                        {
+                            const uint32_t word = reinterpret_cast<const uint16_t *>(im.syn_meta)[syn_base + first + k];
+                            atomicAdd(&acc32[word >> 6], (uint32_t) s_lut16[(word >> 1) & 31u]); // ds_add_u32
+                        }
+                    }
+                }
+                wave_lds_fence(); // w_beg is rewritten by the next window
+            }
+            }
             while (gather_mask != 0u) // wave-uniform
             {
                 const uint32_t j = (uint32_t) __builtin_ctz(gather_mask);
@@ -1479,19 +1652,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (__ballot(amask != 0) == 0ull) continue; // wave-uniform
         gather_chunk(c0, amask, nsyn, lcls);
     }
-    // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
-    if (STREAMABLE) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
-    proc = wave_sum(proc);
-    if (lane == 0) s_red[wave] = proc;
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        double p = 0.0;
-        for (int w = 0; w < BLOCK / WAVE; w++) p += s_red[w];
-        // one value per slice; level 1 of the step reduction adds a core's slices in order (reproducible)
-        st.slice_proc[(size_t) (done & 1) * im.n_slices + slice] = p;
-    }
     // ---- write the accumulated charge back (one access per touched neuron and delay value) ----
+    __syncthreads(); // every wave's additions are in the accumulators
+    long long wb_events = 0; // bitmap records: the synaptic events of the slice = the event counts of its integer accumulators
     const bool shared_core = sd.shared != 0;
     if (LAST && last_mode)
     {
@@ -1510,6 +1673,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             if (v == 0u) continue;
             const uint32_t events = (v + (1u << (im.acc_shift - 1))) >> im.acc_shift;
             sum = (double) (int) (v - (events << im.acc_shift));
+            if (BITMAP_RECORDS && bitmap && i % RS < npad) wb_events += events; // (not the trash entry: padding words land there)
         }
         else
         {
@@ -1537,6 +1701,29 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         else st.ring[gi] += sum;
         st.ring_valid[gi] = 1;
         if (gated) st.arrived[nbase + n] = 1;
+    }
+    // ---- processing-delay sum of this slice (simple timing model): wave partials, combined after the barrier ----
+    if (STREAMABLE) proc += (double) stream_events * slice_lat + (double) stream_msgs * ain_lat;
+    proc = wave_sum(proc);
+    if (BITMAP_RECORDS) wb_events = wave_sum(wb_events);
+    if (lane == 0)
+    {
+        s_red[wave] = proc;
+        if (BITMAP_RECORDS) s_redi[wave] = wb_events;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        double p = 0.0;
+        long long ev = 0;
+        for (int w = 0; w < BLOCK / WAVE; w++)
+        {
+            p += s_red[w];
+            if (BITMAP_RECORDS) ev += s_redi[w];
+        }
+        if (BITMAP_RECORDS && bitmap) p += (double) ev * slice_lat;
+        // one value per slice; level 1 of the step reduction adds a core's slices in order (reproducible)
+        st.slice_proc[(size_t) (done & 1) * im.n_slices + slice] = p;
     }
 }
 
@@ -1818,11 +2005,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
         // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
         const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
         bool pushed = false;
-        if (im.push_cap != 0u)
-        {
-            const uint32_t n_fired = st.push_count[push_buf * 2], n_events = st.push_count[push_buf * 2 + 1];
-            pushed = n_fired <= im.push_cap && n_events <= im.push_max_events; // the delivery launch took the same decision
-        }
+        if (im.push_cap != 0u) pushed = st.push_count[push_buf] != 0u; // the delivery launch of the step read the same word
         if (pushed)
         {
             // the push path counted this core's messages and events: integers times the core's constants
@@ -1830,6 +2013,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
             proc = (double) cnt[1] * im.core_event_lat[c] + (double) cnt[0] * im.core_ain_lat[c];
             cnt[0] = 0u;
             cnt[1] = 0u;
+            if (c == 0u) st.push_count[6] += 1u; // diagnostics: steps delivered by the push path (sanafe_hip_get_push_info)
         }
         else if (s1 - s0 <= 2u)
         {
@@ -1882,7 +2066,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
 
 // Level 2: one wavefront folds the groups (lane = group, further groups in rounds of 64) into the Timestep
 // totals, applies the simple timing model, accumulates RunData and writes the step record.
-__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev)
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev, int decide_buf /* -1: none */)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const GroupPart *gp = st.group_part + (size_t) prev.parity * im.n_groups;
@@ -1952,6 +2136,8 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
             st.step_log[prev.rec_index % st.log_cap] = ts;
             *st.rec = prev.rec_index + 1;
         }
+        // push or pull for the step whose neuron launch this reduction rides in: few events two steps ago -> push
+        if (im.push_cap != 0u && decide_buf >= 0) st.push_count[decide_buf] = (events <= (long long) im.push_max_events) ? 1u : 0u;
         if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;
     }
@@ -1972,7 +2158,7 @@ __global__ void state_log_kernel(const double *v, const double *icur, const uint
 __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PendStep l1, PendStep l2)
 {
     const int wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
+    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, -1);
     const uint32_t group = blockIdx.x * (REDUCE_BLOCK / WAVE) + (uint32_t) wave;
     if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
 }

@@ -976,6 +976,78 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     return 0;
 }
 
+// load(net, overwrite=false) on a chip that has already simulated timesteps (src/chip.cpp:129-138: the new neurons are
+// mapped next to the programmed ones, every unit keeps its state): the combined network was lowered into `to`; the
+// programmed neurons keep their global ids, so their state moves slot by slot -- potentials, LIF input currents,
+// refractory counters, statuses, the time-step buffers / delay lines (by the future step a row belongs to), spike-train
+// cursors -- and the step numbering continues.
+extern "C" int sanafe_chip_carry_state(sanafe_chip *to, sanafe_chip *from)
+{
+    if (!to || !from || !to->dev || !from->dev) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
+    const MappedChip &a = from->mc, &b = to->mc;
+    if (from->n_ranks != 1 || to->n_ranks != 1) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: adding a network to a tile-sharded chip after timesteps have run");
+    for (const sanafe_chip *c : {from, to})
+        if (!c->mc.ext.empty() || !c->mc.host_neurons.empty() || c->hcores || !c->mc.tap_slot.empty())
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: load(net, overwrite=False) after timesteps have been simulated is not "
+                                                    "available with stochastic value streams, plugin / host-side units or `taps` dendrites "
+                                                    "(their state lives in host objects that a new lowering re-creates)");
+    if (from->n_neurons > to->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "the new chip does not hold the programmed neurons");
+    auto buffers = [](const MappedChip &m, std::vector<double> &v, std::vector<double> &u, std::vector<int32_t> &rf, std::vector<uint8_t> &stt,
+                           std::vector<double> &ring, std::vector<uint8_t> &rv, std::vector<uint8_t> &arr, std::vector<uint32_t> &last,
+                           std::vector<uint32_t> &pos, sanafe_hip_state &s) {
+        const size_t n = m.n_slots;
+        v.assign(n, 0.0);
+        u.assign(n, 0.0);
+        rf.assign(n, 0);
+        stt.assign(n, 0);
+        ring.assign(static_cast<size_t>(m.ring_slots) * n, 0.0);
+        rv.assign(static_cast<size_t>(m.ring_slots) * n, 0);
+        arr.assign(n, 0);
+        last.assign(n, 0);
+        pos.assign(std::max<size_t>(1, m.in_train_beg.size()), 0);
+        s = sanafe_hip_state{0, v.data(), u.data(), rf.data(), stt.data(), ring.data(), rv.data(), arr.data(), last.data(), pos.data()};
+    };
+    std::vector<double> av, au, aring, bv, bu, bring;
+    std::vector<int32_t> arf, brf;
+    std::vector<uint8_t> ast, arv, aarr, bst, brv, barr;
+    std::vector<uint32_t> alast, apos, blast, bpos;
+    sanafe_hip_state sa{}, sb{};
+    buffers(a, av, au, arf, ast, aring, arv, aarr, alast, apos, sa);
+    buffers(b, bv, bu, brf, bst, bring, brv, barr, blast, bpos, sb);
+    DEV(sanafe_hip_export_state(from->dev, &sa));
+    DEV(sanafe_hip_export_state(to->dev, &sb)); // the new neurons' initial values stay
+    const int64_t t = sa.timesteps;
+    const uint32_t ra = a.ring_slots, rb = b.ring_slots;
+    for (int64_t g = 0; g < from->n_neurons; g++)
+    {
+        const uint32_t s0 = a.slot_of_gid[g], s1 = b.slot_of_gid[g];
+        bv[s1] = av[s0];
+        bu[s1] = au[s0];
+        brf[s1] = arf[s0];
+        bst[s1] = ast[s0];
+        barr[s1] = aarr[s0];
+        blast[s1] = alast[s0]; // (positions among the core's synapses: only valid while the core's inbound synapses keep their order)
+        // what the time-step buffer / delay line holds for the steps to come: step t + 1 + k sits in row (t + 1 + k) % R
+        for (uint32_t k = 0; k < ra; k++)
+        {
+            const size_t from_at = static_cast<size_t>((t + 1 + k) % ra) * a.n_slots + s0;
+            if (!arv[from_at]) continue;
+            if (k >= rb) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: pending synaptic input does not fit the new chip's delay ring");
+            const size_t to_at = static_cast<size_t>((t + 1 + k) % rb) * b.n_slots + s1;
+            bring[to_at] = aring[from_at];
+            brv[to_at] = 1;
+        }
+        if (a.slot_model[s0] == SANAFE_SOMA_INPUT && b.slot_model[s1] == SANAFE_SOMA_INPUT) bpos[b.slot_aux[s1]] = apos[a.slot_aux[s0]];
+    }
+    sb.timesteps = t;
+    DEV(sanafe_hip_import_state(to->dev, &sb));
+    to->total_timesteps = from->total_timesteps;
+    to->total_messages_sent = from->total_messages_sent;
+    to->total_energy = from->total_energy;
+    to->total_sim_time = from->total_sim_time;
+    return 0;
+}
+
 extern "C" int sanafe_chip_attach_whole(sanafe_chip *chip, const sanafe_desc *desc)
 {
     if (!chip || !desc) return fail(SANAFE_HIP_ERR_INVALID, "null argument");

@@ -134,6 +134,7 @@ public:
     std::vector<py::object> nets; // networks loaded so far (load(net, overwrite=False) adds)
     py::object keepalive;         // lowered description (and whatever it borrows from)
     uintptr_t desc_address_{0};   // the description the chip was created from (kept alive by `keepalive`)
+    bool carry_state{false};      // the next adopt() moves the run-time state of the programmed chip into the new one
     bool whole_attached{false};   // tile-sharded chips: the whole-chip twin exists (sanafe_chip_attach_whole)
     sanafe_chip *h{nullptr};
     int device, n_ranks, rank;
@@ -160,10 +161,26 @@ public:
     void adopt(uintptr_t desc_address, const std::vector<std::tuple<std::string, int64_t, int64_t>> &groups, const py::array_t<uint8_t> &ls,
             const py::array_t<uint8_t> &lp, py::object keep)
     {
-        free_chip();
         sanafe_chip *out = nullptr;
-        const int rc = sanafe_chip_create(reinterpret_cast<const sanafe_desc *>(desc_address), device, n_ranks, rank, &out);
-        if (rc != 0) raise_last("sanafe_chip_create failed");
+        if (carry_state && h)
+        {
+            // load(net, overwrite=False) after timesteps have run: the programmed neurons' state moves into the new lowering
+            const int rc = sanafe_chip_create(reinterpret_cast<const sanafe_desc *>(desc_address), device, n_ranks, rank, &out);
+            if (rc != 0) raise_last("sanafe_chip_create failed");
+            if (sanafe_chip_carry_state(out, h) != 0)
+            {
+                sanafe_chip_destroy(out);
+                raise_last("sanafe_chip_carry_state failed");
+            }
+            free_chip();
+        }
+        else
+        {
+            free_chip();
+            const int rc = sanafe_chip_create(reinterpret_cast<const sanafe_desc *>(desc_address), device, n_ranks, rank, &out);
+            if (rc != 0) raise_last("sanafe_chip_create failed");
+        }
+        carry_state = false;
         h = out;
         keepalive = std::move(keep);
         desc_address_ = desc_address;
@@ -198,13 +215,7 @@ public:
         py::object to_lower = net;
         if (h && !overwrite)
         {
-            if (sanafe_chip_total_timesteps(h) > 0)
-            {
-                PyErr_SetString(PyExc_NotImplementedError,
-                        "UnsupportedError: load(net, overwrite=False) after timesteps have been simulated (the state of the programmed "
-                        "network cannot be carried into the re-lowered chip)");
-                throw py::error_already_set();
-            }
+            carry_state = sanafe_chip_total_timesteps(h) > 0; // (src/chip.cpp:129-138: every programmed unit keeps its state)
             // the groups of the new network are mapped after the programmed ones (ids, mapping order and per-core
             // offsets continue): re-lower the combination
             py::object merged = py::cast(std::make_unique<SpikingNetwork>(nets.front().cast<SpikingNetwork &>().name));

@@ -46,10 +46,13 @@ def c3_shape(S, delays):
 # delays=False is the headline's kernel variant (bench.py's recipe has no synaptic delays: deliver_kernel<7, false, ...>);
 # delays=True adds the six accumulator rows of a delay line that is actually used (6 x 513 accumulators per core do not fit
 # the 10-bit index of the dictionary words: format 0 with integer accumulators)
-@pytest.mark.parametrize("delays,force,fmt", [(False, None, 7), (False, "0", 0), (False, "4", 4), (False, "8", 8), (True, None, 0),
-                                              (True, "8", 8)])
+@pytest.mark.parametrize("delays,force,fmt", [(False, None, 7), (False, "7-delta", 7), (False, "0", 0), (False, "4", 4), (False, "8", 8),
+                                              (True, None, 0), (True, "8", 8)])
 def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt):
     arch, net, ref = c3_shape(S, delays)
+    if force == "7-delta":  # the headline format on 2-byte delta axon records instead of the source bitmaps
+        monkeypatch.setenv("SANAFE_AXON_BITMAP", "0")
+        force = None
     monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")  # C3's slices: 133 M axons / 8,192 slices -> 16,384 axons each
     if force is not None:
         monkeypatch.setenv("SANAFE_SYN_FORMAT", force)
@@ -61,6 +64,8 @@ def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt
     # the C3 delivery shape: every slice on compact records, >= 16 slices on each destination core, ~5 synapses per axon
     assert lay["n_compact_slices"] == info["n_slices"] >= 8 * 16 or (delays and fmt == 8)
     assert 4.5 < info["n_synapses"] / info["n_axons"] < 5.6
+    if fmt == 7:  # every destination core hears from nearly every neuron: source-bitmap axon records unless switched off
+        assert lay["n_bitmap_slices"] == (0 if os.environ.get("SANAFE_AXON_BITMAP") == "0" else info["n_slices"])
     fired_any = 0
     for t in range(STEPS):
         a = chip.run(1, "simple", record=True)

@@ -230,6 +230,33 @@ def test_random_configurations(S, seed, monkeypatch):
         assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-9, atol=1e-12)
 
 
+@pytest.mark.parametrize("net_kind", ["truenorth", "loihi_sparse"])
+def test_push_delivery_on_steps_with_few_spikes(S, monkeypatch, net_kind):
+    """C4-like activity (a fraction of a percent of the neurons fire): the delivery launch walks the fired neurons' out-synapse
+    lists (left per 64-slot chunk by the neuron launch; push or pull decided per step on the device from the events of
+    the step two before) instead of probing every inbound axon.  Same spikes, potentials, counters, energies and sim_time
+    as the oracle and as the pull path (SANAFE_PUSH=0); TrueNorth's first steps (every neuron fires in step 1) pull."""
+    if net_kind == "truenorth":
+        arch, net = nets.truenorth_net(S, n_tiles=32, neurons_per_core=256)
+        monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "2000")  # 8,192 events in step 1
+    else:
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
+        monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")  # (a chip this small would pull: one probe per axon is cheap)
+    chip, orc, tot = check_batched(S, arch, net, steps=40)  # one sim() call: the decision rides in the step pipeline
+    lay = chip.device_layout()
+    assert lay["push_enabled"] and 25 <= lay["pushed_steps"] <= (38 if net_kind == "truenorth" else 40), lay
+    monkeypatch.setenv("SANAFE_PUSH", "0")
+    pull = S.SpikingChip(arch)
+    pull.load(net)
+    assert not pull.device_layout()["push_enabled"]
+    a = pull.run(40, "simple")
+    for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
+        assert a[k] == tot[k], k
+    for k in DBL_KEYS:
+        assert a[k] == pytest.approx(tot[k], rel=1e-12, abs=1e-30), k
+    assert np.array_equal(pull.potentials(), chip.potentials())
+
+
 def test_taps_dendrites(S):
     """Row a21 on the GPU: `taps` dendrites -- per-tap charge through the delivery rows, the RC line advanced by
     taps_kernel, tap 0 handed to the soma through the time-step buffer."""

@@ -214,10 +214,49 @@ def test_second_load_adds_a_network(S):
     assert a["neurons_fired"] == b["neurons_fired"] > 0 and a["spikes"] == b["spikes"] > 0
     assert a["spike_trace"] == b["spike_trace"] and a["energy"] == b["energy"] and a["sim_time"] == b["sim_time"]
     assert np.array_equal(chip.potentials(), ref.potentials())
-    with pytest.raises(NotImplementedError):
-        chip.load(net_b)  # timesteps have been simulated
     chip.load(net_b, overwrite=True)  # clear_hw + load: only the new network remains
     assert chip.n_neurons == 80 and chip.total_timesteps == 0
+
+
+def test_load_without_overwrite_after_timesteps_keeps_the_state(S):
+    """load(net, overwrite=False) on a chip that has already simulated (src/chip.cpp:129-138): the new neurons are mapped next
+    to the programmed ones and every programmed unit keeps its state.  The combined network is lowered again and the
+    programmed neurons' potentials, pending synaptic input and the step counter move into the new chip.  Two networks
+    without edges between them evolve independently, so the chip must equal: network A alone for 12 + 13 steps, network B
+    alone for 13 steps.  (TrueNorth somas: the built-in LIF refuses a first update at a timestep > 1, src/models.cpp:508-511.)"""
+    def build(name, n, core_idx, seed, arch):
+        rng = np.random.default_rng(seed)
+        net = S.Network(name)
+        g = net.create_neuron_group(name, n, {"reset": 0, "leak": 1}, "core_synapses", "core_dendrites", False, True, "core_soma")
+        g.set_attribute_column("threshold", rng.integers(5, 30, size=n).astype(np.float64), integer=True)
+        g.set_attribute_column("bias", np.where(rng.random(n) < 0.4, rng.integers(2, 7, size=n), 0).astype(np.float64), integer=True)
+        src = np.repeat(np.arange(n, dtype=np.int64), 6)
+        dst = rng.integers(0, n, size=6 * n).astype(np.int64)
+        net.add_edges(src, dst, rng.integers(1, 5, size=6 * n).astype(np.float64), "core_synapses")
+        cores = arch.cores()
+        half = n // 2
+        g.map_to_core(cores[core_idx], 0, half)
+        g.map_to_core(cores[core_idx + 1], half, n)
+        return net
+
+    arch = S.presets.truenorth(n_tiles=8, width=4, height=2)
+    chip = S.SpikingChip(arch)
+    chip.load(build("a", 200, 0, 1, arch))
+    first = chip.sim(12, timing_model="simple")
+    chip.load(build("b", 150, 3, 2, arch))  # overwrite=False: the programmed neurons keep their state
+    assert chip.n_neurons == 350 and chip.total_timesteps == 12
+    second = chip.sim(13, timing_model="simple")
+    assert second["timestep_start"] == 13
+    alone_a, alone_b = S.SpikingChip(arch), S.SpikingChip(arch)
+    alone_a.load(build("a", 200, 0, 1, arch))
+    alone_b.load(build("b", 150, 3, 2, arch))
+    a1, a2 = alone_a.sim(12, timing_model="simple"), alone_a.sim(13, timing_model="simple")
+    b2 = alone_b.sim(13, timing_model="simple")
+    assert first["neurons_fired"] == a1["neurons_fired"] > 0
+    assert second["neurons_fired"] == a2["neurons_fired"] + b2["neurons_fired"] and b2["neurons_fired"] > 0
+    assert second["spikes"] == a2["spikes"] + b2["spikes"]
+    v = chip.potentials()
+    assert np.array_equal(v[:200], alone_a.potentials()) and np.array_equal(v[200:], alone_b.potentials())
 
 
 def test_sim_releases_the_gil_and_polls_signals(S):
