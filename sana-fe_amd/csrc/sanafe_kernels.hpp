@@ -879,7 +879,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     {
         // ---- few spikes: push the fired neurons' out-synapses instead of probing every inbound axon (see DevImage) ----
         const uint32_t buf = (uint32_t) (done % 3);
-        if (st.push_count[buf] != 0u) // the same decision in every workgroup and in reduce_l1
+        if (__builtin_nontemporal_load(&st.push_count[buf]) != 0u) // the same decision in every workgroup and in reduce_l1
         {
             const size_t row = (size_t) ((done + 2) % (long long) im.ring_slots) * im.n_slots; // (no synaptic delays on push chips)
             push_deliver(st.push_nfired + (size_t) buf * im.push_cap, st.push_list + (size_t) buf * im.push_cap * WAVE, im.push_ptr, im.push_syn,
@@ -1193,6 +1193,17 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         // Phase B: the words of the dense chunks of the run, streamed in one go.  Phase C: chunks with few spiking axons
         // go through the gather path.
         constexpr uint32_t NW = BLOCK / WAVE;
+        // bitmap records: the two words of a lane for the NEXT run are loaded while this run streams (pf_*)
+        auto bitmap_load = [&](uint32_t r, uint32_t &src_word, uint32_t &spk_word) {
+            const uint32_t rr = r < n_ax ? r : 0u; // (past the end: any valid run, the values are not used)
+            const uint32_t n_here = min(run_len, (n_ax - rr + WAVE_CHUNK - 1u) / WAVE_CHUNK);
+            const bool have = (uint32_t) lane < n_here * 8u;
+            const uint32_t w = (rr / WAVE_CHUNK) * 8u + (uint32_t) lane;
+            src_word = have ? reinterpret_cast<const uint32_t *>(rec)[w] : 0u;
+            spk_word = have ? bits[(uint32_t) a_beg + w] : 0u;
+        };
+        uint32_t pf_src = 0, pf_spk = 0;
+        if (BITMAP_RECORDS && bitmap && n_ax > 0) bitmap_load((uint32_t) wave * run_len * WAVE_CHUNK, pf_src, pf_spk);
         for (uint32_t r0 = (uint32_t) wave * run_len * WAVE_CHUNK; r0 < n_ax; r0 += NW * run_len * WAVE_CHUNK)
         {
             const uint32_t ci0 = r0 / WAVE_CHUNK;
@@ -1289,12 +1300,15 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             uint32_t before_bm = 0;                  // bitmap records: axons of the run before its first dense chunk
             // bitmap records: this lane's source word, its spiking axons, the axons of the run before it (phase C loads them
             // again rather than keeping three registers alive across the stream)
-            auto bitmap_words = [&](uint32_t &bm_src, uint32_t &bm_f, uint32_t &bm_excl, uint32_t &fincl) {
+            auto bitmap_words = [&](uint32_t &bm_src, uint32_t &bm_f, uint32_t &bm_excl, uint32_t &fincl, bool prefetched) {
                 const uint32_t n_here = min(run_len, (n_ax - r0 + WAVE_CHUNK - 1u) / WAVE_CHUNK);
-                const bool have = (uint32_t) lane < n_here * 8u;
-                const uint32_t *srcw = reinterpret_cast<const uint32_t *>(rec) + (size_t) ci0 * 8u;
-                bm_src = have ? srcw[lane] : 0u;
-                const uint32_t spk = have ? bits[(uint32_t) a_beg + ci0 * 8u + (uint32_t) lane] : 0u;
+                uint32_t spk;
+                if (prefetched)
+                {
+                    bm_src = pf_src;
+                    spk = pf_spk;
+                }
+                else bitmap_load(r0, bm_src, spk);
                 bm_f = spk & bm_src;
                 const uint32_t cnt = (uint32_t) __popc(bm_src);
                 bm_excl = wave_inclusive_scan(cnt) - cnt;
@@ -1308,7 +1322,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 //      word per lane, a run = 8 windows = the 64 lanes.  "Which axons spiked" is ONE AND of two coalesced
                 //      loads -- the slice's source bitmap (bit = this core has an axon from that neuron) and the global spike
                 //      bitmap at the same position -- instead of a record decode, a prefix sum and a random probe per axon.
-                const uint32_t n_here = bitmap_words(bm_src, bm_f, bm_excl, fincl);
+                const uint32_t n_here = bitmap_words(bm_src, bm_f, bm_excl, fincl, true);
+                bitmap_load(r0 + NW * run_len * WAVE_CHUNK, pf_src, pf_spk); // the next run's, in flight during the stream
                 stream_msgs += (uint32_t) __popc(bm_f);
                 // per chunk (8 lanes): spiking axons -> stream (many), gather (few) or nothing
 #pragma unroll
@@ -1559,7 +1574,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
             if (BITMAP_RECORDS && bitmap && gather_mask != 0u) // wave-uniform
             {
             uint32_t bm_src, bm_f, bm_excl, fincl_unused;
-            bitmap_words(bm_src, bm_f, bm_excl, fincl_unused);
+            bitmap_words(bm_src, bm_f, bm_excl, fincl_unused, false);
             while (gather_mask != 0u)
             {
                 // bitmap records: a window with fewer than STREAM_MIN_ACTIVE_LANES spiking axons.  The whole wave takes them
