@@ -503,9 +503,9 @@ def main():
         #     bitmap, each read once when every chunk is streamed (an upper bound when few axons spike), + one 17-byte
         #     write-back per neuron; neuron launch = per-slot state read + written, + 40 B per fired neuron.  DESIGN.md 5
         #     states the per-unit figures.  achieved = these bytes / the HIP-event-timed launch duration of THIS run.
-        lay = (C.c_uint64 * 8)()
+        lay = (C.c_uint64 * 9)()
         H.sanafe_hip_layout_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        if H.sanafe_hip_layout_bytes(dev, lay, 8) != 0:
+        if H.sanafe_hip_layout_bytes(dev, lay, 9) != 0:
             raise RuntimeError(H.sanafe_hip_last_error().decode())
         lay = [int(x) for x in lay]
         design_deliver = float(sum(lay[0:5])) + 17.0 * upd
@@ -524,6 +524,9 @@ def main():
                 "algorithmic_bytes_per_launch": design_deliver, "avg_launch_ms": dm.value,
                 "algorithmic_bytes_parts": {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
                                             "slice_descriptors": lay[3], "spike_bitmap": lay[4], "write_back": 17.0 * upd},
+                # bitmap axon records keep one synapse-count byte per axon that only the gather path reads (windows with
+                # fewer than 8 spiking axons): NOT part of algorithmic_bytes_per_launch
+                "axon_record_bytes_read_by_gather_path_only": lay[8],
                 "units_per_launch": {"synaptic_events": ev, "messages": msgs, "neurons_updated": upd, "neurons_fired": fired,
                                      "synapses_streamed": int(info["n_synapses"]), "axons_probed": int(info["n_axons"])},
                 "contract_model_bytes_per_launch": contract_deliver,

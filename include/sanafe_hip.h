@@ -239,10 +239,13 @@ int sanafe_hip_get_acc_shift(sanafe_hip_chip *chip);
  * 256-slot windows + one synapse-count byte per axon; "which axons spiked" is an AND with the spike bitmap).
  * SANAFE_AXON_BITMAP=0 keeps the 2-byte delta records (tests, A/B runs). */
 int sanafe_hip_get_bitmap_slices(sanafe_hip_chip *chip);
-/* Push delivery (steps with few spikes walk the fired neurons' out-synapses instead of probing every inbound axon of
- * the chip -- same result, chosen per step on the device from the events the step's spikes cause): enabled = the chip
- * qualifies (integer weights, no synaptic delays / last-event cores / taps / host units / lost charge, one latency class
- * per core, one GPU; SANAFE_PUSH=0 switches it off), pushed_steps = steps delivered that way since create. */
+/* Push delivery (the neuron launch of a step with few spikes delivers them itself, walking the fired neurons' out-synapses,
+ * and the delivery launch -- one probe per inbound axon of the chip whatever the activity -- returns at once; same result,
+ * chosen per step on the device from the events of an earlier step): enabled = 1 when the chip qualifies (integer weights, no
+ * synaptic delays / last-event cores / taps / host units / lost charge, one latency class per core, one GPU, ring_slots >= 2;
+ * SANAFE_PUSH=0 switches it off), 2 when the chip is push-ONLY (at most one out-synapse per neuron on average,
+ * SANAFE_PUSH_ONLY_DEGREE / SANAFE_PUSH_ONLY=0|1: every step is pushed, one launch per step); pushed_steps = steps delivered
+ * that way since create. */
 int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t *pushed_steps);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.
@@ -250,8 +253,11 @@ int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t 
  *   [4] global spike bitmap   -- one delivery launch reads [0..4] once when every chunk is streamed, less when
  *       few axons spike (gather path), plus 8 + 8 + 1 bytes per post-synaptic neuron and delay value it touches;
  *   [5] / [6] bytes the neuron launch reads / writes per step for the per-slot state (all mapped neurons)
- *   [7] bytes read per FIRED neuron on top (static downstream totals of its spike). */
-#define SANAFE_HIP_LAYOUT_FIELDS 8
+ *   [7] bytes read per FIRED neuron on top (static downstream totals of its spike);
+ *   [8] part of the axon-record array that a launch which streams every chunk does NOT read: the one synapse-count byte
+ *       per axon behind the bitmap records (slice mode 2), read only for 256-slot windows with so few spiking axons that
+ *       they take the gather path.  [1] excludes it. */
+#define SANAFE_HIP_LAYOUT_FIELDS 9
 int sanafe_hip_layout_bytes(sanafe_hip_chip *chip, uint64_t *out, int n);
 
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)

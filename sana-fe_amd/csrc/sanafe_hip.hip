@@ -364,12 +364,13 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
 {
     DevImage &im = c->im;
     im.push_cap = 0;
+    im.push_always = 0;
     if (std::getenv("SANAFE_PUSH") != nullptr && std::atoi(std::getenv("SANAFE_PUSH")) == 0) return 0; // tests / A-B runs
     // (the integer formats whose kernels have a PUSH instantiation: 7, and 0 / 3 on integer accumulators)
     const bool integer_weights = c->syn_format == 7 || ((c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0);
     if (!integer_weights || h.n_global_slots != h.n_slots || c->has_delay || im.has_last || h.n_taps != 0 || h.n_ext != 0 ||
-            h.n_synapses == 0 || h.n_synapses > (64ull << 20) || h.ax_lat_class == nullptr)
-        return 0;
+            h.n_synapses == 0 || h.n_synapses > (64ull << 20) || h.ax_lat_class == nullptr || h.ring_slots < 2)
+        return 0; // (two rows of the time-step buffer: the neuron launch adds to the next step's row while it reads this step's)
     for (uint32_t g = 0; g < h.n_slots; g++)
         if ((h.slot_cls[g] & 7u) == SANAFE_SOMA_HOST) return 0; // their spikes are set after the neuron launch
     for (uint64_t k = 0; k < h.n_synapses; k++)
@@ -412,12 +413,19 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     TRY(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_ain_lat));
     TRY(upload(c, ev_lat.data(), ev_lat.size(), &im.core_event_lat));
     im.push_cap = h.n_slots / WAVE;
-    // a pushed event costs three atomics; the pull path one probe per inbound axon of the chip, whatever the activity
+    // Push-only chips: a pushed event costs a few global atomics, a pull launch one probe per inbound axon whatever the
+    // activity.  With at most SANAFE_PUSH_ONLY_DEGREE out-synapses per neuron on average the worst step (every neuron fires)
+    // pushes in about the time of one pull launch, so the chip runs ONE launch per step and never decides anything.
+    {
+        double degree = 1.0;
+        if (const char *env = std::getenv("SANAFE_PUSH_ONLY_DEGREE")) degree = std::atof(env);
+        im.push_always = (double) h.n_synapses <= degree * (double) h.n_slots ? 1u : 0u;
+        if (const char *env = std::getenv("SANAFE_PUSH_ONLY")) im.push_always = std::atoi(env) != 0 ? 1u : 0u;
+    }
+    // a pushed event costs three atomics inside the neuron launch; the pull path one probe per inbound axon of the chip, whatever the activity
     im.push_max_events = (uint32_t) std::min<uint64_t>(16384, std::max<uint64_t>(256, h.n_axons / 128));
     if (const char *env = std::getenv("SANAFE_PUSH_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0L, std::atol(env));
     TRY(dalloc(c, 8, &c->st.push_count)); // [0..2] decisions (0: pull), [6] steps delivered by the push path
-    TRY(dalloc(c, 3 * (size_t) im.push_cap, &c->st.push_nfired));
-    TRY(dalloc(c, 3 * (size_t) im.push_cap * WAVE, &c->st.push_list));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     return 0;
 }
@@ -892,7 +900,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         std::vector<uint8_t> mode(h.n_slices, 0), slat(h.n_slices, 0);
         std::vector<uint32_t> chunk0(h.n_slices, 0);
         std::vector<uint64_t> n_slice_chunks(h.n_slices, 0);
-        uint64_t n_chunks = 0, n_bytes = 0;
+        uint64_t n_chunks = 0, n_bytes = 0, n_gather_only = 0;
         bool any_exact = false;
         bool any_last_cores = false;
         for (uint32_t g = 0; g < h.n_slots && !any_last_cores; g++)
@@ -948,6 +956,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             n_slice_chunks[sl] = (mode[sl] == 2) ? (uint64_t) (h.ax_pre[h.slice_axon_end[sl] - 1] >> 8) - (h.ax_pre[h.slice_axon_beg[sl]] >> 8) + 1ull
                                                  : (n + WAVE_CHUNK - 1) / WAVE_CHUNK;
             n_bytes += (((mode[sl] == 2) ? n_slice_chunks[sl] * 32ull + n : n * (mode[sl] ? 2ull : 8ull)) + 15ull) & ~15ull;
+            if (mode[sl] == 2) n_gather_only += n; // the synapse-count bytes: read for windows on the gather path only
             chunk0[sl] = (uint32_t) n_chunks;
             n_chunks += n_slice_chunks[sl] + 1; // + end entry: first synapse after the slice
             if (n_chunks >= (1ull << 32)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "too many axon chunks"));
@@ -1169,7 +1178,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
         c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : dict16 ? 2ull : 4ull);
         // (format 8: build_ordered below replaces [0] with the bytes of the per-accumulator lists)
-        c->layout_bytes[1] = n_bytes;
+        c->layout_bytes[1] = n_bytes - n_gather_only;
+        c->layout_bytes[8] = n_gather_only;
         c->layout_bytes[2] = n_chunks * 8ull;
         c->layout_bytes[3] = (uint64_t) h.n_slices * sizeof(SliceDesc);
         c->layout_bytes[4] = h.n_global_slots / 8;
@@ -1243,7 +1253,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // (+ zero words past the end: the last 256-slot window of bitmap axon records, the bit padding entries of the ordered layout probe)
     TRYC(dalloc(c, h.n_global_slots / 32 + 16, &st.bits_global));
     st.bits_local = st.bits_global + h.slot_offset / 32;
-    TRYC(dalloc(c, 2 * (size_t) im.n_wgs, &st.wg_part));
+    TRYC(dalloc(c, 2 * (size_t) im.n_wgs * PARTS_PER_WG, &st.wg_part));
     TRYC(dalloc(c, 2 * (size_t) h.n_slices, &st.slice_proc));
     TRYC(dalloc(c, 2 * (size_t) im.n_groups, &st.group_part));
     st.delay_log = nullptr;
@@ -1303,7 +1313,6 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
     // first launch.
     st.push_count = st.push_core_cnt = nullptr;
-    st.push_nfired = st.push_list = nullptr;
     TRYC(build_push(c, h)); // (before the kernel is picked: chips with push tables run the PUSH instantiations)
     if (c->syn_format == 8)
     {
@@ -1469,6 +1478,9 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     const size_t rslot = (size_t) (sa.t % c->im.ring_slots);
     sa.ring = c->st.ring + rslot * c->im.n_slots;
     sa.rvalid = c->st.ring_valid + rslot * c->im.n_slots;
+    const size_t nslot = (size_t) ((sa.t + 1) % c->im.ring_slots);
+    sa.ring_next = c->st.ring + nslot * c->im.n_slots;
+    sa.rvalid_next = c->st.ring_valid + nslot * c->im.n_slots;
     if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
     if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
     const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
@@ -1488,6 +1500,7 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 // Delivers the slices [first, first + count) of the launch order.
 static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
+    if (c->im.push_cap != 0u && c->im.push_always != 0u) return 0; // the neuron launch delivered the step's spikes itself
     if (c->syn_format == 8)
     {
         // ordered delivery: one launch for the whole chip -- every wavefront folds an accumulator group, then walks
@@ -1632,7 +1645,7 @@ extern "C" int sanafe_hip_get_acc_shift(sanafe_hip_chip *c)
 extern "C" int sanafe_hip_get_push_info(sanafe_hip_chip *c, uint32_t *enabled, uint32_t *pushed_steps)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
-    if (enabled) *enabled = c->im.push_cap != 0u ? 1u : 0u;
+    if (enabled) *enabled = c->im.push_cap != 0u ? (c->im.push_always != 0u ? 2u : 1u) : 0u;
     if (pushed_steps)
     {
         *pushed_steps = 0;
@@ -1917,13 +1930,15 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
     const size_t last_parity = (size_t) ((c->t_host > 0 ? c->t_host - 1 : 0) & 1); // the step launched last
     if (gen_sum) // as level 1 of the step reduction forms it
     {
-        std::vector<WgPart> wp(std::max<uint32_t>(1, c->im.n_wgs));
-        TRY(d2h(c, wp.data(), c->st.wg_part + last_parity * c->im.n_wgs, c->im.n_wgs));
+        const size_t n_parts = (size_t) c->im.n_wgs * PARTS_PER_WG;
+        std::vector<WgPart> wp(std::max<size_t>(1, n_parts));
+        TRY(d2h(c, wp.data(), c->st.wg_part + last_parity * n_parts, n_parts));
         for (uint32_t k = 0; k < c->im.n_cores; k++)
         {
             double lat = 0.0;
             long long packets = 0;
-            for (uint32_t w = c->h_core_wg_beg[k]; w < c->h_core_wg_beg[k + 1]; w++) lat += wp[w].lat, packets += wp[w].packets;
+            for (size_t w = (size_t) c->h_core_wg_beg[k] * PARTS_PER_WG; w < (size_t) c->h_core_wg_beg[k + 1] * PARTS_PER_WG; w++)
+                lat += wp[w].lat, packets += wp[w].packets;
             gen_sum[k] = lat + (double) packets * c->h_core_out_lat[k];
         }
     }

@@ -5,6 +5,7 @@
 
 constexpr int WAVE = 64;
 constexpr int NEURON_BLOCK = 256;   // 4 wavefronts = up to 4 consecutive 64-slot chunks of ONE simulated core
+constexpr int PARTS_PER_WG = NEURON_BLOCK / WAVE; // step partials: one per wavefront of a neuron workgroup (WgPart)
 constexpr int DELIVER_BLOCK = 256;
 constexpr int AX_PER_THREAD = 4;    // axon records per lane: one 8-byte (compact) or two 16-byte (wide) loads
 constexpr int REDUCE_BLOCK = 256;
@@ -13,6 +14,13 @@ constexpr uint32_t COST_LDS_MAX = 64;  // cost classes staged in LDS (4 KiB)
 
 // One neuron workgroup: up to 4 chunks of one core (a 256-neuron TrueNorth core is one workgroup, a 1024-neuron
 // Loihi core four).  One 16-byte scalar load tells the workgroup everything it needs before its slot loads.
+#ifndef SANAFE_NEURON_SGPRS
+#define SANAFE_NEURON_SGPRS 102 // (80 made the kernel reload kernel arguments a dozen times before its first vector load: +0.8 us per launch on the 1 M neuron chip)
+#endif
+#ifndef SANAFE_NEURON_ATTR
+// the uniform TrueNorth instantiation fits 64 registers without spilling: 8 wavefronts per SIMD instead of 6 (+4 % on C4)
+#define SANAFE_NEURON_ATTR __attribute__((amdgpu_waves_per_eu((UNI && MODEL == SANAFE_SOMA_TRUENORTH) ? 8 : 6, 8)))
+#endif
 struct WgDesc
 {
     uint32_t slot0;   // first (local) slot
@@ -20,7 +28,7 @@ struct WgDesc
     uint32_t nchunks; // 1..4
     uint32_t pad;
 };
-// Partial sums of one neuron workgroup (one writer), by step parity.
+// Partial sums of one WAVEFRONT of a neuron workgroup (one writer), by step parity: PARTS_PER_WG per workgroup.
 struct WgPart
 {
     double e_soma, e_dend, e_syn, e_net, lat;
@@ -135,16 +143,21 @@ struct DevImage
     int syn_format;               // 0 .. 4, 6, 7 as above
     int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
-    // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): every wavefront of the neuron
-    // launch leaves the fired neurons of its 64-slot chunk in the chunk's own list segment (no atomics), and when activity is
-    // low the delivery launch walks the fired neurons' static out-synapse lists instead of probing every inbound axon of
-    // the chip (deliver_kernel).  Which path a step takes is decided on the device from the synaptic events of the step
-    // two before it (reduce_l2 leaves the decision for the delivery launch and for reduce_l1 of that step).
+    // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): the neuron launch delivers the
+    // spikes itself -- the wavefront that updated a 64-slot chunk walks the static out-synapse lists of the neurons that fired
+    // and adds their weights to the NEXT step's row of the time-step buffer (push chips keep two rows, so no wavefront of the
+    // launch still reads what another one adds to) -- and the delivery launch of the step, which would probe every inbound
+    // axon of the chip, returns at once.  Which path a step takes is decided on the device from the synaptic events of the
+    // step THREE before it (reduce_l2 of that step rides in the previous neuron launch and leaves one word that the neuron
+    // launch, the delivery launch and reduce_l1 of the step all read).
     // Only built for chips where the result cannot depend on the order of the additions and the per-core message costs are
     // integers times a constant: integer weights, no synaptic delays / last-event cores / taps / host units, one latency
-    // class per core, one GPU.  push_cap == 0: not built.
-    uint32_t push_cap;            // 0: not built; else the number of 64-slot neuron chunks (one list segment each)
-    uint32_t push_max_events;     // a step is pushed when the step TWO before it caused at most this many synaptic events
+    // class per core, one GPU, ring_slots >= 2.  push_cap == 0: not built.
+    uint32_t push_cap;            // 0: not built; else the number of 64-slot neuron chunks
+    uint32_t push_always;         // 1: every step is pushed and the chip has NO delivery launch (chips with so few synapses per
+                                  // neuron that even a step in which every neuron fires costs about what one probe of all
+                                  // inbound axons costs: C4 has one synapse per neuron)
+    uint32_t push_max_events;     // a step is pushed when the step THREE before it caused at most this many synaptic events
                                   // (the prediction only picks the faster path: both paths are exact for any activity)
     const uint32_t *push_ptr;     // [n_slots + 1] out-synapses of each neuron
     const struct PushEntry *push_syn; // post slot, destination core | first-synapse-of-its-axon flag, weight
@@ -192,7 +205,7 @@ struct PendStep
 {
     int valid;          // 0: nothing to do
     int simple_timing, record, parity;
-    int push_buf;        // step number % 3: the push-delivery buffers of that step
+    int push_buf;        // step number % 3: the push decision word and per-core counters of that step
     long long rec_index; // record slot of that step
 };
 
@@ -210,7 +223,7 @@ struct DevState
     uint32_t *ring_last;   // [n_slots], SANAFE_IN_LAST cores: 1 + position (in the core's synapses) of the last event
     uint32_t *bits_local;  // [n_slots/32]; multi-GPU: this chip's window INSIDE bits_global
     uint32_t *bits_global; // [n_global_slots/32] (== bits_local on one GPU)
-    WgPart *wg_part;       // [2][n_wgs], by step parity
+    WgPart *wg_part;       // [2][n_wgs][PARTS_PER_WG], by step parity
     double *slice_proc;    // [2][n_slices], by step parity: processing-delay sum of each delivery slice
     GroupPart *group_part; // [2][n_groups], by step parity
     long long *t;          // timesteps simulated so far
@@ -220,10 +233,8 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
-    // push delivery, triple-buffered by step number % 3
+    // push delivery, by step number % 3
     uint32_t *push_count;         // [0..2]: 1 = the step with that number % 3 is pushed; [6]: steps pushed so far (diagnostics)
-    uint8_t *push_nfired;         // [3][push_cap] fired neurons of each 64-slot chunk
-    uint8_t *push_list;           // [3][push_cap][64] their lanes (any order)
     uint32_t *push_core_cnt;      // [3][n_cores][2]: messages, events delivered to each core by the push path
     double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
@@ -302,7 +313,9 @@ struct StepArgs
     const int *ext_row;  // external stream values of this step, or NULL
     long long t;         // Timestep::timestep of this step (steps simulated before it + 1)
     int parity;          // (t - 1) & 1: which half of the partials this step writes
-    int push_buf;        // (t - 1) % 3: the push-delivery buffers this step fills (the launch zeroes buffer (push_buf + 1) % 3)
+    int push_buf;        // (t - 1) % 3: the push decision word and the per-core counters of this step
+    double *ring_next;   // the NEXT step's row of the time-step buffer (push chips: ring_slots >= 2), where pushed spikes land
+    uint8_t *rvalid_next;
 };
 
 // A chip whose neurons all carry the same class word (one soma model, one parameter set, one cost class, one input
@@ -336,22 +349,20 @@ struct UniformSoma
 // lanes whose neuron fired add (3) one 40-byte record of what the spike causes downstream.
 // ---------------------------------------------------------------------------------------
 template <int MODEL, bool UNI>
-__global__ void __launch_bounds__(NEURON_BLOCK) __attribute__((amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(NEURON_BLOCK) __attribute__((amdgpu_num_sgpr(SANAFE_NEURON_SGPRS))) SANAFE_NEURON_ATTR
 neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1, PendStep l2)
 {
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
     if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
-        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, sa.push_buf);
+        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, (sa.push_buf + 1) % 3);
         const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
         if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
         return;
     }
     __shared__ sanafe_hip_soma_class s_soma[UNI ? 1 : SOMA_LDS_MAX];
     __shared__ sanafe_hip_cost_class s_cost[UNI ? 1 : COST_LDS_MAX];
-    __shared__ double s_d[NEURON_BLOCK / WAVE][5];
-    __shared__ long long s_l[NEURON_BLOCK / WAVE][5];
     const uint32_t wg = blockIdx.x - im.n_reduce_wgs;
     uint32_t slot0, nchunks, nlive = WAVE, core = 0xffffffffu;
     if (UNI)
@@ -395,6 +406,12 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         if (MODEL != SANAFE_SOMA_TRUENORTH && im.any_refrac) rc_in = p_refrac[lane];
         if (!UNI && sa.ext_row != nullptr) ext_col = im.slot_ext[c0 + lane];
     }
+    // push or pull for this step: written by reduce_l2 in the PREVIOUS neuron launch; the delivery launch and reduce_l1 read
+    // the same word.  Loaded HERE, behind the per-slot loads: it is a dependent load (pointer, then word) that misses the
+    // scalar cache in the first wavefronts of a launch, and a wait for it placed before the vector loads -- where the compiler
+    // puts it when left alone -- costs every wavefront a memory round trip (4.5 us per launch on the 1 M neuron chip).
+    asm volatile("" ::: "memory");
+    const bool push_now = im.push_cap != 0u && (im.push_always != 0u || st.push_count[sa.push_buf] != 0u);
     if (!UNI)
     {
         // ---- class tables -> LDS, in flight together with the slot loads ----
@@ -610,12 +627,14 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         if (live && model != SANAFE_SOMA_HOST) st.status[c0 + lane] = (uint8_t) status;
         if (sa.stlog != nullptr && live) sa.stlog[c0 + lane] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
-        if (im.push_cap != 0u)
+        // push delivery (see DevImage::push_*): this step was decided to be one of few spikes -- the wavefront delivers its
+        // own neurons' spikes right here, into the NEXT step's row of the time-step buffer (push chips keep two rows)
+        uint32_t push_b = 0, push_e = 0;
+        const bool pushing = push_now && fired_mask != 0ull; // wave-uniform
+        if (pushing && status == 3)
         {
-            // push delivery: the fired lanes of this chunk, in the chunk's own list segment (no atomics, nothing to zero)
-            const size_t q = (size_t) sa.push_buf * im.push_cap + (c0 >> 6);
-            if (status == 3) st.push_list[q * WAVE + (uint32_t) __popcll(fired_mask & ((1ull << lane) - 1ull))] = (uint8_t) lane;
-            if (lane == 0) st.push_nfired[q] = (uint8_t) __popcll(fired_mask);
+            push_b = im.push_ptr[c0 + lane];
+            push_e = im.push_ptr[c0 + lane + 1];
         }
         if (lane == 0)
         {
@@ -684,38 +703,42 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
             }
         }
+        if (pushing)
+        {
+            // neuron by neuron, the lanes over its out-synapses (integer-valued weights: exact in any order)
+            uint32_t *cnt = st.push_core_cnt + (size_t) sa.push_buf * im.n_cores * 2u;
+            for (unsigned long long m = fired_mask; m != 0ull; m &= m - 1ull)
+            {
+                const int j = __ffsll((long long) m) - 1;
+                const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) push_b, j), ei = (uint32_t) __builtin_amdgcn_readlane((int) push_e, j);
+                for (uint32_t k = bi + lane; k < ei; k += WAVE)
+                {
+                    const PushEntry pe = im.push_syn[k];
+                    atomicAdd(&sa.ring_next[pe.post], pe.w);
+                    sa.rvalid_next[pe.post] = 1;
+                    const uint32_t pc = pe.core & 0x7fffffffu;
+                    atomicAdd(&cnt[pc * 2u + 1u], 1u);
+                    if (pe.core >> 31) atomicAdd(&cnt[pc * 2u], 1u);
+                }
+            }
+        }
     }
     if (lane == 0)
     {
-        s_d[wave][0] = e_soma;
-        s_d[wave][1] = e_dend;
-        s_d[wave][2] = e_syn;
-        s_d[wave][3] = e_net;
-        s_d[wave][4] = lat;
-        s_l[wave][0] = n_upd;
-        s_l[wave][1] = n_fire;
-        s_l[wave][2] = n_pack;
-        s_l[wave][3] = n_hops;
-        s_l[wave][4] = n_ev;
-    }
-    __syncthreads();
-    if (threadIdx.x < 10)
-    {
-        // ten lanes, one field each: the waves are combined in a fixed order (deterministic)
-        const int k = (int) threadIdx.x;
-        WgPart *out = st.wg_part + (size_t) sa.parity * im.n_wgs + wg;
-        if (k < 5)
-        {
-            double d = 0.0;
-            for (uint32_t w = 0; w < nchunks; w++) d += s_d[w][k];
-            reinterpret_cast<double *>(out)[k] = d;
-        }
-        else
-        {
-            long long l = 0;
-            for (uint32_t w = 0; w < nchunks; w++) l += s_l[w][k - 5];
-            reinterpret_cast<long long *>(out)[k] = l;
-        }
+        // every wavefront leaves its own partial (no LDS, no workgroup barrier: a wavefront retires as soon as its chunk is
+        // done); reduce_l1 adds a core's partials in a fixed order.  Wavefronts without a chunk write zeros.
+        WgPart part;
+        part.e_soma = e_soma;
+        part.e_dend = e_dend;
+        part.e_syn = e_syn;
+        part.e_net = e_net;
+        part.lat = lat;
+        part.updated = n_upd;
+        part.fired = n_fire;
+        part.packets = n_pack;
+        part.hops = n_hops;
+        part.events = n_ev;
+        st.wg_part[((size_t) sa.parity * im.n_wgs + wg) * PARTS_PER_WG + wave] = part;
     }
 }
 
@@ -788,53 +811,6 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 #endif
 }
 
-// Push delivery of one step (deliver_kernel<..., PUSH> when the step's decision word says so): one wavefront per 64-slot
-// neuron chunk, all of them -- most are empty -- and one lane per fired neuron of the chunk, walking that neuron's
-// out-synapses.  Kept out of line: the streaming kernel must not pay registers for it.
-// (arguments by value, in registers: a reference to the kernel's by-value image would be copied to the stack)
-__device__ __noinline__ void push_deliver(const uint8_t *nfired /* of this step's buffer */, const uint8_t *list, const uint32_t *push_ptr,
-        const PushEntry *push_syn, double *ring_row, uint8_t *valid_row, uint32_t *cnt, uint32_t push_cap, uint32_t block)
-{
-    const uint32_t gwave = (blockIdx.x * block + threadIdx.x) >> 6, n_waves = (gridDim.x * block) >> 6;
-    const uint32_t pl = threadIdx.x & (WAVE - 1);
-    // every wavefront takes `per` consecutive chunks (all wavefronts of the launch work: C4 has 4 chunks per wavefront);
-    // their fired counts come with ONE load, lane j holding chunk j's
-    const uint32_t per = min((uint32_t) WAVE, (push_cap + n_waves - 1u) / n_waves);
-    for (uint32_t q0 = gwave * per; q0 < push_cap; q0 += n_waves * per)
-    {
-        const uint32_t q = q0 + pl;
-        const uint32_t mine = (pl < per && q < push_cap) ? nfired[q] : 0u;
-        unsigned long long busy = __ballot(mine != 0u);
-        while (busy != 0ull) // chunks with fired neurons (a few per cent of them)
-        {
-            const uint32_t j = (uint32_t) __ffsll((long long) busy) - 1u;
-            busy &= busy - 1ull;
-            const uint32_t chunk = q0 + j, n_fired = (uint32_t) __builtin_amdgcn_readlane((int) mine, (int) j);
-            // the chunk's fired lanes and their synapse ranges, one lane each (one round trip for all of them)
-            uint32_t b = 0, e = 0;
-            if (pl < n_fired)
-            {
-                const uint32_t pre = chunk * WAVE + list[(size_t) chunk * WAVE + pl];
-                b = push_ptr[pre];
-                e = push_ptr[pre + 1];
-            }
-            for (uint32_t i = 0; i < n_fired; i++) // neuron by neuron, the lanes over its out-synapses
-            {
-                const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) b, (int) i), ei = (uint32_t) __builtin_amdgcn_readlane((int) e, (int) i);
-                for (uint32_t k = bi + pl; k < ei; k += WAVE)
-                {
-                    const PushEntry pe = push_syn[k];
-                    atomicAdd(&ring_row[pe.post], pe.w); // integers: exact in any order
-                    valid_row[pe.post] = 1;
-                    const uint32_t core = pe.core & 0x7fffffffu;
-                    atomicAdd(&cnt[core * 2u + 1u], 1u);
-                    if (pe.core >> 31) atomicAdd(&cnt[core * 2u], 1u);
-                }
-            }
-        }
-    }
-}
-
 // LAST: the chip has cores whose time-step buffer sits before the dendrite unit (SANAFE_IN_LAST): for those cores the
 // workgroup keeps, per post-synaptic neuron, the position of the LAST event in delivery order (LDS atomic max)
 // instead of a sum -- the buffer holds one pipeline result per neuron and later events overwrite earlier ones
@@ -877,15 +853,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 
     if constexpr (PUSH)
     {
-        // ---- few spikes: push the fired neurons' out-synapses instead of probing every inbound axon (see DevImage) ----
-        const uint32_t buf = (uint32_t) (done % 3);
-        if (__builtin_nontemporal_load(&st.push_count[buf]) != 0u) // the same decision in every workgroup and in reduce_l1
-        {
-            const size_t row = (size_t) ((done + 2) % (long long) im.ring_slots) * im.n_slots; // (no synaptic delays on push chips)
-            push_deliver(st.push_nfired + (size_t) buf * im.push_cap, st.push_list + (size_t) buf * im.push_cap * WAVE, im.push_ptr, im.push_syn,
-                    st.ring + row, st.ring_valid + row, st.push_core_cnt + (size_t) buf * im.n_cores * 2u, im.push_cap, BLOCK);
-            return;
-        }
+        // ---- few spikes: the neuron launch of this step pushed its spikes itself (neuron_kernel); nothing to deliver ----
+        if (st.push_count[(uint32_t) (done % 3)] != 0u) return; // the same decision in the neuron launch and in reduce_l1
     }
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // a scalar: chunk offsets and bases stay in SGPRs
@@ -1997,8 +1966,8 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
     long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
     if (c < im.n_cores)
     {
-        const WgPart *part = st.wg_part + (size_t) parity * im.n_wgs;
-        const uint32_t w0 = im.core_wg_beg[c], w1 = im.core_wg_beg[c + 1];
+        const WgPart *part = st.wg_part + (size_t) parity * im.n_wgs * PARTS_PER_WG;
+        const uint32_t w0 = im.core_wg_beg[c] * PARTS_PER_WG, w1 = im.core_wg_beg[c + 1] * PARTS_PER_WG;
         const uint32_t s0 = im.core_slice_beg[c], s1 = im.core_slice_beg[c + 1];
         const double out_lat = im.core_axon_out_latency[c];
         double lat = 0;
@@ -2020,7 +1989,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
         // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
         const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
         bool pushed = false;
-        if (im.push_cap != 0u) pushed = st.push_count[push_buf] != 0u; // the delivery launch of the step read the same word
+        if (im.push_cap != 0u) pushed = im.push_always != 0u || st.push_count[push_buf] != 0u; // the neuron and delivery launches of the step read the same word
         if (pushed)
         {
             // the push path counted this core's messages and events: integers times the core's constants
@@ -2151,7 +2120,7 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
             st.step_log[prev.rec_index % st.log_cap] = ts;
             *st.rec = prev.rec_index + 1;
         }
-        // push or pull for the step whose neuron launch this reduction rides in: few events two steps ago -> push
+        // push or pull for the step AFTER the one whose neuron launch this reduction rides in: few events three steps before it -> push
         if (im.push_cap != 0u && decide_buf >= 0) st.push_count[decide_buf] = (events <= (long long) im.push_max_events) ? 1u : 0u;
         if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;
@@ -2294,7 +2263,7 @@ __global__ void host_status_kernel(DevImage im, DevState st, uint32_t count, con
     const uint32_t g = slots[i];
     const uint8_t s = status[i];
     st.status[g] = s;
-    WgPart *cp = st.wg_part + (size_t) parity * im.n_wgs + im.core_wg_beg[core[i]];
+    WgPart *cp = st.wg_part + ((size_t) parity * im.n_wgs + im.core_wg_beg[core[i]]) * PARTS_PER_WG;
     if (!raw)
     {
         const sanafe_hip_cost_class &cc = im.cost_classes[(im.slot_cls[g] >> 6) & 1023u];
@@ -2325,7 +2294,7 @@ __global__ void host_core_costs_kernel(DevImage im, DevState st, uint32_t count,
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const sanafe_hip_host_core_costs k = costs[i];
-    WgPart *cp = st.wg_part + (size_t) parity * im.n_wgs + im.core_wg_beg[k.core];
+    WgPart *cp = st.wg_part + ((size_t) parity * im.n_wgs + im.core_wg_beg[k.core]) * PARTS_PER_WG;
     cp->e_syn += k.synapse_energy; // (one thread per core; the neuron launch of the step wrote the partial long before)
     cp->e_dend += k.dendrite_energy;
     cp->e_soma += k.soma_energy;

@@ -1187,7 +1187,9 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     }
     if (mc.soma_classes.empty()) mc.soma_classes.push_back(sanafe_hip_soma_class{});
     if (mc.cost_classes.empty()) mc.cost_classes.push_back(sanafe_hip_cost_class{});
-    mc.ring_slots = any_gated_delay ? 7 : any_delay_dendrite ? 6 : 1; // gated delay lines mature one step later
+    // gated delay lines mature one step later; chips without delays keep two rows of the time-step buffer (this step's and
+    // the next one's), so the device may deliver a quiet step's spikes from inside the neuron launch (DevImage: push delivery)
+    mc.ring_slots = any_gated_delay ? 7 : any_delay_dendrite ? 6 : 2;
     if (any_taps) mc.ring_slots = 8; // the delay field doubles as the tap index (<= 7): the image contract is field < ring_slots
 
     lap("neurons + slots");

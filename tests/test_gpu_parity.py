@@ -230,21 +230,27 @@ def test_random_configurations(S, seed, monkeypatch):
         assert np.allclose(chip.potentials(), orc.potentials(), rtol=1e-9, atol=1e-12)
 
 
-@pytest.mark.parametrize("net_kind", ["truenorth", "loihi_sparse"])
+@pytest.mark.parametrize("net_kind", ["truenorth_push_only", "truenorth", "loihi_sparse"])
 def test_push_delivery_on_steps_with_few_spikes(S, monkeypatch, net_kind):
-    """C4-like activity (a fraction of a percent of the neurons fire): the delivery launch walks the fired neurons' out-synapse
-    lists (left per 64-slot chunk by the neuron launch; push or pull decided per step on the device from the events of
-    the step two before) instead of probing every inbound axon.  Same spikes, potentials, counters, energies and sim_time
-    as the oracle and as the pull path (SANAFE_PUSH=0); TrueNorth's first steps (every neuron fires in step 1) pull."""
-    if net_kind == "truenorth":
+    """C4-like activity (a fraction of a percent of the neurons fire): the NEURON launch delivers the spikes itself -- the
+    wavefront of a 64-slot chunk walks the out-synapse lists of its fired neurons and adds to the next step's row of the
+    time-step buffer -- and the delivery launch, which probes every inbound axon, returns at once (push or pull decided per
+    step on the device from the events of the step three before), or is not launched at all on chips with at most one
+    synapse per neuron (push-only: TrueNorth's one edge per neuron).  Same spikes, potentials, counters, energies and sim_time
+    as the oracle and as the pull path (SANAFE_PUSH=0)."""
+    if net_kind.startswith("truenorth"):
         arch, net = nets.truenorth_net(S, n_tiles=32, neurons_per_core=256)
         monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "2000")  # 8,192 events in step 1
+        if net_kind == "truenorth":
+            monkeypatch.setenv("SANAFE_PUSH_ONLY", "0")  # decide per step: the first steps (every neuron fires in step 1) pull
     else:
         arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
         monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")  # (a chip this small would pull: one probe per axon is cheap)
     chip, orc, tot = check_batched(S, arch, net, steps=40)  # one sim() call: the decision rides in the step pipeline
     lay = chip.device_layout()
-    assert lay["push_enabled"] and 25 <= lay["pushed_steps"] <= (38 if net_kind == "truenorth" else 40), lay
+    assert lay["push_enabled"] and lay["push_only"] == (net_kind == "truenorth_push_only"), lay
+    lo, hi = {"truenorth_push_only": (40, 40), "truenorth": (25, 37), "loihi_sparse": (25, 40)}[net_kind]
+    assert lo <= lay["pushed_steps"] <= hi, lay
     monkeypatch.setenv("SANAFE_PUSH", "0")
     pull = S.SpikingChip(arch)
     pull.load(net)
