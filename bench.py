@@ -355,8 +355,8 @@ def collect_traffic_inline(args, n_launch_tail):
             d["fetch_bytes_corrected"] = 2.0 * 1024.0 * d["FETCH_SIZE_KiB_avg"]
             d["write_bytes"] = 1024.0 * d["WRITE_SIZE_KiB_avg"]
             d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected"] + d["write_bytes"]
-    if "deliver_kernel" not in res or "hbm_bytes_per_launch" not in res["deliver_kernel"]:
-        return None, "no deliver_kernel counter rows in the rocprofv3 output"
+    if not any("hbm_bytes_per_launch" in d for d in res.values()):
+        return None, "no neuron_kernel / deliver_kernel counter rows in the rocprofv3 output"
     return res, None
 
 
@@ -540,18 +540,32 @@ def main():
                 "whole_step": {"algorithmic_bytes": design_neuron + design_deliver,
                                "achieved_GBps": gbps(design_neuron + design_deliver, nm.value + dm.value + rm.value)}}
 
+    if roof is not None and roof["neuron_kernel"]["avg_launch_ms"] > roof["avg_launch_ms"]:
+        # The neuron launch dominates the step (C4: a push-only chip has no delivery launch at all; C2): the top-level
+        # fields describe THAT kernel, the delivery launch moves to a sub-block.
+        nk = roof.pop("neuron_kernel")
+        roof["deliver_kernel"] = {k: roof[k] for k in ("avg_launch_ms", "algorithmic_bytes_per_launch", "achieved", "frac",
+                                                       "contract_model_bytes_per_launch", "frac_contract_model",
+                                                       "algorithmic_bytes_parts")}
+        roof.update({"kernel": "neuron_kernel", "achieved": nk["achieved_GBps"], "frac": nk["frac"],
+                     "algorithmic_bytes_per_launch": nk["algorithmic_bytes_per_launch"], "avg_launch_ms": nk["avg_launch_ms"],
+                     "contract_model_bytes_per_launch": nk["contract_model_bytes_per_launch"],
+                     "frac_contract_model": nk["frac_contract_model"],
+                     "algorithmic_bytes_parts": {"per_slot_state_read": lay[5], "per_slot_state_written": lay[6],
+                                                 "per_fired_neuron": lay[7] * fired}})
+    dominant = roof["kernel"] if roof is not None else None
     if roof is not None:
         # (3) HBM bytes per launch from the PMC counters (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950,
         #     plus WRITE_SIZE; separate --pmc passes): collected by this very command in two rocprofv3 child runs
         #     (--traffic inline, the default), or -- marked as NOT from this run -- read from the newest stored
         #     profiles/*/summary.json of the same workload.
-        if pmc is not None:
-            roof["traffic"] = pmc["deliver_kernel"]["hbm_bytes_per_launch"]
+        if pmc is not None and "hbm_bytes_per_launch" in pmc.get(dominant, {}):
+            roof["traffic"] = pmc[dominant]["hbm_bytes_per_launch"]
             roof["traffic_from_this_run"] = True
             roof["traffic_source"] = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE child runs of this command "
                                       "(%.0f s), averaged over the last %d launches" % (t_pmc, args.timed_steps))
-            roof["traffic_counters"] = pmc["deliver_kernel"]
-            if "hbm_bytes_per_launch" in pmc.get("neuron_kernel", {}):
+            roof["traffic_counters"] = pmc[dominant]
+            if "neuron_kernel" in roof and "hbm_bytes_per_launch" in pmc.get("neuron_kernel", {}):
                 roof["neuron_kernel"]["traffic"] = pmc["neuron_kernel"]["hbm_bytes_per_launch"]
         elif args.traffic != "none":
             if pmc_error:
@@ -562,14 +576,14 @@ def main():
                 try:
                     with open(path) as f:
                         summ = json.load(f)
-                    if summ["bench_line"]["config"]["workload"] == workload and "hbm_bytes_per_launch" in summ["kernels"]["deliver_kernel"] \
+                    if summ["bench_line"]["config"]["workload"] == workload and "hbm_bytes_per_launch" in summ["kernels"][dominant] \
                             and summ.get("collected_unix", 0) > newest:
                         newest = summ.get("collected_unix", 0)
-                        roof["traffic"] = summ["kernels"]["deliver_kernel"]["hbm_bytes_per_launch"]
+                        roof["traffic"] = summ["kernels"][dominant]["hbm_bytes_per_launch"]
                         roof["traffic_source"] = "STORED, not from this run: " + os.path.relpath(path, ROOT)
                         roof["traffic_collected_utc"] = time.strftime("%Y-%m-%d %H:%M", time.gmtime(newest)) if newest > 0 else None
                         nk = summ["kernels"].get("neuron_kernel", {})
-                        if "hbm_bytes_per_launch" in nk:
+                        if "neuron_kernel" in roof and "hbm_bytes_per_launch" in nk:
                             roof["neuron_kernel"]["traffic"] = nk["hbm_bytes_per_launch"]
                 except (KeyError, TypeError, ValueError, OSError):
                     continue

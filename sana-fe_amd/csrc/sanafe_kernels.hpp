@@ -705,20 +705,41 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         }
         if (pushing)
         {
-            // neuron by neuron, the lanes over its out-synapses (integer-valued weights: exact in any order)
+            // neuron by neuron, the lanes over its out-synapses (integer-valued weights: exact in any order).  The per-core
+            // message / event counters are bumped once per RUN of lanes with the same destination core (a neuron's synapses
+            // lie core by core), not once per synapse: thousands of same-address atomics would serialise at ~2.5 ns each.
             uint32_t *cnt = st.push_core_cnt + (size_t) sa.push_buf * im.n_cores * 2u;
             for (unsigned long long m = fired_mask; m != 0ull; m &= m - 1ull)
             {
                 const int j = __ffsll((long long) m) - 1;
                 const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) push_b, j), ei = (uint32_t) __builtin_amdgcn_readlane((int) push_e, j);
-                for (uint32_t k = bi + lane; k < ei; k += WAVE)
+                for (uint32_t k0 = bi; k0 < ei; k0 += WAVE) // (wave-uniform bounds)
                 {
-                    const PushEntry pe = im.push_syn[k];
-                    atomicAdd(&sa.ring_next[pe.post], pe.w);
-                    sa.rvalid_next[pe.post] = 1;
-                    const uint32_t pc = pe.core & 0x7fffffffu;
-                    atomicAdd(&cnt[pc * 2u + 1u], 1u);
-                    if (pe.core >> 31) atomicAdd(&cnt[pc * 2u], 1u);
+                    const uint32_t k = k0 + lane;
+                    const bool act = k < ei; // lanes 0 .. n - 1
+                    uint32_t pc = 0xffffffffu;
+                    bool first = false;
+                    if (act)
+                    {
+                        const PushEntry pe = im.push_syn[k];
+                        atomicAdd(&sa.ring_next[pe.post], pe.w);
+                        sa.rvalid_next[pe.post] = 1;
+                        pc = pe.core & 0x7fffffffu;
+                        first = (pe.core >> 31) != 0u;
+                    }
+                    const uint32_t before = (uint32_t) __shfl_up((int) pc, 1, WAVE);
+                    const bool head = act && (lane == 0u || before != pc);
+                    const unsigned long long heads = __ballot(head), firsts = __ballot(first);
+                    if (head)
+                    {
+                        const unsigned long long later = heads & ~((2ull << lane) - 1ull); // (lane 63: the shift wraps to 0 - 1: no later head)
+                        const uint32_t n_act = min(ei - k0, (uint32_t) WAVE);
+                        const uint32_t end = (lane < 63u && later != 0ull) ? (uint32_t) __ffsll((long long) later) - 1u : n_act;
+                        const unsigned long long run = (end >= 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+                        atomicAdd(&cnt[pc * 2u + 1u], end - lane);
+                        const uint32_t n_msgs = (uint32_t) __popcll(firsts & run);
+                        if (n_msgs != 0u) atomicAdd(&cnt[pc * 2u], n_msgs);
+                    }
                 }
             }
         }
