@@ -782,7 +782,13 @@ constexpr uint32_t HEAD_WINDOW = 2048; // events covered by one 64-word head bit
 #define SANAFE_DELIVER_WAVES_PER_EU 5
 #endif
 #ifndef SANAFE_BITMAP_WAVES_PER_EU
-#define SANAFE_BITMAP_WAVES_PER_EU 5 // (bitmap axon records leave ~9 registers of headroom: 6 waves per SIMD spill 5 dwords)
+#define SANAFE_BITMAP_WAVES_PER_EU 6 // bitmap axon records need fewer registers: with 3 instead of 4 groups in flight per lane the
+                                     // kernel fits 80 (one spilled dword) and a sixth wavefront per SIMD hides more of the
+                                     // vector-issue stalls: +5 % on 1,024 x 256, +0..2 % on 512 x 512 (7 or 8 wavefronts spill
+                                     // 4-12 dwords and lose 3-8 %)
+#endif
+#ifndef SANAFE_BITMAP_STREAM_DEPTH
+#define SANAFE_BITMAP_STREAM_DEPTH 3
 #endif
 constexpr int STREAM_DEPTH = SANAFE_STREAM_DEPTH; // 16-byte groups per lane in flight in the stream path
 #ifndef SANAFE_STREAM_MIN_ACTIVE_LANES
@@ -893,7 +899,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     constexpr bool STREAMABLE = (SYN_FMT == 0 || SYN_FMT == 3 || SYN_FMT == 4 || DICT16); // stream layout, index-coded words
     constexpr uint32_t GROUP_WORDS = DICT16 ? 8u : 4u; // synapse words in one 16-byte group
     constexpr bool FP_WEIGHTS = (SYN_FMT == 2 || SYN_FMT == 4);
-    constexpr int SDEPTH = (SYN_FMT == 4) ? 2 : STREAM_DEPTH; // fp64 weights triple the registers of a group in flight
+    constexpr int SDEPTH = (SYN_FMT == 4) ? 2 : BITMAP ? SANAFE_BITMAP_STREAM_DEPTH : STREAM_DEPTH; // fp64 weights triple the registers of a group in flight
     const uint32_t RS = STREAMABLE ? npad + 1u : npad;
     const long long t = done + 1;
     const unsigned long long a_beg = sd.a_beg;

@@ -40,9 +40,9 @@ def _steady_state_waits(fn, depth_in_flight):
     return [int(x) for l in region for x in re.findall(r"s_waitcnt vmcnt\((\d+)\)", l)]
 
 
-@pytest.mark.parametrize("fmt,depth_in_flight", [(7, 4), (6, 4), (0, 4), (3, 4), (4, 2)])
-def test_stream_loads_are_counted(isa, fmt, depth_in_flight):
-    fn = _function(isa, "deliver_kernelILi%dELb0ELb0ELb0ELi256E" % fmt)
+@pytest.mark.parametrize("fmt,depth_in_flight,bitmap", [(7, 4, 0), (7, 3, 1), (6, 4, 0), (0, 4, 0), (3, 4, 0), (4, 2, 0)])
+def test_stream_loads_are_counted(isa, fmt, depth_in_flight, bitmap):
+    fn = _function(isa, "deliver_kernelILi%dELb0ELb0ELb0ELi256ELb%dELb0E" % (fmt, bitmap))
     waits = _steady_state_waits(fn, depth_in_flight)
     assert waits, "the stream loop of deliver_kernel<%d> waits for no load at all?" % fmt
     assert min(waits) >= depth_in_flight - 1, (fmt, waits)
