@@ -894,8 +894,10 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     try
     {
         // SANAFE_TARGET_SLICES: delivery work items to aim for (tests use it to force multi-slice cores)
-        uint32_t target_slices = 8192; // several times the ~1,300 resident workgroups (no tail), few enough that a big core's
-                                       // write-back is shared by 16 slices, not 32 (C3: 8 k 0.303 ms, 16 k 0.308 ms, 4 k 0.306 ms)
+        uint32_t target_slices = 6144; // 4 x the 1,536 delivery workgroups resident at six wavefronts per SIMD (bitmap records; no
+                                       // partial last round), few enough that a big core's write-back is shared by 6-12 slices
+                                       // (C3 1,024 x 256: 3,072 / 6,144 slices 0.281 ms, 4,096 0.294, 8,192 0.308; delta records
+                                       // and formats 0 / 6: 6,144 is 1-5 % faster than 8,192 as well)
         if (const char *env = std::getenv("SANAFE_TARGET_SLICES")) target_slices = static_cast<uint32_t>(std::max(1L, std::atol(env)));
         uint32_t min_slice_axons = 1024; // one 256-axon chunk per wavefront: small chips still spread over many CUs
         if (const char *env = std::getenv("SANAFE_MIN_SLICE_AXONS")) min_slice_axons = static_cast<uint32_t>(std::max(4L, std::atol(env)));
