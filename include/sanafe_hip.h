@@ -108,7 +108,8 @@ typedef struct sanafe_hip_image
     uint32_t n_cores;
     uint32_t n_slots;        /* padded neuron slots, multiple of 64 */
     uint32_t n_soma_classes, n_cost_classes;
-    uint32_t ring_slots;     /* 1 without synaptic delays, 6 with (max_delay 5, src/models.hpp:158) */
+    uint32_t ring_slots;     /* rows of the time-step buffer / delay ring: >= 1; the host mapper passes 2 without synaptic delays (this
+                              * step's row and the next one's: what push delivery needs), 6 with (max_delay 5, src/models.hpp:158) */
     uint32_t n_slices;       /* delivery work items, >= number of cores with inbound axons */
     uint64_t n_axons, n_synapses;
     uint32_t n_input;        /* input-model neurons */
