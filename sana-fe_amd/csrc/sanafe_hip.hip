@@ -1178,6 +1178,8 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // what one delivery launch reads when every chunk is streamed (sanafe_hip_layout_bytes)
         c->layout_bytes[0] = (c->syn_format == 2) ? h.n_synapses * 12ull : n_dev_syn * (c->syn_format == 4 ? 12ull : dict16 ? 2ull : 4ull);
         // (format 8: build_ordered below replaces [0] with the bytes of the per-accumulator lists)
+        im.bitmap_run_len = 8;
+        if (const char *env = std::getenv("SANAFE_BITMAP_RUN_LEN")) im.bitmap_run_len = (uint32_t) std::min(8L, std::max(1L, std::atol(env)));
         c->layout_bytes[1] = n_bytes - n_gather_only;
         c->layout_bytes[8] = n_gather_only;
         c->layout_bytes[2] = n_chunks * 8ull;

@@ -143,6 +143,9 @@ struct DevImage
     int syn_format;               // 0 .. 4, 6, 7 as above
     int acc_shift;                // format 7: every event adds weight + 2^acc_shift
     int has_last;                 // some cores keep only the last event's current (SANAFE_IN_LAST)
+    uint32_t bitmap_run_len;      // bitmap axon records: 256-slot windows a wavefront streams in one go (<= 8), chosen so that a
+                                  // run's 16-byte groups fill whole 64-lane rows (the last row of a run is processed in full
+                                  // however few of its lanes hold a group)
     // Push delivery for steps with FEW spikes (C4-like activity: 0.3 % of the neurons fire): the neuron launch delivers the
     // spikes itself -- the wavefront that updated a 64-slot chunk walks the static out-synapse lists of the neurons that fired
     // and adds their weights to the NEXT step's row of the time-step buffer (push chips keep two rows, so no wavefront of the
@@ -965,6 +968,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     uint32_t run_len = 1;
     if (RUNS && compact)
         while (run_len < RUN_MAX && run_len * (BLOCK / WAVE) * WAVE_CHUNK < n_ax) run_len *= 2;
+    if (BITMAP && compact && run_len == RUN_MAX) run_len = im.bitmap_run_len; // (bitmap records: any length up to RUN_MAX, see DevImage)
     auto next_c = [&](uint32_t c) -> uint32_t { return c + stride; };
     uint32_t c0 = (uint32_t) wave * WAVE_CHUNK; // per-chunk loop: axon offset of the chunk inside the slice
     uint32_t *w_bits = s_bits[RUNS ? wave : 0];
@@ -1190,16 +1194,20 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         // go through the gather path.
         constexpr uint32_t NW = BLOCK / WAVE;
         // bitmap records: the two words of a lane for the NEXT run are loaded while this run streams (pf_*)
-        auto bitmap_load = [&](uint32_t r, uint32_t &src_word, uint32_t &spk_word) {
+        // (+ where the run's chunks start among the core's synapse words, lane j: chunk j, lane n_here: the end -- a scalar load
+        //  of two table entries at the start of phase B would put one more memory round trip in front of every run's stream)
+        uint32_t pf_csyn = 0;
+        auto bitmap_load = [&](uint32_t r, uint32_t &src_word, uint32_t &spk_word, bool with_csyn) {
             const uint32_t rr = r < n_ax ? r : 0u; // (past the end: any valid run, the values are not used)
             const uint32_t n_here = min(run_len, (n_ax - rr + WAVE_CHUNK - 1u) / WAVE_CHUNK);
             const bool have = (uint32_t) lane < n_here * 8u;
             const uint32_t w = (rr / WAVE_CHUNK) * 8u + (uint32_t) lane;
             src_word = have ? reinterpret_cast<const uint32_t *>(rec)[w] : 0u;
             spk_word = have ? bits[(uint32_t) a_beg + w] : 0u;
+            if (with_csyn) pf_csyn = chunk_syn0[rr / WAVE_CHUNK + min((uint32_t) lane, n_here)];
         };
         uint32_t pf_src = 0, pf_spk = 0;
-        if (BITMAP_RECORDS && bitmap && n_ax > 0) bitmap_load((uint32_t) wave * run_len * WAVE_CHUNK, pf_src, pf_spk);
+        if (BITMAP_RECORDS && bitmap && n_ax > 0) bitmap_load((uint32_t) wave * run_len * WAVE_CHUNK, pf_src, pf_spk, true);
         for (uint32_t r0 = (uint32_t) wave * run_len * WAVE_CHUNK; r0 < n_ax; r0 += NW * run_len * WAVE_CHUNK)
         {
             const uint32_t ci0 = r0 / WAVE_CHUNK;
@@ -1294,6 +1302,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 if (N == 1) q_single = q[0];
             };
             uint32_t before_bm = 0;                  // bitmap records: axons of the run before its first dense chunk
+            uint32_t csyn_lane = 0;                  // bitmap records: first synapse word of chunk `lane` of this run (prefetched)
             // bitmap records: this lane's source word, its spiking axons, the axons of the run before it (phase C loads them
             // again rather than keeping three registers alive across the stream)
             auto bitmap_words = [&](uint32_t &bm_src, uint32_t &bm_f, uint32_t &bm_excl, uint32_t &fincl, bool prefetched) {
@@ -1304,7 +1313,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     bm_src = pf_src;
                     spk = pf_spk;
                 }
-                else bitmap_load(r0, bm_src, spk);
+                else bitmap_load(r0, bm_src, spk, false);
                 bm_f = spk & bm_src;
                 const uint32_t cnt = (uint32_t) __popc(bm_src);
                 bm_excl = wave_inclusive_scan(cnt) - cnt;
@@ -1319,7 +1328,8 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 //      loads -- the slice's source bitmap (bit = this core has an axon from that neuron) and the global spike
                 //      bitmap at the same position -- instead of a record decode, a prefix sum and a random probe per axon.
                 const uint32_t n_here = bitmap_words(bm_src, bm_f, bm_excl, fincl, true);
-                bitmap_load(r0 + NW * run_len * WAVE_CHUNK, pf_src, pf_spk); // the next run's, in flight during the stream
+                csyn_lane = pf_csyn;
+                bitmap_load(r0 + NW * run_len * WAVE_CHUNK, pf_src, pf_spk, true); // the next run's, in flight during the stream
                 stream_msgs += (uint32_t) __popc(bm_f);
                 // per chunk (8 lanes): spiking axons -> stream (many), gather (few) or nothing
 #pragma unroll
@@ -1337,6 +1347,22 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                     // bit table for phase B: bit 32 + a = "axon a (counted from the first dense chunk) spiked".  The spiking
                     // bits of a lane are its word compressed by its source mask, placed at the lane's first axon.
                     const uint32_t first_dense = (uint32_t) __builtin_ctz(dense_mask);
+                    if constexpr (DICT16)
+                    {
+                        // the stream's first loads go out BEFORE the table is built: its ~120 instructions and LDS round trips
+                        // then run under the loads' latency instead of in front of it (same pattern as in phase B below)
+                        const uint32_t last_d = 31u - (uint32_t) __builtin_clz(dense_mask);
+                        const uint32_t p0 = (uint32_t) __builtin_amdgcn_readlane((int) csyn_lane, (int) first_dense);
+                        const uint32_t ng = ((uint32_t) __builtin_amdgcn_readlane((int) csyn_lane, (int) (last_d + 1u)) - p0) / GROUP_WORDS;
+                        const uint4 *s0 = reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + p0));
+#pragma unroll
+                        for (int u = 0; u < SDEPTH; u++)
+                        {
+                            const uint32_t g_u = (uint32_t) lane + (uint32_t) u * WAVE;
+                            sq[u] = load_stream16(s0 + (g_u < ng ? g_u : ng - 1u));
+                            keep_load_order();
+                        }
+                    }
                     before_bm = (uint32_t) __builtin_amdgcn_readlane((int) bm_excl, (int) (8u * first_dense));
                     w_bits[lane] = 0u;
                     if (lane < 8) w_bits[64 + lane] = 0u;
@@ -1377,14 +1403,19 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                 // ---- Phase B: stream the words of chunks first_dense .. last_dense ----
                 wave_lds_fence();
                 const uint32_t first_dense = (uint32_t) __builtin_ctz(dense_mask), last_dense = 31u - (uint32_t) __builtin_clz(dense_mask);
-                const uint32_t run_pos0 = chunk_syn0[ci0 + first_dense];
-                const uint32_t run_groups = (chunk_syn0[ci0 + last_dense + 1u] - run_pos0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
+                const uint32_t run_pos0 = (BITMAP_RECORDS && bitmap) ? (uint32_t) __builtin_amdgcn_readlane((int) csyn_lane, (int) first_dense)
+                                                                     : chunk_syn0[ci0 + first_dense];
+                const uint32_t run_end = (BITMAP_RECORDS && bitmap) ? (uint32_t) __builtin_amdgcn_readlane((int) csyn_lane, (int) (last_dense + 1u))
+                                                                    : chunk_syn0[ci0 + last_dense + 1u];
+                const uint32_t run_groups = (run_end - run_pos0) / GROUP_WORDS; // chunks are 16-byte aligned and padded
                 const uint4 *src = DICT16 ? reinterpret_cast<const uint4 *>(reinterpret_cast<const uint16_t *>(im.syn_meta) + (syn_base + run_pos0))
                                           : reinterpret_cast<const uint4 *>(im.syn_meta + (syn_base + run_pos0));
                 const double2 *wsrc = (SYN_FMT == 4) ? reinterpret_cast<const double2 *>(im.syn_weight + (syn_base + run_pos0)) : nullptr;
                 // The first SDEPTH groups of every lane.  All loads of the stream are unconditional (past the end: the last
                 // group again) and issued in one fixed pattern: only then can the loads in flight be counted, so that a
                 // group waits for ITS load (vmcnt(SDEPTH - 1)) and not for all of them.
+                if (!(BITMAP_RECORDS && bitmap)) // (bitmap records: issued before the bit table was built)
+                {
 #pragma unroll
                 for (int u = 0; u < SDEPTH; u++)
                 {
@@ -1397,6 +1428,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         sw[u][1] = wsrc[2 * g + 1];
                     }
                     keep_load_order();
+                }
                 }
                 if constexpr (DICT16)
                 {
