@@ -1606,10 +1606,40 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         // workgroup finish together -- 17 k-axon slices cost 3 % against 16 k, 10 k-axon ones 8 % against 8 k (measured).
         uint64_t chunk = std::max<uint64_t>(std::max<uint32_t>(4, min_slice_axons & ~3u), ((A / std::max<uint32_t>(1, target_slices)) + 1023) & ~1023ull);
         if (chunk > 8192) chunk = (chunk + 8191) & ~8191ull;
+        const char *align_env = std::getenv("SANAFE_SLICE_ALIGN"); // 0: cut every core by axon count (A/B runs)
+        const bool align_to_source_slots = !(align_env != nullptr && std::atoi(align_env) == 0);
         for (uint32_t k = 0; k < LC; k++)
         {
             uint64_t b = core_axon_beg[k];
             const uint64_t e = core_axon_beg[k + 1];
+            // A core that hears from most of the neurons of a wide span of the chip (C3: 92-99 % of them) gets BITMAP axon records
+            // on the device (deliver_kernel): a run of a wavefront is then 8 windows of 256 SOURCE SLOTS, whatever the number of
+            // axons in them, so such a core is cut where the source slot passes a multiple of 8,192 -- every slice holds whole
+            // runs, the same number for each of the four wavefronts of its workgroup (cut by axon count, 6 slices of 170.7
+            // windows make 22 runs: 6, 6, 5, 5 per wavefront).
+            if (e - b > chunk && align_to_source_slots)
+            {
+                const uint64_t u0 = mc.ax_pre[b] >> 13, units = (mc.ax_pre[e - 1] >> 13) - u0 + 1;
+                bool ascending = true;
+                for (uint64_t a = b + 1; a < e && ascending; a++) ascending = mc.ax_pre[a] > mc.ax_pre[a - 1];
+                if (ascending && units >= 2 && (e - b) * 4ull >= units * 8192ull)
+                {
+                    const uint64_t n_cuts = std::min<uint64_t>(units, std::max<uint64_t>(1, (e - b + chunk / 2) / chunk));
+                    for (uint64_t i = 0; i < n_cuts; i++)
+                    {
+                        const uint64_t slot_end = (u0 + ((i + 1) * units) / n_cuts) << 13;
+                        const uint64_t cut = (i + 1 == n_cuts) ? e
+                                                               : static_cast<uint64_t>(std::lower_bound(mc.ax_pre.begin() + b, mc.ax_pre.begin() + e,
+                                                                                               static_cast<uint32_t>(std::min<uint64_t>(slot_end, 0xffffffffull))) - mc.ax_pre.begin());
+                        if (cut == b) continue; // (no axon in these units)
+                        mc.slice_core.push_back(k);
+                        mc.slice_axon_beg.push_back(b);
+                        mc.slice_axon_end.push_back(cut);
+                        b = cut;
+                    }
+                    continue;
+                }
+            }
             while (b < e)
             {
                 // later slices start on a multiple of 4 axons so the 16-byte ax_pre loads stay aligned
