@@ -240,6 +240,10 @@ int sanafe_hip_get_acc_shift(sanafe_hip_chip *chip);
  * 256-slot windows + one synapse-count byte per axon; "which axons spiked" is an AND with the spike bitmap).
  * SANAFE_AXON_BITMAP=0 keeps the 2-byte delta records (tests, A/B runs). */
 int sanafe_hip_get_bitmap_slices(sanafe_hip_chip *chip);
+/* 1: the chip's delivery kernel keeps 16 sub-accumulators per post-synaptic neuron in LDS, picked by the word's weight code
+ * (bitmap records, cores of at most 256 neurons, no synaptic delays): the accumulator address is the 2-byte word itself with
+ * two bits masked.  Same results (sums of integers).  SANAFE_SUB_ACCUMULATORS=0 keeps one accumulator per neuron. */
+int sanafe_hip_get_sub_accumulators(sanafe_hip_chip *chip);
 /* Push delivery (the neuron launch of a step with few spikes delivers them itself, walking the fired neurons' out-synapses,
  * and the delivery launch -- one probe per inbound axon of the chip whatever the activity -- returns at once; same result,
  * chosen per step on the device from the events of an earlier step): enabled = 1 when the chip qualifies (integer weights, no

@@ -405,9 +405,11 @@ class SpikingChip(_Base):
         H.sanafe_hip_get_push_info.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         H.sanafe_hip_get_push_info(self.device_handle(), C.byref(en), C.byref(pushed))
         H.sanafe_hip_get_bitmap_slices.argtypes = [C.c_void_p]
+        H.sanafe_hip_get_sub_accumulators.argtypes = [C.c_void_p]
         return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle())),
                 "push_enabled": bool(en.value), "push_only": en.value == 2, "pushed_steps": int(pushed.value),
-                "n_bitmap_slices": int(H.sanafe_hip_get_bitmap_slices(self.device_handle()))}
+                "n_bitmap_slices": int(H.sanafe_hip_get_bitmap_slices(self.device_handle())),
+                "sub_accumulators": bool(H.sanafe_hip_get_sub_accumulators(self.device_handle()))}
 
     def step_neurons(self):
         self._check(self._L.sanafe_chip_step_neurons(self._h))

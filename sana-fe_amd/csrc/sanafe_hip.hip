@@ -88,6 +88,7 @@ struct sanafe_hip_chip
     std::vector<uint32_t> h_core_wg_beg, h_core_slice_beg; // host copies for sanafe_hip_read_core_delays
     std::vector<double> h_core_out_lat;
     uint64_t layout_bytes[SANAFE_HIP_LAYOUT_FIELDS]{};
+    bool sub_accumulators{false}; // deliver_kernel<..., SUB>
     std::vector<double> weight_lut; // formats 6, 7: the chip's distinct weight values (<= 32)
     int acc_shift{0};               // format 7: see DevImage
     bool small_slices{false};       // every delivery slice holds at most two 256-axon chunks: 64-thread delivery workgroups
@@ -195,11 +196,12 @@ struct DeliverVariant
     int fmt;
     bool delay, last, iacc;
     int block;
-    bool bitmap, push;
+    bool bitmap, push, sub;
     const void *fn;
 };
-#define SANAFE_DV(F, D, L, I, B) {F, D, L, I, B, false, false, reinterpret_cast<const void *>(deliver_kernel<F, D, L, I, B>)}
-#define SANAFE_DVX(F, D, I, B, BM, P) {F, D, false, I, B, BM, P, reinterpret_cast<const void *>(deliver_kernel<F, D, false, I, B, BM, P>)}
+#define SANAFE_DV(F, D, L, I, B) {F, D, L, I, B, false, false, false, reinterpret_cast<const void *>(deliver_kernel<F, D, L, I, B>)}
+#define SANAFE_DVX(F, D, I, B, BM, P) {F, D, false, I, B, BM, P, false, reinterpret_cast<const void *>(deliver_kernel<F, D, false, I, B, BM, P>)}
+#define SANAFE_DVS(P) {7, false, false, false, DELIVER_BLOCK, true, P, true, reinterpret_cast<const void *>(deliver_kernel<7, false, false, false, DELIVER_BLOCK, true, P, true>)}
 #define SANAFE_DV_FORMAT(F) SANAFE_DV(F, false, false, false, DELIVER_BLOCK), SANAFE_DV(F, true, false, false, DELIVER_BLOCK), \
                             SANAFE_DV(F, false, true, false, DELIVER_BLOCK), SANAFE_DV(F, false, false, false, 64)
 #define SANAFE_DV_IACC(F) SANAFE_DV(F, false, false, true, DELIVER_BLOCK), SANAFE_DV(F, true, false, true, DELIVER_BLOCK), \
@@ -211,11 +213,14 @@ const DeliverVariant deliver_variants[] = {
         SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, false), SANAFE_DVX(7, true, false, DELIVER_BLOCK, true, false),
         SANAFE_DVX(7, false, false, 64, true, false), SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, true),
         SANAFE_DVX(7, false, false, 64, true, true),
+        // ... on sub-accumulators (cores of at most 256 neurons, no synaptic delays)
+        SANAFE_DVS(false), SANAFE_DVS(true),
         // push-delivery prologue on the integer formats (no synaptic delays, no last-event cores)
         SANAFE_DVX(7, false, false, DELIVER_BLOCK, false, true), SANAFE_DVX(7, false, false, 64, false, true),
         SANAFE_DVX(0, false, true, DELIVER_BLOCK, false, true), SANAFE_DVX(3, false, true, DELIVER_BLOCK, false, true)};
 #undef SANAFE_DV
 #undef SANAFE_DVX
+#undef SANAFE_DVS
 #undef SANAFE_DV_FORMAT
 #undef SANAFE_DV_IACC
 // ordered delivery (format 8): dictionary entries x bitmap in LDS x per-neuron write-back rules
@@ -229,10 +234,11 @@ const OrderedVariant ordered_variants[] = {SANAFE_OV(false, false, false), SANAF
         SANAFE_OV(false, true, true), SANAFE_OV(true, false, false), SANAFE_OV(true, false, true), SANAFE_OV(true, true, false),
         SANAFE_OV(true, true, true)};
 #undef SANAFE_OV
-const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block, bool bitmap, bool push)
+const DeliverVariant *find_deliver_variant(int fmt, bool delay, bool last, bool iacc, int block, bool bitmap, bool push, bool sub)
 {
     for (const DeliverVariant &v : deliver_variants)
-        if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block && v.bitmap == bitmap && v.push == push)
+        if (v.fmt == fmt && v.delay == delay && v.last == last && v.iacc == iacc && v.block == block && v.bitmap == bitmap && v.push == push &&
+                v.sub == sub)
             return &v;
     return nullptr;
 }
@@ -1336,8 +1342,13 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         // (the 64-thread variant is built for the plain kernels only: no synaptic delays, no last-event cores, fp64 or
         //  dictionary accumulators)
         const bool use_small = c->small_slices && !im.has_last && !c->has_delay && !iacc;
+        // sub-accumulators (deliver_kernel<..., SUB>): bitmap records, cores of at most 256 neurons, no synaptic delays
+        bool sub = c->n_bitmap_slices > 0 && !use_small && !c->has_delay && max_pad <= SUB_MAX_NEURONS;
+        if (const char *env = std::getenv("SANAFE_SUB_ACCUMULATORS")) // tests / A-B runs: 0 keeps one accumulator per neuron
+            if (std::atoi(env) == 0) sub = false;
+        c->sub_accumulators = sub;
         const DeliverVariant *v = find_deliver_variant(c->syn_format, !im.has_last && c->has_delay, im.has_last != 0, iacc, use_small ? 64 : DELIVER_BLOCK,
-                c->n_bitmap_slices > 0, im.push_cap != 0u);
+                c->n_bitmap_slices > 0, im.push_cap != 0u, sub);
         if (v == nullptr)
             return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "no delivery kernel for format %d (delay %d, last %d, integer accumulators %d)",
                     c->syn_format, (int) c->has_delay, im.has_last, (int) iacc));
@@ -1640,6 +1651,7 @@ extern "C" int sanafe_hip_write_ext(sanafe_hip_chip *c, int64_t n_steps, const i
 }
 
 extern "C" int sanafe_hip_get_bitmap_slices(sanafe_hip_chip *c) { return c ? (int) c->n_bitmap_slices : 0; }
+extern "C" int sanafe_hip_get_sub_accumulators(sanafe_hip_chip *c) { return (c && c->sub_accumulators) ? 1 : 0; }
 extern "C" int sanafe_hip_get_acc_shift(sanafe_hip_chip *c)
 {
     return c ? c->acc_shift : 0;

@@ -850,10 +850,18 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 // BITMAP: every compact slice of the chip is on bitmap axon records (SliceDesc::mode 2; format 7 only) -- compiled apart from
 // the 2-byte delta records so that neither phase A pays for the other's registers.  PUSH: the chip has push-delivery tables
 // (DevImage::push_*); the kernel starts with the per-step push / pull decision.
-template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false, int BLOCK = DELIVER_BLOCK, bool BITMAP = false, bool PUSH = false>
+// SUB: bitmap records on cores of at most SUB_MAX_NEURONS neurons -- every accumulator is spread over 16 sub-accumulators, picked by
+// the upper four bits of the word's weight code, 64 bytes per neuron in STATIC LDS: the accumulator's LDS address is then the
+// word itself with its low two bits masked (one instruction per word instead of a bit-field extract and a shift-add: 70 -> 62
+// vector instructions per 16-byte group), same-address and bank conflicts thin out, and the write-back adds the sixteen
+// (count * 2^shift + sum; the sub-sums obey the bounds the host proved for the whole).
+constexpr uint32_t SUB_MAX_NEURONS = 256;
+template <int SYN_FMT, bool HAS_DELAY, bool LAST, bool IACC = false, int BLOCK = DELIVER_BLOCK, bool BITMAP = false, bool PUSH = false, bool SUB = false>
 __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(BITMAP ? SANAFE_BITMAP_WAVES_PER_EU : SANAFE_DELIVER_WAVES_PER_EU, 8)))
 deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, uint32_t first_slice)
 {
+    static_assert(!SUB || (BITMAP && !HAS_DELAY), "sub-accumulators: bitmap records without synaptic delays");
+    __shared__ uint32_t s_sub[SUB ? (SUB_MAX_NEURONS + 1u) * 16u : 1u]; // [neuron | trash entry][code >> 1]
     __shared__ uint32_t s_beg[BLOCK / WAVE][WAVE_CHUNK];       // first synapse of each active axon
     __shared__ __align__(256) uint32_t s_pref[BLOCK / WAVE][WAVE];   // head bitmap of the event window / spiked-axon mask
     __shared__ double s_red[BLOCK / WAVE];
@@ -1032,7 +1040,12 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         }
         else if (INT_ACC)
         {
-            acc32[i] = 0u;
+            if constexpr (SUB)
+            {
+#pragma unroll
+                for (int q = 0; q < 16; q += 4) *reinterpret_cast<uint4 *>(&s_sub[i * 16u + q]) = make_uint4(0u, 0u, 0u, 0u);
+            }
+            else acc32[i] = 0u;
         }
         else if (TOUCH_BYTES)
         {
@@ -1482,10 +1495,20 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         for (int k = 0; k < 8; k++)
                             if (fired[k])
                             {
+                                lds_u32 *slot;
+                                if constexpr (SUB)
+                                {
+                                    // (LDS byte address = static array + the 16-bit word with its low two bits masked)
+                                    const uint32_t half = (k & 1) ? (d4[k >> 1] >> 16) : d4[k >> 1];
+                                    slot = (lds_u32 *) &s_sub[(half & 0xfffcu) >> 2];
+                                }
+                                else
+                                {
                                 // (LDS byte address = opaque base + 4 * index: a bit-field extract and one shift-add)
                                 uint32_t idx = __builtin_amdgcn_ubfe(d4[k >> 1], (k & 1) ? 22u : 6u, 10u);
                                 asm("" : "+v"(idx)); // (or the shift is folded back into the extract: three instructions)
-                                lds_u32 *slot = reinterpret_cast<lds_u32 *>(acc_base + (idx << 2));
+                                slot = reinterpret_cast<lds_u32 *>(acc_base + (idx << 2));
+                                }
                                 if (LAST && last_mode) __hip_atomic_fetch_max(slot, pos0 + (uint32_t) k + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                                 else __hip_atomic_fetch_add(slot, wv[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // ds_add_u32 (lost charge lands in the trash entry)
                             }
@@ -1646,7 +1669,7 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
                         for (uint32_t k = (uint32_t) lane; k < n; k += WAVE)
                         {
                             const uint32_t word = reinterpret_cast<const uint16_t *>(im.syn_meta)[syn_base + first + k];
-                            atomicAdd(&acc32[word >> 6], (uint32_t) s_lut16[(word >> 1) & 31u]); // ds_add_u32
+                            atomicAdd(SUB ? &s_sub[(word & 0xfffcu) >> 2] : &acc32[word >> 6], (uint32_t) s_lut16[(word >> 1) & 31u]); // ds_add_u32
                         }
                     }
                 }
@@ -1712,7 +1735,18 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
         if (INT_ACC)
         {
             // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (checked by the host): 0 = no event arrived
-            const uint32_t v = acc32[i];
+            uint32_t v;
+            if constexpr (SUB)
+            {
+                v = 0u;
+#pragma unroll
+                for (int q = 0; q < 16; q += 4)
+                {
+                    const uint4 p4 = *reinterpret_cast<const uint4 *>(&s_sub[i * 16u + q]);
+                    v += (p4.x + p4.y) + (p4.z + p4.w);
+                }
+            }
+            else v = acc32[i];
             if (v == 0u) continue;
             const uint32_t events = (v + (1u << (im.acc_shift - 1))) >> im.acc_shift;
             sum = (double) (int) (v - (events << im.acc_shift));

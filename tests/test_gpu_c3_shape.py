@@ -81,3 +81,34 @@ def test_c3_delivery_shape_matches_the_oracle(S, monkeypatch, delays, force, fmt
     dest = np.unique(np.linspace(0, 511, 8).astype(np.int64))
     dest_fired = sum(int((ref[t][1].reshape(512, 512)[dest] == 3).sum()) for t in range(STEPS))
     assert dest_fired > 0.15 * STEPS * len(dest) * 512
+
+
+@pytest.mark.parametrize("sub", [True, False])
+def test_survey_shape_1024_cores_of_256_matches_the_oracle(S, monkeypatch, sub):
+    """SURVEY 8(d)'s shape of C3 -- the bench default: 1,024 cores x 256 neurons -- with 16 destination cores that hear from
+    (nearly) every one of the 262,144 neurons: bitmap axon records, cores cut into slices at multiples of 8,192 source slots,
+    and, on cores of at most 256 neurons, the SUB-ACCUMULATOR instantiation of the delivery kernel (16 partial accumulators per
+    neuron, picked by the weight code; `SANAFE_SUB_ACCUMULATORS=0` keeps one per neuron).  Ten steps against the oracle."""
+    _cache.clear()
+    arch, net = nets.c3_delivery_shape(S, cores=1024, neurons_per_core=256, dest_cores=16, out_degree=41, p_fire=0.3, delays=False)
+    orc = OracleChip(S.to_desc(arch, net))
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")
+    if not sub:
+        monkeypatch.setenv("SANAFE_SUB_ACCUMULATORS", "0")
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    lay, info = chip.device_layout(), chip.info()
+    assert lay["syn_format"] == 7 and lay["n_bitmap_slices"] == info["n_slices"] >= 16 * 4
+    assert lay["sub_accumulators"] == sub
+    fired = 0
+    for t in range(STEPS):
+        a, b = chip.run(1, "simple", record=True), orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k)
+        st = orc.status()
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
+        fired += int((st == 3).sum())
+    assert fired > 0.3 * STEPS * 262144 * 0.9
