@@ -800,6 +800,14 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             if (lut_ok)
             {
                 std::sort(lut.begin(), lut.end()); // thread-count independent codes
+                if (lut.size() <= 16)
+                {
+                    // up to 16 values take the EVEN codes (the odd ones repeat them): the delivery kernel on sub-accumulators
+                    // picks the sub-accumulator -- and with it the LDS bank -- by code >> 1, so the values spread over all 16
+                    std::vector<double> spread(32, 0.0);
+                    for (size_t i = 0; i < lut.size(); i++) spread[2 * i] = spread[2 * i + 1] = lut[i];
+                    lut = spread;
+                }
                 lut.resize(32, 0.0);
                 c->weight_lut = lut;
             }
