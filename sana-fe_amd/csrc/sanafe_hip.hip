@@ -1563,6 +1563,7 @@ static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long 
 }
 static int flush_pending(sanafe_hip_chip *c)
 {
+    const bool flushed = c->pend1.valid || c->pend2.valid;
     while (c->pend1.valid || c->pend2.valid)
     {
         const uint32_t grid = c->pend1.valid ? std::max(1u, c->im.n_reduce_wgs) : 1u;
@@ -1571,6 +1572,10 @@ static int flush_pending(sanafe_hip_chip *c)
         c->pend2 = c->pend1;
         c->pend1.valid = 0;
     }
+    // The step pipeline is empty: no launch in flight reads a push / pull decision any more, and the reductions that would
+    // have renewed the decisions rode in no neuron launch.  Back to "pull" for the next steps -- a caller that steps one
+    // timestep per call must not stay on a stale "push" while its network's activity grows.
+    if (flushed && c->im.push_cap != 0u && c->im.push_always == 0u) HIPCHK(hipMemsetAsync(c->st.push_count, 0, 3 * sizeof(uint32_t), c->stream));
     return 0;
 }
 
