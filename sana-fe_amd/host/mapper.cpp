@@ -1617,7 +1617,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             // axons in them, so such a core is cut where the source slot passes a multiple of 8,192 -- every slice holds whole
             // runs, the same number for each of the four wavefronts of its workgroup (cut by axon count, 6 slices of 170.7
             // windows make 22 runs: 6, 6, 5, 5 per wavefront).
-            if (e - b > chunk && align_to_source_slots)
+            if (e - b > chunk && chunk >= 8192 && align_to_source_slots) // (small chips keep small slices: one chunk per wavefront)
             {
                 const uint64_t u0 = mc.ax_pre[b] >> 13, units = (mc.ax_pre[e - 1] >> 13) - u0 + 1;
                 bool ascending = true;
