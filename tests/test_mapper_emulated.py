@@ -205,3 +205,38 @@ def test_host_rand_matches_libc():
     L.sanafe_test_glibc_rand.argtypes = [ctypes.c_uint32, ctypes.c_int64, ctypes.c_void_p]
     L.sanafe_test_glibc_rand(1, 2000, out.ctypes.data)
     assert out.tolist() == expect
+
+
+def test_dense_cores_are_cut_at_multiples_of_8192_source_slots(S, monkeypatch):
+    """The slice cutter (host/mapper.cpp, "delivery slices"): a core that hears from most neurons of a wide span of the chip is
+    cut where the SOURCE SLOT passes a multiple of 8,192 -- whole runs of the bitmap-record delivery kernel, the same number for
+    every wavefront of a slice's workgroup -- once slices are large (>= 8,192 axons); `SANAFE_SLICE_ALIGN=0` and small chips cut
+    by axon count.  Either way the slices tile every core's axons, and the emulated image still reproduces the oracle."""
+    arch, net = nets.c3_delivery_shape(S, cores=96, neurons_per_core=512, dest_cores=2, out_degree=3, p_fire=0.3, delays=False)
+    monkeypatch.setenv("SANAFE_TARGET_SLICES", "8")  # 2 cores x ~45 k inbound axons / 8 -> slices of 16,384 axons
+    im, _ = S.map_only(arch, net)
+    beg, end, core, pre = im["slice_axon_beg"], im["slice_axon_end"], im["slice_core"], im["ax_pre"]
+    assert im["n_slices"] >= 4
+    cuts = 0
+    for s in range(1, im["n_slices"]):
+        if core[s] == core[s - 1]:  # a cut inside a core: the first axon of the slice is the first one past a multiple of 8,192
+            assert beg[s] == end[s - 1]
+            assert pre[beg[s]] // 8192 > pre[end[s - 1] - 1] // 8192, (s, pre[end[s - 1] - 1], pre[beg[s]])
+            cuts += 1
+    assert cuts >= 2
+    monkeypatch.setenv("SANAFE_SLICE_ALIGN", "0")
+    im0, _ = S.map_only(arch, net)
+    assert any(im0["slice_core"][s] == im0["slice_core"][s - 1] and
+               im0["ax_pre"][im0["slice_axon_beg"][s]] // 8192 == im0["ax_pre"][im0["slice_axon_end"][s - 1] - 1] // 8192
+               for s in range(1, im0["n_slices"]))  # by axon count: some cut falls inside an 8,192-slot unit
+    monkeypatch.delenv("SANAFE_SLICE_ALIGN")
+    compare(S, arch, net, 4)
+
+
+def test_time_step_buffer_rows(S):
+    """Chips without synaptic delays keep TWO rows of the time-step buffer (this step's and the next one's: push delivery
+    adds to the next row from inside the neuron launch); delay lines keep 6 (max_delay 5, src/models.hpp:158)."""
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, arch_kind="loihi")
+    assert S.map_only(arch, net)[0]["ring_slots"] == 2
+    arch, net = nets.random_loihi(S, n_tiles=2, neurons_per_core=64, out_degree=8, delays=True)
+    assert S.map_only(arch, net)[0]["ring_slots"] == 6
