@@ -1,28 +1,31 @@
 // sanafe_hip.hip -- SANA-FE's per-timestep simulation loop for MI355X (gfx950, CDNA4).
 //
-// Implements the C ABI of include/sanafe_hip.h.  Two launches per timestep, all on one
+// Implements the C ABI of include/sanafe_hip.h.  Two launches per timestep (one on push-only chips), all on one
 // HIP stream, no host round trip between steps:
 //
-//   K1 neuron_kernel   one 256-thread workgroup per simulated core, its 64-slot chunks dealt to the 4
-//                      wavefronts; SoA neuron state, coalesced 8-byte loads; soma update (LIF / TrueNorth /
-//                      input, incl. the host-generated stochastic value streams); wave ballot -> spike
-//                      bitmap; per-core cost/counter sums by wave reduction.
+//   K1 neuron_kernel   one 256-thread workgroup per up to four 64-slot chunks of a simulated core, one wavefront per
+//                      chunk; SoA neuron state, coalesced 8-byte loads; soma update (LIF / TrueNorth / input, incl.
+//                      the host-generated stochastic value streams); wave ballot -> spike bitmap; cost / counter
+//                      partials per wavefront.  On steps with few spikes the wavefront also DELIVERS its neurons'
+//                      spikes (push delivery: static out-synapse lists, atomics into the next step's buffer row).
+//                      The leading workgroups reduce the two previous steps (K3).
 //                      Reference: process_neurons / process_neuron / execute_pipeline,
 //                      src/chip.cpp:624-654, 710-736, 766-789; models src/models.cpp:441-903;
 //                      default costing src/pipeline.hpp:631-731.
 //   K2 deliver_kernel  one 256-thread workgroup (4 independent wavefronts) per delivery slice of a
-//                      destination core: walks the core's static inbound-axon list in 256-axon chunks
-//                      against the spike bitmap ("pull": messages are never materialised) and adds the
-//                      weights of the spiking axons' synapses into LDS accumulators (one row per delay
-//                      value) before one write-back.  Two paths per chunk: STREAM (many spikes: every
-//                      synapse word of the chunk is read once, in order, and says itself whether its axon
-//                      spiked) and GATHER (few spikes: compaction by ballot + prefix sums, load-balanced
-//                      expansion to synaptic events).  The chunk loop is software-pipelined.
+//                      destination core: walks the core's static inbound-axon list against the spike bitmap
+//                      ("pull": messages are never materialised) and adds the weights of the spiking axons'
+//                      synapses into LDS accumulators before one write-back.  Axon records: a source bitmap per
+//                      256-slot window (dense fan-in), 2-byte deltas, or 8-byte records; synapse words: 2-byte
+//                      dictionary words or 4-byte words, streamed in runs of 8 chunks (every word is read once,
+//                      in order, and says itself whether its axon spiked) or gathered (few spikes).
 //                      Reference: process_messages / process_message, src/chip.cpp:656-764;
 //                      AccumulatorModel / AccumulatorWithDelayModel src/models.cpp:71-131.
-//   K3 reduce_step     fixed-order reduction of the per-core partials into the timestep totals, simple
-//                      timing model, run totals, t += 1.  Runs in workgroup 0 of the NEXT step's neuron
-//                      launch (a timestep is two launches); reduce_kernel flushes the last step.
+//   K2o ordered_deliver_kernel   chips with non-integer weights: one lane per accumulator folds the accumulator's own
+//                      synapse list in the reference's delivery order (bit-equal fp64 sums, no atomics).
+//   K3 reduce_l1 / l2  fixed-order, two-level reduction of the per-wavefront partials and the slices' processing
+//                      delays into the timestep totals, simple timing model, run totals, t += 1.  Rides in the
+//                      leading workgroups of the NEXT two neuron launches; reduce_kernel flushes the last steps.
 //                      Reference: sim_calculate_ts_energy, sim_update_ts_counters,
 //                      schedule_messages_timestep_simple, src/chip.cpp:1028-1051, 1171-1261;
 //                      src/schedule.cpp:61-102.
