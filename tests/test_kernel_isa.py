@@ -46,3 +46,33 @@ def test_stream_loads_are_counted(isa, fmt, depth_in_flight, bitmap):
     waits = _steady_state_waits(fn, depth_in_flight)
     assert waits, "the stream loop of deliver_kernel<%d> waits for no load at all?" % fmt
     assert min(waits) >= depth_in_flight - 1, (fmt, waits)
+
+
+def _metadata(isa):
+    """name -> (vgprs, scratch bytes) of every kernel, from the code object's metadata at the end of the assembly."""
+    out = {}
+    for block in "\n".join(isa).split("  - .agpr_count:")[1:]:
+        def field(name):
+            return re.search(r"\.%s:\s+(\S+)" % name, block).group(1)
+        out[field("name")] = (int(field("vgpr_count")), int(field("private_segment_fixed_size")))
+    return out
+
+
+def test_hot_kernels_keep_their_occupancy_and_do_not_spill(isa):
+    """The measured operating points: the neuron kernels fit 64 VGPRs (8 wavefronts per SIMD), the
+    bitmap-record delivery kernels 80 (6 per SIMD), every other delivery instantiation 96 (5 per SIMD) -- and the headline
+    instantiations use no scratch at all (a spilled dword in the stream loop costs ~10 % of the launch)."""
+    meta = _metadata(isa)
+    neuron = {k: v for k, v in meta.items() if "neuron_kernel" in k}
+    assert len(neuron) == 5
+    for name, (vgprs, scratch) in neuron.items():
+        assert vgprs <= 64 and scratch == 0, (name, vgprs, scratch)
+    deliver = {k: v for k, v in meta.items() if "deliver_kernelILi" in k}
+    assert len(deliver) >= 40
+    for name, (vgprs, scratch) in deliver.items():
+        assert vgprs <= 96 and scratch <= 16, (name, vgprs, scratch)
+    # format 7 on bitmap records, 256 threads, with and without push prologue / sub-accumulators
+    hot = {k: v for k, v in deliver.items() if "deliver_kernelILi7ELb0ELb0ELb0ELi256ELb1E" in k}
+    assert len(hot) == 4
+    for name, (vgprs, scratch) in hot.items():
+        assert vgprs <= 80 and scratch == 0, (name, vgprs, scratch)
