@@ -318,7 +318,8 @@ int sanafe_hip_read_status(sanafe_hip_chip *chip, uint8_t *out);
 int sanafe_hip_read_step_status(sanafe_hip_chip *chip, int64_t first, int64_t count, uint8_t *out);
 int sanafe_hip_read_potentials(sanafe_hip_chip *chip, double *out);
 int sanafe_hip_read_input_current(sanafe_hip_chip *chip, double *out); /* LIF `u` trace */
-/* Per-core sums of the last step: generation-delay sum and processing-delay sum. */
+/* Per-core sums of the last step: generation-delay sum and processing-delay sum (either may be NULL).  proc_sum is refused
+ * (SANAFE_HIP_ERR_UNSUPPORTED) on chips with push delivery: pushed steps price a core's messages inside the step reduction. */
 int sanafe_hip_read_core_delays(sanafe_hip_chip *chip, double *gen_sum, double *proc_sum);
 
 /* Parameter patches between sim() calls (slot-indexed, local). */

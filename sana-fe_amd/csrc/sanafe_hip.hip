@@ -1974,6 +1974,10 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
     }
     if (proc_sum)
     {
+        // pushed steps price a core's messages inside the step reduction (reduce_l1, from counters it clears): nothing to read back
+        if (c->im.push_cap != 0u)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "per-core processing delays are not kept on chips with push delivery "
+                                                    "(create the chip with SANAFE_PUSH=0 to read them)");
         std::vector<double> sp(std::max<uint32_t>(1, c->im.n_slices));
         TRY(d2h(c, sp.data(), c->st.slice_proc + last_parity * c->im.n_slices, c->im.n_slices));
         for (uint32_t k = 0; k < c->im.n_cores; k++)
