@@ -29,7 +29,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
-def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0, weights="int8"):
+ACTIVITY_THRESHOLD = 30000  # --target-activity: far above anything the +-8 synaptic weights add up to within a run
+
+
+def activity_biases(n, target, seed):
+    """--target-activity: per-neuron integer biases that make `target` of the neurons fire per step in steady state.
+    Soft reset (V -= threshold) and a threshold the synaptic input never reaches on its own: a neuron with bias b fires at
+    the rate b / threshold.  A fraction q of the neurons gets rates uniform in [1/12, 1/4] (targets up to 12.5 %) or in
+    [1/4, 1] (above), q = target / mean rate; the others stay silent.  Different rates keep the population desynchronised,
+    and the synaptic input jitters the spike times, so the set of firing neurons changes from step to step."""
+    rng = np.random.default_rng(seed + 77)
+    lo, hi = (1.0 / 12.0, 0.25) if target <= 0.125 else (0.25, 1.0)
+    q = min(1.0, target / (0.5 * (lo + hi)))
+    rate = np.where(rng.random(n) < q, lo + (hi - lo) * rng.random(n), 0.0)
+    return np.floor(rate * ACTIVITY_THRESHOLD)
+
+
+def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fire, seed, rank=0, weights="int8", target_activity=None):
     """Built through the product front-end (C++17 / PyBind11 description objects)."""
     n_tiles = max(1024, (cores_per_gpu * n_gpus + 3) // 4) if cores_per_gpu * n_gpus > 4096 else 1024
     arch = S.presets.loihi_large(n_tiles=n_tiles, n_inputs=4)
@@ -38,10 +54,16 @@ def build_workload(S, n_gpus, cores_per_gpu, neurons_per_core, out_degree, p_fir
     n_per_gpu = cores_per_gpu * neurons_per_core
     n = n_per_gpu * n_gpus
     net = S.Network("random_%dk" % (n // 1024))
-    g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
-                                "loihi_dendrites_delay", False, True, "loihi_lif")
+    if target_activity is None:
+        attrs = {"threshold": 64, "reset": 0, "force_update": True}
+    else:
+        attrs = {"threshold": ACTIVITY_THRESHOLD, "reset_mode": "soft", "force_update": True}
+    g = net.create_neuron_group("n", n, attrs, "loihi_sparse_synapse", "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(seed)
-    g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128.0, 0.0), integer=True)
+    if target_activity is None:
+        g.set_attribute_column("bias", np.where(rng.random(n) < p_fire, 128.0, 0.0), integer=True)
+    else:
+        g.set_attribute_column("bias", activity_biases(n, target_activity, seed), integer=True)
     # a rank only needs the edges that start or end in its own shard of the neurons.  Weak scaling: every neuron draws
     # its targets from the n_per_gpu neurons (one GPU's worth of cores) centred on itself, ids wrapping -- on one GPU
     # that is the uniform recipe of SURVEY 8(d); on N GPUs the fan-in statistics of a core (sources per core, synapses
@@ -240,6 +262,10 @@ def parse_args():
     ap.add_argument("--neurons-per-core", type=int, default=256)
     ap.add_argument("--out-degree", type=int, default=2621)
     ap.add_argument("--p-fire", type=float, default=0.1)
+    ap.add_argument("--target-activity", type=float, default=None,
+                    help="c3: hold the fraction of neurons that fire per step at this value (threshold 30000, soft reset, per-neuron "
+                         "biases = rate x threshold) instead of the headline recipe, whose activity runs away to ~34 %%: the regime "
+                         "real SNNs run in is 0.5-5 %% (profiles/r04_c3_activity.json)")
     ap.add_argument("--weights", choices=("int8", "int12", "float", "int8wide", "floatwide"), default="int8",
                     help="c3: synaptic weights -- integers in +-8 (default, SURVEY 8d), integers in +-800, 16 non-integers, "
                          "~240 distinct integers in +-127, or a different non-integer per synapse")
@@ -339,7 +365,8 @@ def collect_traffic_inline(args, n_launch_tail):
                     for row in csv.DictReader(fh):
                         if row["Counter_Name"] != counter:
                             continue
-                        k = "deliver_kernel" if "deliver_kernel" in row["Kernel_Name"] else \
+                        k = "event_deliver_kernel" if "event_deliver_kernel" in row["Kernel_Name"] else \
+                            "deliver_kernel" if "deliver_kernel" in row["Kernel_Name"] else \
                             "neuron_kernel" if "neuron_kernel" in row["Kernel_Name"] else None
                         if k:
                             rows.setdefault(k, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
@@ -357,6 +384,11 @@ def collect_traffic_inline(args, n_launch_tail):
             d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected"] + d["write_bytes"]
     if not any("hbm_bytes_per_launch" in d for d in res.values()):
         return None, "no neuron_kernel / deliver_kernel counter rows in the rocprofv3 output"
+    if "event_deliver_kernel" in res and "deliver_kernel" in res and "hbm_bytes_per_launch" in res["event_deliver_kernel"]:
+        # chips with the event layout launch both delivery kernels every step, one of them returns at once: a step's
+        # delivery traffic is the sum
+        res["event_deliver_kernel"]["hbm_bytes_per_launch"] += res["deliver_kernel"].get("hbm_bytes_per_launch", 0.0)
+        res["deliver_kernel"]["hbm_bytes_per_launch"] = res["event_deliver_kernel"]["hbm_bytes_per_launch"]
     return res, None
 
 
@@ -406,11 +438,14 @@ def main():
                     "one out-edge per neuron, 80%% remote" % (n_total, args.tiles_per_gpu))
     else:
         arch, net = build_workload(S, world, args.cores_per_gpu, args.neurons_per_core, args.out_degree, args.p_fire,
-                                   args.seed, rank, args.weights)
+                                   args.seed, rank, args.weights, args.target_activity)
         n_total = args.cores_per_gpu * args.neurons_per_core * world
         workload = ("arch/loihi_large.yaml + synthetic random SNN (BASELINE configs[2]): %d LIF neurons (%d cores x %d per "
-                    "GPU), out-degree %d, %.0f%% biased to fire every step, loihi_dendrites_delay"
-                    % (n_total, args.cores_per_gpu, args.neurons_per_core, args.out_degree, 100 * args.p_fire))
+                    "GPU), out-degree %d, %s, loihi_dendrites_delay"
+                    % (n_total, args.cores_per_gpu, args.neurons_per_core, args.out_degree,
+                       "%.0f%% biased to fire every step" % (100 * args.p_fire) if args.target_activity is None else
+                       "activity held at %.3g%% of the neurons per step (threshold %d, soft reset, per-neuron biases)"
+                       % (100 * args.target_activity, ACTIVITY_THRESHOLD)))
         if args.weights != "int8":
             workload += ", %s weights" % args.weights
     workload += ", %s timing" % args.timing
@@ -486,6 +521,7 @@ def main():
     # ---- roofline pass: HIP events around every kernel on its own stream (one rank, the chip's own stream) ----
     roof = None
     if want_roof:
+        pushed_before = chip.device_layout()["pushed_steps"]
         H.sanafe_hip_set_timing(dev, 1)
         b2 = chip.read_totals()
         if H.sanafe_hip_step(dev, args.timed_steps, 1, 0) != 0:
@@ -503,12 +539,30 @@ def main():
         #     bitmap, each read once when every chunk is streamed (an upper bound when few axons spike), + one 17-byte
         #     write-back per neuron; neuron launch = per-slot state read + written, + 40 B per fired neuron.  DESIGN.md 5
         #     states the per-unit figures.  achieved = these bytes / the HIP-event-timed launch duration of THIS run.
-        lay = (C.c_uint64 * 9)()
+        lay = (C.c_uint64 * 11)()
         H.sanafe_hip_layout_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        if H.sanafe_hip_layout_bytes(dev, lay, 9) != 0:
+        if H.sanafe_hip_layout_bytes(dev, lay, 11) != 0:
             raise RuntimeError(H.sanafe_hip_last_error().decode())
         lay = [int(x) for x in lay]
-        design_deliver = float(sum(lay[0:5])) + 17.0 * upd
+        design_stream = float(sum(lay[0:5])) + 17.0 * upd
+        design_deliver, deliver_parts, deliver_name = design_stream, None, "deliver_kernel"
+        layout_now = chip.device_layout()
+        evl = layout_now.get("event_layout")
+        by_events = (layout_now["pushed_steps"] - pushed_before) / float(args.timed_steps) if evl else 0.0
+        if evl:
+            # Steps delivered by events (event_deliver_kernel) read: every workgroup its segment of the spike bitmap
+            # (groups x bitmap), per fired neuron and core group 8 + 4 bytes of the block tables, the fired neurons' blocks
+            # of 2-byte words (padded to 16 bytes per block: layout bytes / synapses per word on average), and write back
+            # 17 bytes per (segment, neuron) that received an event (atomics: the segments of a group share its neurons).
+            n_acc = float(evl["segments"]) * float(info["n_neurons"])
+            touched = n_acc * (1.0 - np.exp(-ev / n_acc)) if n_acc > 0 else 0.0
+            ev_parts = {"spike_bitmap_scans": evl["groups"] * lay[4], "block_tables": 12.0 * fired * evl["groups"],
+                        "synapse_words_of_fired_neurons": ev * lay[9] / max(1.0, float(info["n_synapses"])),
+                        "write_back": 17.0 * touched}
+            design_event = float(sum(ev_parts.values()))
+            design_deliver = by_events * design_event + (1.0 - by_events) * design_stream
+            if by_events >= 0.5:
+                deliver_name, deliver_parts = "event_deliver_kernel", ev_parts
         design_neuron = float(lay[5] + lay[6]) + lay[7] * fired
         # (2) SURVEY 8(d)'s byte model (48 B per neuron update, 28 B per synaptic event, 96 B per message): it prices
         #     12-byte synapses, HBM accumulators and materialised 40-byte messages, none of which this design moves, so
@@ -519,11 +573,13 @@ def main():
             return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
 
         achieved = gbps(design_deliver, dm.value)
-        roof = {"bound": "hbm", "kernel": "deliver_kernel", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        roof = {"bound": "hbm", "kernel": deliver_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": None, "traffic_from_this_run": False,
                 "algorithmic_bytes_per_launch": design_deliver, "avg_launch_ms": dm.value,
-                "algorithmic_bytes_parts": {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
-                                            "slice_descriptors": lay[3], "spike_bitmap": lay[4], "write_back": 17.0 * upd},
+                "steps_delivered_by_events": by_events,
+                "algorithmic_bytes_parts": deliver_parts or {"synapse_words": lay[0], "axon_records": lay[1], "chunk_tables": lay[2],
+                                                             "slice_descriptors": lay[3], "spike_bitmap": lay[4],
+                                                             "write_back": 17.0 * upd},
                 # bitmap axon records keep one synapse-count byte per axon that only the gather path reads (windows with
                 # fewer than 8 spiking axons): NOT part of algorithmic_bytes_per_launch
                 "axon_record_bytes_read_by_gather_path_only": lay[8],

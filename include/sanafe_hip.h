@@ -252,6 +252,19 @@ int sanafe_hip_get_sub_accumulators(sanafe_hip_chip *chip);
  * SANAFE_PUSH_ONLY_DEGREE / SANAFE_PUSH_ONLY=0|1: every step is pushed, one launch per step); pushed_steps = steps delivered
  * that way since create. */
 int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t *pushed_steps);
+/* Event-driven delivery (replaces the per-message walk of process_messages / process_message, src/chip.cpp:656-764, for
+ * steps with few spikes on chips too large for push tables): a second copy of the format-7 synapse words, regrouped
+ * source-neuron-major per group of destination cores, so that a step reads the spike bitmap, one table entry per (fired
+ * neuron, core group) and that neuron's blocks of words -- work in proportion to the step's synaptic events, LDS integer
+ * accumulators like the streaming kernel, same results.  Which kernel delivers a step is decided on the device (few
+ * events three steps earlier -> events) and counted in sanafe_hip_get_push_info's pushed_steps.
+ *   info[0] core groups (0: the chip has no event layout)   [1] segments of the source space (grid = groups x segments)
+ *   [2] 16-byte units of all blocks   [3] words per (neuron, group) block x 1000   [4] lanes per block   [5] weight-code bits
+ *   [6] accumulator shift   [7] 1: every step goes by events (SANAFE_EVENT=2)   [8] event threshold of the decision
+ * SANAFE_EVENT=0 off / 1 build whatever the block length / 2 build and always use; SANAFE_EVENT_SEGMENTS,
+ * SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_LPB (4 | 8), SANAFE_EVENT_MAX_EVENTS. */
+#define SANAFE_HIP_EVENT_INFO_FIELDS 9
+int sanafe_hip_get_event_info(sanafe_hip_chip *chip, uint64_t *info, int n);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.
  *   [0] synapse words (+ fp64 weights in format 2)   [1] axon records   [2] chunk tables   [3] slice descriptors
@@ -261,8 +274,11 @@ int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t 
  *   [7] bytes read per FIRED neuron on top (static downstream totals of its spike);
  *   [8] part of the axon-record array that a launch which streams every chunk does NOT read: the one synapse-count byte
  *       per axon behind the bitmap records (slice mode 2), read only for 256-slot windows with so few spiking axons that
- *       they take the gather path.  [1] excludes it. */
-#define SANAFE_HIP_LAYOUT_FIELDS 9
+ *       they take the gather path.  [1] excludes it.
+ *   [9] / [10] event layout (sanafe_hip_get_event_info): all blocks of synapse words / the per-neuron tables.  A step
+ *       delivered by events reads, per fired neuron, its blocks (2 bytes per synaptic event + padding to 16 bytes per
+ *       block) and 8 + 4 bytes of [10] per core group. */
+#define SANAFE_HIP_LAYOUT_FIELDS 11
 int sanafe_hip_layout_bytes(sanafe_hip_chip *chip, uint64_t *out, int n);
 
 /* Split step for tile-sharded (multi-GPU) runs and for host-evaluated (plugin)

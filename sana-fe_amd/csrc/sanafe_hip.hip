@@ -118,6 +118,10 @@ struct sanafe_hip_chip
     int ord_debug{0};               // SANAFE_ORDERED_ROLE=1/2: launch one role of ordered_deliver_kernel only (profiling)
     size_t ord_lds{0};              // format 8: dynamic LDS of ordered_deliver_kernel (the spike bitmap), 0: probe global memory
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
+    const void *event_fn{nullptr};   // event_deliver_kernel instantiation (chips with the event layout, DevImage::ev_*)
+    int ev_lpb{4};                   // its lanes per block
+    double ev_avg_block{0.0};        // words per (source neuron, core group) block
+    uint32_t ev_grid{0};
     uint32_t deliver_block{0};
     uint32_t neuron_grid{0};
     long long rec_host{0};
@@ -436,6 +440,233 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     if (const char *env = std::getenv("SANAFE_PUSH_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0L, std::atol(env));
     TRY(dalloc(c, 8, &c->st.push_count)); // [0..2] decisions (0: pull), [6] steps delivered by the push path
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
+    return 0;
+}
+
+// Event-driven delivery layout (DevImage: ev_*): the chip's format-7 words a second time, regrouped source-neuron-major per
+// group of destination cores, for steps with few spikes.  Built only where event_deliver_kernel is exact and pays:
+// integer dictionary weights on bitmap axon records (one axon per source neuron and core, every axon owns its synapses, no
+// lost charge), no synaptic delays / last-event cores / taps / host units, one latency class per core, and blocks long
+// enough to be worth a table entry.  SANAFE_EVENT=0 switches it off, 1 builds it whatever the block length, 2 also delivers
+// every step with it (tests); SANAFE_EVENT_SEGMENTS, SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_MAX_EVENTS tune it.
+int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
+{
+    DevImage &im = c->im;
+    im.ev_groups = 0;
+    im.ev_always = 0;
+    int want = -1; // default: build when it pays
+    if (const char *env = std::getenv("SANAFE_EVENT")) want = std::atoi(env);
+    if (want == 0) return 0;
+    if (c->syn_format != 7 || c->n_bitmap_slices == 0 || c->n_bitmap_slices != h.n_slices || c->has_delay || im.has_last || h.n_taps != 0 ||
+            h.n_synapses == 0 || h.ax_lat_class == nullptr || h.n_slots / 64 == 0)
+        return 0;
+    for (uint32_t g = 0; g < h.n_slots; g++)
+        if ((h.slot_cls[g] & 7u) == SANAFE_SOMA_HOST) return 0; // their spikes are set after the neuron launch
+    // the dictionary, densely coded
+    std::vector<double> lut;
+    for (double w : c->weight_lut)
+    {
+        bool known = false;
+        for (double v : lut) known = known || v == w;
+        if (!known) lut.push_back(w);
+    }
+    std::sort(lut.begin(), lut.end());
+    const uint32_t code_bits = lut.size() <= 16 ? 4u : 5u;
+    const uint32_t acc_max = 1u << (16u - code_bits);
+    auto lut_code = [&](double w) {
+        for (uint32_t q = 0; q < lut.size(); q++)
+            if (lut[q] == w) return q;
+        return 0u;
+    };
+    // groups of consecutive cores: at most 16, their slots within acc_max - EV_TRASH accumulators
+    uint32_t max_group_cores = 16;
+    if (const char *env = std::getenv("SANAFE_EVENT_GROUP_CORES")) max_group_cores = (uint32_t) std::min(16L, std::max(1L, std::atol(env)));
+    std::vector<EvGroup> groups;
+    std::vector<uint32_t> group_of(h.n_cores, 0xffffffffu);
+    for (uint32_t k = 0; k < h.n_cores; k++)
+    {
+        const uint32_t npad = (h.core_ncount[k] + 63u) & ~63u;
+        if (npad == 0) continue; // (no neurons: no inbound synapses either)
+        if (npad > acc_max - EV_TRASH) return 0;
+        const uint32_t end = h.core_nbase[k] + npad;
+        if (groups.empty() || k - groups.back().core0 >= max_group_cores || end - groups.back().slot0 > acc_max - EV_TRASH)
+            groups.push_back(EvGroup{k, 0u, h.core_nbase[k], 0u});
+        groups.back().n_cores = k - groups.back().core0 + 1u;
+        groups.back().n_acc = end - groups.back().slot0;
+        group_of[k] = (uint32_t) groups.size() - 1u;
+    }
+    const uint32_t NG = (uint32_t) groups.size();
+    if (NG == 0 || NG > 4096) return 0;
+    // one latency class per core (the reduction prices a core's events with one constant)
+    std::vector<double> ev_lat(h.n_cores, 0.0);
+    {
+        std::vector<int> cls(h.n_cores, -1);
+        for (uint32_t sl = 0; sl < h.n_slices; sl++)
+        {
+            if (h.slice_axon_end[sl] == h.slice_axon_beg[sl]) continue;
+            const uint32_t core = h.slice_core[sl];
+            const int lc = h.ax_lat_class[h.slice_axon_beg[sl]]; // (bitmap slices: one class per slice)
+            if (lc == 255) return 0;
+            if (cls[core] < 0) cls[core] = lc;
+            else if (cls[core] != lc) return 0;
+        }
+        for (uint32_t k = 0; k < h.n_cores; k++)
+            if (cls[k] >= 0) ev_lat[k] = h.lat_class_per_event ? h.lat_class_per_event[cls[k]] : 0.0;
+    }
+    // slices of each group (slices are sorted by core)
+    std::vector<uint32_t> group_slice_beg(NG + 1, h.n_slices);
+    for (uint32_t sl = h.n_slices; sl-- > 0;) group_slice_beg[group_of[h.slice_core[sl]]] = sl;
+    for (uint32_t g = NG; g-- > 0;)
+        if (group_slice_beg[g] > group_slice_beg[g + 1]) group_slice_beg[g] = group_slice_beg[g + 1]; // (a group without slices)
+    const uint64_t N = h.n_global_slots;
+    const uint64_t row = (uint64_t) NG + 1u;
+    if (N * row >= (1ull << 32)) return 0;
+    // pass 1: words and core masks per (source neuron, group)
+    std::vector<uint32_t> cnt(N * NG, 0u);
+    std::vector<uint16_t> mask(N * NG, 0);
+    std::atomic<bool> bad{false};
+    parallel_for(NG, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t g = lo; g < hi; g++)
+            for (uint32_t sl = group_slice_beg[g]; sl < group_slice_beg[g + 1]; sl++)
+            {
+                const uint16_t bit = (uint16_t) (1u << (h.slice_core[sl] - groups[g].core0));
+                for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl]; a++)
+                {
+                    const uint64_t at = (uint64_t) h.ax_pre[a] * NG + g;
+                    if (mask[at] & bit) bad = true; // two axons from one neuron into one core: messages would be miscounted
+                    mask[at] |= bit;
+                    cnt[at] += h.ax_nsyn[a];
+                }
+            }
+    });
+    if (bad.load()) return 0;
+    // is it worth it?  A block costs a table entry and starts a new 128-byte line: short blocks make the gather dearer than
+    // the stream at any activity.
+    {
+        uint64_t blocks = 0;
+        for (uint64_t i = 0; i < N * NG; i++) blocks += cnt[i] != 0u;
+        if (blocks == 0 || (want < 1 && (double) h.n_synapses / (double) blocks < 6.0)) return 0;
+        c->ev_avg_block = (double) h.n_synapses / (double) blocks;
+    }
+    // segments of the source space: 1,024-slot tiles, at most 64 per segment (16-bit list entries)
+    const uint32_t n_tiles = (uint32_t) ((N + EV_TILE - 1) / EV_TILE);
+    uint32_t segments = 8;
+    if (const char *env = std::getenv("SANAFE_EVENT_SEGMENTS")) segments = (uint32_t) std::max(1L, std::atol(env));
+    segments = std::min(segments, n_tiles);
+    segments = std::max(segments, (n_tiles + 63u) / 64u);
+    // pass 2: offsets.  meta[n][g] = first unit of the block (relative to the neuron's base) | mask << 16; meta[n][NG] = end
+    std::vector<uint32_t> meta(N * row, 0u);
+    std::vector<uint32_t> base(N + 1, 0u);
+    parallel_for(N, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++)
+        {
+            uint32_t off = 0;
+            for (uint32_t g = 0; g < NG; g++)
+            {
+                meta[n * row + g] = off | ((uint32_t) mask[n * NG + g] << 16);
+                off += (cnt[n * NG + g] + 7u) / 8u;
+                if (off > 0xffffu) bad = true;
+            }
+            meta[n * row + NG] = off;
+            base[n + 1] = off;
+        }
+    });
+    if (bad.load()) return 0;
+    uint64_t total_units = 0;
+    for (uint64_t n = 0; n < N; n++)
+    {
+        const uint32_t units = base[n + 1];
+        base[n] = (uint32_t) total_units;
+        total_units += units;
+        if (total_units >= (1ull << 32)) return 0;
+    }
+    base[N] = (uint32_t) total_units;
+    // pass 3: the words, group by group (a block is written by one thread); cnt becomes the write cursor.  Per (segment,
+    // accumulator): events and |weight| sums, for the bounds of the integer accumulators.
+    std::vector<uint16_t> words((total_units + 64u) * 8u, 0);
+    std::atomic<uint64_t> max_count{0}, max_abs{0};
+    for (uint64_t i = 0; i < N * NG; i++) cnt[i] = 0u;
+    const uint32_t seg_tiles = (n_tiles + segments - 1u) / segments;
+    parallel_for(NG, [&](uint64_t lo, uint64_t hi) {
+        std::vector<uint32_t> count((size_t) segments * acc_max);
+        std::vector<uint64_t> abs_sum((size_t) segments * acc_max);
+        uint64_t mc = 0, ma = 0;
+        for (uint64_t g = lo; g < hi; g++)
+        {
+            std::fill(count.begin(), count.end(), 0u);
+            std::fill(abs_sum.begin(), abs_sum.end(), 0ull);
+            for (uint32_t sl = group_slice_beg[g]; sl < group_slice_beg[g + 1]; sl++)
+            {
+                const uint32_t core = h.slice_core[sl];
+                const uint32_t acc0 = h.core_nbase[core] - groups[g].slot0;
+                for (uint64_t a = h.slice_axon_beg[sl]; a < h.slice_axon_end[sl]; a++)
+                {
+                    const uint64_t n = h.ax_pre[a];
+                    const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
+                    const size_t sg = (size_t) std::min<uint32_t>((uint32_t) (n / EV_TILE) / seg_tiles, segments - 1u) * acc_max;
+                    uint64_t at = ((uint64_t) base[n] + (meta[n * row + g] & 0xffffu)) * 8u + cnt[n * NG + g];
+                    for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
+                    {
+                        const uint32_t idx = acc0 + (h.syn_meta[src + k] & 0xffffu);
+                        words[at++] = (uint16_t) (lut_code(h.syn_weight[src + k]) | (idx << code_bits));
+                        count[sg + idx]++;
+                        abs_sum[sg + idx] += (uint64_t) std::fabs(h.syn_weight[src + k]);
+                    }
+                    cnt[n * NG + g] += h.ax_nsyn[a];
+                }
+            }
+            for (size_t q = 0; q < count.size(); q++) mc = std::max<uint64_t>(mc, count[q]), ma = std::max(ma, abs_sum[q]);
+        }
+        uint64_t seen = max_count.load();
+        while (seen < mc && !max_count.compare_exchange_weak(seen, mc)) {}
+        seen = max_abs.load();
+        while (seen < ma && !max_abs.compare_exchange_weak(seen, ma)) {}
+    });
+    int shift = 1;
+    while ((1ull << (shift - 1)) <= max_abs.load() && shift < 32) shift++;
+    if (shift > 15 || ((max_count.load() + 1ull) << shift) > (1ull << 32)) return 0; // (weight + 2^shift: 16 bits in the kernel's table)
+    // padding words of every block: code 0 into the trash entries behind the group's accumulators
+    parallel_for(N, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++)
+            for (uint32_t g = 0; g < NG; g++)
+            {
+                const uint64_t b0 = ((uint64_t) base[n] + (meta[n * row + g] & 0xffffu)) * 8u;
+                const uint64_t b1 = ((uint64_t) base[n] + (meta[n * row + g + 1] & 0xffffu)) * 8u;
+                for (uint64_t p = b0 + cnt[n * NG + g]; p < b1; p++) words[p] = (uint16_t) ((groups[g].n_acc + (uint32_t) (p & (EV_TRASH - 1u))) << code_bits);
+            }
+    });
+    std::vector<uint32_t> chunk_core(h.n_slots / 64, 0u);
+    for (uint32_t k = 0; k < h.n_cores; k++)
+        for (uint32_t q = 0; q < (h.core_ncount[k] + 63u) / 64u; q++) chunk_core[h.core_nbase[k] / 64u + q] = k;
+    lut.resize(32, 0.0);
+    TRY(upload(c, groups.data(), groups.size(), &im.ev_group));
+    TRY(upload(c, base.data(), base.size(), &im.ev_base));
+    TRY(upload(c, meta.data(), meta.size(), &im.ev_meta));
+    TRY(upload(c, words.data(), words.size(), &im.ev_words));
+    TRY(upload(c, chunk_core.data(), chunk_core.size(), &im.ev_chunk_core));
+    TRY(upload(c, lut.data(), lut.size(), &im.ev_lut));
+    TRY(upload(c, h.core_axon_in_latency, h.n_cores, &im.core_ain_lat));
+    TRY(upload(c, ev_lat.data(), ev_lat.size(), &im.core_event_lat));
+    im.ev_groups = NG;
+    im.ev_segments = segments;
+    im.ev_seg_tiles = seg_tiles;
+    im.ev_tiles = n_tiles;
+    im.ev_shift = shift;
+    im.ev_code_bits = code_bits;
+    im.ev_always = want >= 2 ? 1u : 0u;
+    // the per-step decision rides on the push machinery (reduce_l2 decides, reduce_l1 prices the per-core counters)
+    im.push_cap = h.n_slots / WAVE;
+    im.push_always = im.ev_always;
+    // the gather moves a few times the bytes of the stream per event: up to this many synaptic events, a step goes by events
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, h.n_synapses / 8u);
+    if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
+    TRY(dalloc(c, 8, &c->st.push_count));
+    TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
+    c->layout_bytes[9] = total_units * 16ull;
+    c->layout_bytes[10] = meta.size() * 4ull + base.size() * 4ull;
+    c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
+    c->ev_lpb = c->ev_avg_block > 32.0 ? 8 : 4; // lanes (16-byte units) per block and batch
+    if (const char *env = std::getenv("SANAFE_EVENT_LPB")) c->ev_lpb = std::atoi(env) == 8 ? 8 : 4;
     return 0;
 }
 
@@ -1270,7 +1501,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // the local spike bitmap is this chip's window of the global one: local delivery can start right after the
     // neuron launch, and the multi-GPU exchange gathers in place
     // (+ zero words past the end: the last 256-slot window of bitmap axon records, the bit padding entries of the ordered layout probe)
-    TRYC(dalloc(c, h.n_global_slots / 32 + 16, &st.bits_global));
+    TRYC(dalloc(c, h.n_global_slots / 32 + 64, &st.bits_global)); // (+ the rest of the event kernel's last 1,024-slot tile)
     st.bits_local = st.bits_global + h.slot_offset / 32;
     TRYC(dalloc(c, 2 * (size_t) im.n_wgs * PARTS_PER_WG, &st.wg_part));
     TRYC(dalloc(c, 2 * (size_t) h.n_slices, &st.slice_proc));
@@ -1332,7 +1563,16 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
     // first launch.
     st.push_count = st.push_core_cnt = nullptr;
-    TRYC(build_push(c, h)); // (before the kernel is picked: chips with push tables run the PUSH instantiations)
+    im.ev_groups = 0;
+    im.ev_always = 0;
+    {
+        // (before the kernel is picked: chips with push tables or the event layout run the PUSH instantiations)
+        const bool force_event = std::getenv("SANAFE_EVENT") != nullptr && std::atoi(std::getenv("SANAFE_EVENT")) >= 1;
+        if (force_event) TRYC(build_event(c, h));
+        if (im.ev_groups == 0u) TRYC(build_push(c, h));
+        // chips too big for push tables (a global atomic per event) get the event layout (LDS accumulators) when it pays
+        if (im.ev_groups == 0u && im.push_cap == 0u && !force_event) TRYC(build_event(c, h));
+    }
     if (c->syn_format == 8)
     {
         // the whole spike bitmap in LDS when it leaves room for four workgroups per CU
@@ -1371,6 +1611,11 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         HIPC(hipFuncSetAttribute(v->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int) c->deliver_lds));
         c->deliver_fn = v->fn;
         c->deliver_block = (uint32_t) v->block;
+        if (im.ev_groups != 0u)
+        {
+            if (im.ev_code_bits == 4u) c->event_fn = c->ev_lpb == 8 ? reinterpret_cast<const void *>(event_deliver_kernel<8, 4>) : reinterpret_cast<const void *>(event_deliver_kernel<4, 4>);
+            else c->event_fn = c->ev_lpb == 8 ? reinterpret_cast<const void *>(event_deliver_kernel<8, 5>) : reinterpret_cast<const void *>(event_deliver_kernel<4, 5>);
+        }
     }
     HIPC(hipDeviceSynchronize());
     *out = c;
@@ -1524,6 +1769,24 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 // Delivers the slices [first, first + count) of the launch order.
 static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
+    if (c->im.ev_groups != 0u)
+    {
+        // Chips with the event layout: the streaming kernel (its PUSH instantiation returns at once on a step the device
+        // decided to deliver by events) and the event kernel (returns at once on the others); both read the word reduce_l2
+        // left for this step.  The event kernel takes the whole source space at once: it goes with the last slices.
+        long long done = c->t_host;
+        if (count > 0 && c->im.ev_always == 0u)
+        {
+            void *args[] = {&c->im, &c->st, &done, &first};
+            HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(count), dim3(c->deliver_block), args, c->deliver_lds, c->stream));
+        }
+        if (first + count == c->im.n_slices)
+        {
+            void *args[] = {&c->im, &c->st, &done};
+            HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(256), args, 0, c->stream));
+        }
+        return 0;
+    }
     if (c->im.push_cap != 0u && c->im.push_always != 0u) return 0; // the neuron launch delivered the step's spikes itself
     if (c->syn_format == 8)
     {
@@ -1575,10 +1838,9 @@ static int flush_pending(sanafe_hip_chip *c)
         c->pend2 = c->pend1;
         c->pend1.valid = 0;
     }
-    // The step pipeline is empty: no launch in flight reads a push / pull decision any more, and the reductions that would
-    // have renewed the decisions rode in no neuron launch.  Back to "pull" for the next steps -- a caller that steps one
-    // timestep per call must not stay on a stale "push" while its network's activity grows.
-    if (flushed && c->im.push_cap != 0u && c->im.push_always == 0u) HIPCHK(hipMemsetAsync(c->st.push_count, 0, 3 * sizeof(uint32_t), c->stream));
+    // (push / pull decisions need no reset here: level 2 of every step -- in a neuron launch or in reduce_kernel above --
+    //  renews the word of the step three after it, reduce_l2)
+    (void) flushed;
     return 0;
 }
 
@@ -1687,6 +1949,20 @@ extern "C" int sanafe_hip_get_push_info(sanafe_hip_chip *c, uint32_t *enabled, u
             HIPCHK(hipStreamSynchronize(c->stream));
         }
     }
+    return 0;
+}
+extern "C" int sanafe_hip_get_event_info(sanafe_hip_chip *c, uint64_t *info, int n)
+{
+    if (!c || !info || n < SANAFE_HIP_EVENT_INFO_FIELDS) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    info[0] = c->im.ev_groups;
+    info[1] = c->im.ev_groups ? c->im.ev_segments : 0;
+    info[2] = c->layout_bytes[9] / 16u;
+    info[3] = (uint64_t) (c->ev_avg_block * 1000.0);
+    info[4] = c->im.ev_groups ? (uint64_t) c->ev_lpb : 0;
+    info[5] = c->im.ev_groups ? c->im.ev_code_bits : 0;
+    info[6] = c->im.ev_groups ? (uint64_t) c->im.ev_shift : 0;
+    info[7] = c->im.ev_groups ? c->im.ev_always : 0;
+    info[8] = c->im.ev_groups ? c->im.push_max_events : 0;
     return 0;
 }
 extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32_t *n_compact_slices)

@@ -177,6 +177,36 @@ struct DevImage
                                         // padding entries point at bit n_global_slots, which never fires
     const double *ord_w;                // the entries' weights (no dictionary), same indexing
     int ord_dict;                       // weights are 5-bit codes into weight_lut
+    // Event-driven delivery (event_deliver_kernel): the reference touches only the synapses behind the messages that arrived
+    // (src/chip.cpp:738-764).  A second copy of the format-7 words, regrouped SOURCE-NEURON-major: the destination cores are
+    // cut into groups whose accumulators fit one workgroup's LDS (EvGroup), and the words a neuron sends into a group lie in
+    // one contiguous, 16-byte aligned BLOCK, the blocks of a neuron group after group.  A step with few spikes then reads the
+    // spike bitmap, per (fired neuron, group) one 8-byte table entry, and that neuron's blocks -- work and bytes in proportion
+    // to the step's synaptic events instead of to the chip's synapses.  Which kernel delivers a step is decided on the device
+    // like push delivery (push_count, push_max_events); both are exact for any activity.  ev_groups == 0: not built.
+    uint32_t ev_groups;           // core groups
+    uint32_t ev_segments;         // the source space is cut into this many segments of ev_seg_tiles tiles: grid = groups x segments
+    uint32_t ev_seg_tiles;        // 1,024-slot tiles of the global source space per segment (<= 64: list entries are 16 bits)
+    uint32_t ev_tiles;            // tiles in all: n_global_slots / 1024, rounded up
+    uint32_t ev_always;           // 1: every step is delivered by events, the streaming kernel is never launched (tests)
+    int ev_shift;                 // every event adds weight + 2^ev_shift; bounds proven per (segment, accumulator)
+    const struct EvGroup *ev_group;   // [ev_groups]
+    const uint32_t *ev_base;      // [n_global_slots + 1] first 16-byte unit of each source neuron's blocks
+    const uint32_t *ev_meta;      // [n_global_slots][ev_groups + 1]: bits 0-15 first unit of the neuron's block for the group,
+                                  // relative to ev_base; bits 16-31 which cores of the group it reaches (one message each).
+                                  // Entry [ev_groups]: the end.  A block's length is the next entry's offset minus its own.
+    const uint16_t *ev_words;     // weight code (ev_code_bits) | accumulator index << ev_code_bits; padding words add into the
+                                  // trash entries behind the group's accumulators
+    const uint32_t *ev_chunk_core; // [n_slots / 64] local core of each 64-slot chunk
+    const double *ev_lut;         // [32] the chip's distinct weight values, densely coded
+    uint32_t ev_code_bits;        // 4 (<= 16 distinct weights: 4,096 accumulators per group) or 5 (2,048)
+};
+// One group of destination cores of the event layout: consecutive cores whose slots (each core padded to 64) span at most
+// 2^(16 - code bits) - 64 accumulators; accumulator i of the group is local slot slot0 + i.
+struct EvGroup
+{
+    uint32_t core0, n_cores; // <= 16 cores: one bit each in ev_meta
+    uint32_t slot0, n_acc;   // n_acc: a multiple of 64
 };
 struct PushEntry
 {
@@ -359,7 +389,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
     if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
-        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, (sa.push_buf + 1) % 3);
+        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, l2.push_buf); // (step s decides for step s + 3: the same slot)
         const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
         if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
         return;
@@ -414,7 +444,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     // scalar cache in the first wavefronts of a launch, and a wait for it placed before the vector loads -- where the compiler
     // puts it when left alone -- costs every wavefront a memory round trip (4.5 us per launch on the 1 M neuron chip).
     asm volatile("" ::: "memory");
-    const bool push_now = im.push_cap != 0u && (im.push_always != 0u || st.push_count[sa.push_buf] != 0u);
+    const bool push_now = im.push_cap != 0u && im.ev_groups == 0u && (im.push_always != 0u || st.push_count[sa.push_buf] != 0u); // (event chips decide the same way, but their spikes are delivered by event_deliver_kernel)
     if (!UNI)
     {
         // ---- class tables -> LDS, in flight together with the slot loads ----
@@ -1805,6 +1835,184 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 }
 
 // ---------------------------------------------------------------------------------------
+// K2e: EVENT-DRIVEN spike delivery (DevImage::ev_*): work in proportion to the step's synaptic events, like the reference's
+// process_messages / process_message (src/chip.cpp:656-764), for steps in which a few percent of the neurons fire.
+//
+//   grid = 8 x ceil(groups / 8) x segments, block = 256.  A workgroup owns the LDS accumulators of ONE group of destination
+//   cores and ONE segment of the source space.  Workgroups b and b + 8 share an XCD (observed round-robin placement; speed
+//   only): consecutive workgroups of an XCD take neighbouring groups of the same segment, so the 128-byte lines that hold a
+//   fired neuron's blocks for neighbouring groups are fetched into that XCD's L2 once.
+//   Every wavefront (no barrier inside the loop)
+//     1. scans 1,024-slot tiles of its segment of the spike bitmap and lists the neurons that fired (16-bit entries in LDS);
+//     2. drains the list in batches of 64 / LPB neurons, LPB lanes per neuron: table entry of (neuron, group) -> where the
+//        block starts, how many 16-byte units it holds, which cores it reaches; every lane takes one unit = 8 words and adds
+//        weight + 2^shift into the group's 32-bit integer accumulators (sums of integers: exact in any order).  Three stages
+//        in flight: the table entries of batch b + 2 and the words of batch b + 1 are loading while batch b is added.
+//   Write-back as in deliver_kernel (count and sum separate again), with atomics: the segments of a group share its neurons.
+//   Messages and events per destination core go to the push counters that level 1 of the step reduction prices.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t EV_TILE = 1024;      // source slots per tile: 16 per lane
+constexpr uint32_t EV_LIST_CAP = 1536;  // per wavefront: a tile adds at most 1,024 entries, the list is drained from 512 on
+constexpr uint32_t EV_DRAIN_AT = 512;
+constexpr uint32_t EV_TRASH = 64;       // accumulators behind a group's own that padding words add into
+template <int LPB, int CODE_BITS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+{
+    constexpr uint32_t ACC_MAX = 1u << (16 - CODE_BITS);
+    constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
+    constexpr uint32_t NB = WAVE / LPB; // neurons per batch
+    __shared__ uint32_t s_acc[ACC_MAX];
+    __shared__ uint16_t s_lut16[32];
+    __shared__ uint16_t s_list[4][EV_LIST_CAP];
+    __shared__ uint32_t s_msgs[16], s_events[16];
+    if (im.ev_always == 0u && st.push_count[(uint32_t) (done % 3)] == 0u) return; // this step is streamed by deliver_kernel
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
+    // workgroup -> (group, segment): blocks b and b + 8 share an XCD
+    const uint32_t gpx = (im.ev_groups + 7u) / 8u;
+    const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
+    const uint32_t g = xcd * gpx + k % gpx, seg = k / gpx;
+    if (g >= im.ev_groups) return; // (workgroup-uniform)
+    const EvGroup eg = im.ev_group[g];
+    for (uint32_t i = threadIdx.x; i < ACC_MAX; i += 256) s_acc[i] = 0u;
+    if (threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.ev_lut[threadIdx.x] + (1 << im.ev_shift));
+    if (threadIdx.x < 16) s_msgs[threadIdx.x] = s_events[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
+    const uint32_t seg_slot0 = tile0 * EV_TILE;
+    const uint32_t row = im.ev_groups + 1u; // entries of a neuron in ev_meta
+    uint16_t *list = s_list[wave];
+    const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
+    uint32_t msg_cnt[(16 + LPB - 1) / LPB];        // messages to core q, q + LPB, ... of the group, over this lane's neurons
+#pragma unroll
+    for (uint32_t m = 0; m < (16 + LPB - 1) / LPB; m++) msg_cnt[m] = 0u;
+    typedef __attribute__((address_space(3))) uint32_t lds_u32;
+    auto add8 = [&](const uint4 &w4) {
+        const uint32_t d4[4] = {w4.x, w4.y, w4.z, w4.w};
+        uint32_t wv[8];
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+        {
+            wv[2 * h] = s_lut16[d4[h] & CODE_MASK];
+            wv[2 * h + 1] = s_lut16[(d4[h] >> 16) & CODE_MASK];
+        }
+#pragma unroll
+        for (int h = 0; h < 4; h++)
+        {
+            __hip_atomic_fetch_add((lds_u32 *) &s_acc[(d4[h] & 0xffffu) >> CODE_BITS], wv[2 * h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add((lds_u32 *) &s_acc[d4[h] >> (16 + CODE_BITS)], wv[2 * h + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    struct Meta
+    {
+        uint32_t m0, m1, base;
+        bool have;
+    };
+    struct Words
+    {
+        uint4 w;
+        uint32_t unit0, units;
+    };
+    const uint4 *words = reinterpret_cast<const uint4 *>(im.ev_words);
+    auto drain = [&](uint32_t len) {
+        wave_lds_fence(); // the list entries the lanes wrote
+        auto fetch_meta = [&](uint32_t b, Meta &m) {
+            m.have = b + j < len;
+            const uint32_t f = seg_slot0 + (uint32_t) list[m.have ? b + j : b];
+            const uint32_t *mrow = im.ev_meta + (size_t) f * row + g;
+            m.m0 = mrow[0];
+            m.m1 = mrow[1];
+            m.base = im.ev_base[f];
+        };
+        auto fetch_words = [&](const Meta &m, Words &w) {
+            w.units = m.have ? (m.m1 - m.m0) & 0xffffu : 0u;
+            w.unit0 = m.base + (m.m0 & 0xffffu);
+            // (lanes without a unit read the block's first unit -- or, for an empty block, whatever follows: the array is padded)
+            w.w = load_stream16(words + (size_t) w.unit0 + (q < w.units ? q : 0u));
+            if (m.have)
+            {
+                const uint32_t mask = m.m0 >> 16;
+#pragma unroll
+                for (uint32_t mm = 0; mm < (16 + LPB - 1) / LPB; mm++) msg_cnt[mm] += (mask >> (q + mm * LPB)) & 1u;
+            }
+        };
+        Meta ma;
+        Words wb;
+        fetch_meta(0u, ma);
+        fetch_words(ma, wb);
+        if (NB < len) fetch_meta(NB, ma);
+        for (uint32_t b = 0; b < len; b += NB) // (wave-uniform bounds)
+        {
+            const Words wc = wb;
+            if (b + NB < len) fetch_words(ma, wb);
+            if (b + 2u * NB < len) fetch_meta(b + 2u * NB, ma);
+            if (q < wc.units) add8(wc.w);
+            // blocks of more than LPB units: the rest, LPB units at a time
+            for (uint32_t u = q + LPB; __ballot(u < wc.units) != 0ull; u += LPB)
+                if (u < wc.units) add8(load_stream16(words + (size_t) wc.unit0 + u));
+        }
+        wave_lds_fence(); // the list is rewritten
+    };
+    uint32_t len = 0;
+    for (uint32_t tile = tile0 + wave; tile < tile1; tile += 4u) // (wave-uniform bounds)
+    {
+        // 16 slots per lane: lanes 2i and 2i + 1 share a word of the bitmap
+        const uint32_t w32 = st.bits_global[tile * (EV_TILE / 32u) + (lane >> 1)];
+        uint32_t half = (w32 >> (16u * (lane & 1u))) & 0xffffu;
+        const uint32_t cnt = (uint32_t) __popc(half);
+        const uint32_t incl = wave_inclusive_scan(cnt);
+        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
+        uint32_t pos = len + incl - cnt;
+        const uint32_t rel0 = (tile - tile0) * EV_TILE + lane * 16u;
+        while (half != 0u)
+        {
+            list[pos++] = (uint16_t) (rel0 + (uint32_t) __builtin_ctz(half));
+            half &= half - 1u;
+        }
+        len += total;
+        if (len >= EV_DRAIN_AT)
+        {
+            drain(len);
+            len = 0;
+        }
+    }
+    if (len > 0u) drain(len);
+    // messages per core of the group: lanes with the same q hold counts of the same cores
+#pragma unroll
+    for (uint32_t mm = 0; mm < (16 + LPB - 1) / LPB; mm++)
+        if (msg_cnt[mm] != 0u && q + mm * LPB < 16u) atomicAdd(&s_msgs[q + mm * LPB], msg_cnt[mm]);
+    __syncthreads(); // every wavefront's additions are in the accumulators
+    const long long t = done + 1;
+    const size_t ring_row = (size_t) ((t + 1) % im.ring_slots) * im.n_slots;
+    for (uint32_t i0 = wave * WAVE; i0 < eg.n_acc; i0 += 256u) // (n_acc: a multiple of 64 -> wave-uniform)
+    {
+        const uint32_t i = i0 + lane;
+        const uint32_t v = s_acc[i];
+        uint32_t events = 0;
+        if (v != 0u)
+        {
+            // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (proven by the host per segment and accumulator)
+            events = (v + (1u << (im.ev_shift - 1))) >> im.ev_shift;
+            const double sum = (double) (int) (v - (events << im.ev_shift));
+            const size_t gi = ring_row + eg.slot0 + i;
+            if (im.ev_segments > 1u) atomicAdd(&st.ring[gi], sum);
+            else st.ring[gi] = sum; // (no synaptic delays: the neuron launch left every consumed entry at 0.0)
+            st.ring_valid[gi] = 1;
+        }
+        const long long ev = wave_sum((long long) events);
+        if (lane == 0 && ev != 0) atomicAdd(&s_events[im.ev_chunk_core[(eg.slot0 + i0) >> 6] - eg.core0], (uint32_t) ev);
+    }
+    __syncthreads();
+    if (threadIdx.x < eg.n_cores)
+    {
+        uint32_t *cnt = st.push_core_cnt + ((size_t) (uint32_t) (done % 3) * im.n_cores + eg.core0 + threadIdx.x) * 2u;
+        if (s_msgs[threadIdx.x] != 0u) atomicAdd(&cnt[0], s_msgs[threadIdx.x]);
+        if (s_events[threadIdx.x] != 0u) atomicAdd(&cnt[1], s_events[threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // K2o: ORDERED spike delivery, for chips with non-integer weights (syn_format 8).
 //
 // fp64 addition does not associate: the reference adds a step's synaptic currents into an accumulator one by one, in
@@ -2213,7 +2421,11 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
             st.step_log[prev.rec_index % st.log_cap] = ts;
             *st.rec = prev.rec_index + 1;
         }
-        // push or pull for the step AFTER the one whose neuron launch this reduction rides in: few events three steps before it -> push
+        // push (or event delivery) or pull for the step THREE after this one -- the step whose number % 3 is this step's, so the
+        // word this step's own launches read is renewed once all of them are done (level 1 of this step ran in an earlier
+        // launch).  Whoever runs level 2 decides: the neuron launch two steps later or reduce_kernel (a flush), so a caller
+        // that flushes after every step still gets fresh decisions, and a flush in the middle of a split step (level 2 of the
+        // step BEFORE it) leaves that step's own word alone.
         if (im.push_cap != 0u && decide_buf >= 0) st.push_count[decide_buf] = (events <= (long long) im.push_max_events) ? 1u : 0u;
         if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;
@@ -2235,7 +2447,7 @@ __global__ void state_log_kernel(const double *v, const double *icur, const uint
 __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PendStep l1, PendStep l2)
 {
     const int wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, -1);
+    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, l2.push_buf);
     const uint32_t group = blockIdx.x * (REDUCE_BLOCK / WAVE) + (uint32_t) wave;
     if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
 }

@@ -1,0 +1,143 @@
+"""Event-driven delivery (event_deliver_kernel, DevImage::ev_*) against the oracle.
+
+The reference walks only the synapses behind the messages that arrived (src/chip.cpp:738-764).  On chips too large for
+push tables the device keeps a second, source-neuron-major copy of the format-7 synapse words; a step with few spikes
+is delivered from it -- spike bitmap -> fired neurons -> their blocks of words -> LDS integer accumulators -- and a
+busy step by the streaming kernel, decided per step on the device.  Both must give the oracle's spikes, potentials,
+counters, energies and sim_time."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import nets  # noqa: E402
+from oracle.oracle import OracleChip  # noqa: E402
+from test_gpu_parity import DBL_KEYS, INT_KEYS, check_batched, check_stepwise  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("p_fire,segments,group_cores,lpb", [(0.02, "1", "16", "4"), (0.02, "3", "3", "8"), (0.5, "2", "5", "4")])
+def test_every_step_by_events_matches_the_oracle(S, monkeypatch, p_fire, segments, group_cores, lpb):
+    """SANAFE_EVENT=2: every step goes through the event kernel, the streaming kernel is never launched.  One and several
+    segments of the source space (the last one empty: 4 tiles over 3 segments of 2), core groups that do not fill the
+    8-way block -> group mapping, both lane shapes, sparse and dense activity (blocks longer than one batch slot)."""
+    monkeypatch.setenv("SANAFE_EVENT", "2")
+    monkeypatch.setenv("SANAFE_EVENT_SEGMENTS", segments)
+    monkeypatch.setenv("SANAFE_EVENT_GROUP_CORES", group_cores)
+    monkeypatch.setenv("SANAFE_EVENT_LPB", lpb)
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=90 if p_fire > 0.1 else 30, arch_kind="loihi",
+                                  p_fire=p_fire, seed=51)
+    chip, _ = check_stepwise(S, arch, net, steps=14)
+    lay = chip.device_layout()
+    ev = lay["event_layout"]
+    assert lay["syn_format"] == 7 and ev is not None and ev["always"], lay
+    assert ev["segments"] == int(segments) and ev["lanes_per_block"] == int(lpb), ev
+    assert ev["groups"] == {"16": 2, "3": 6, "5": 4}[group_cores], ev  # (at most 15 cores of 256 slots fit 4,096 - 64 accumulators)
+    assert lay["pushed_steps"] == 14, lay  # steps delivered by events are counted like pushed ones
+
+
+def test_event_or_stream_decided_per_step(S, monkeypatch):
+    """SANAFE_EVENT=1: the device decides per step (few events three steps earlier -> events).  One sim() call, so the
+    decision rides in the step pipeline; a network whose activity starts high and settles, so both kernels run.  Same
+    result as the oracle and as the chip without the event layout."""
+    monkeypatch.setenv("SANAFE_EVENT", "1")
+    monkeypatch.setenv("SANAFE_EVENT_MAX_EVENTS", "7400")  # 4,530 events in step 1, 7,000-8,100 from step 9 on
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.05, seed=52)
+    chip, orc, tot = check_batched(S, arch, net, steps=40)
+    lay = chip.device_layout()
+    assert lay["event_layout"] is not None and not lay["event_layout"]["always"], lay
+    assert 6 <= lay["pushed_steps"] <= 36, lay  # some steps by events, the first three (no decision yet) and the busy ones streamed
+    monkeypatch.setenv("SANAFE_EVENT", "0")
+    monkeypatch.setenv("SANAFE_PUSH", "0")
+    plain = S.SpikingChip(arch)
+    plain.load(net)
+    assert plain.device_layout()["event_layout"] is None
+    a = plain.run(40, "simple")
+    for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
+        assert a[k] == tot[k], k
+    for k in DBL_KEYS:
+        assert a[k] == pytest.approx(tot[k], rel=1e-12, abs=1e-30), k
+    assert np.array_equal(plain.potentials(), chip.potentials())
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("p_fire", [0.01, 0.3])
+def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire):
+    """SURVEY 8(d)'s shape of C3 -- 262,144 source neurons on 1,024 cores of 256, 16 destination cores that hear from
+    (nearly) every neuron -- delivered by events at p_fire 0.01 and at the headline's 0.3: ten steps
+    against the oracle.  (The 16 destination cores lie in 16 different core groups: blocks of ~2.6 words, far below what the
+    layout is built for by default -- SANAFE_EVENT=2 forces it; the table walk, the masks and the bounds are the same.)"""
+    arch, net = nets.c3_delivery_shape(S, cores=1024, neurons_per_core=256, dest_cores=16, out_degree=41, p_fire=p_fire, delays=False)
+    orc = OracleChip(S.to_desc(arch, net))
+    monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")
+    monkeypatch.setenv("SANAFE_EVENT", "2")
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    lay, info = chip.device_layout(), chip.info()
+    ev = lay["event_layout"]
+    assert lay["syn_format"] == 7 and lay["n_bitmap_slices"] == info["n_slices"] and ev is not None and ev["always"], lay
+    assert ev["groups"] == 69 and ev["segments"] == 8 and ev["code_bits"] == 4, ev  # 15 cores of 256 per group, 16 weight values
+    fired = 0
+    for t in range(10):
+        a, b = chip.run(1, "simple", record=True), orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k)
+        st = orc.status()
+        assert np.array_equal(chip.status(), st), t
+        assert np.array_equal(chip.potentials(), orc.potentials()), t
+        fired += int((st == 3).sum())
+    assert fired > 0.8 * p_fire * 10 * 262144
+
+
+@pytest.mark.parametrize("kind", ["push", "event"])
+def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind):
+    """sanafe_hip_step_neurons, then a call that flushes the pending reductions (synchronize, device_layout's
+    push info, read_totals), then sanafe_hip_step_deliver.  The flush must not clear the push / pull word the neuron launch
+    has already read: the delivery launch and level 1 of the step reduction have to see the same decision, or a pushed step
+    is delivered twice and its per-core counters leak into a later step.  Against the oracle and against SANAFE_PUSH=0."""
+    if kind == "push":
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
+        monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")
+    else:
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.02, seed=44)
+        monkeypatch.setenv("SANAFE_EVENT", "1")
+        monkeypatch.setenv("SANAFE_EVENT_MAX_EVENTS", "1000000")
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    orc = OracleChip(S.to_desc(arch, net))
+    lay = chip.device_layout()
+    assert lay["push_enabled"] and not lay["push_only"], lay
+    assert (lay["event_layout"] is not None) == (kind == "event")
+    # a few whole steps first, in ONE call, so that decisions exist for the steps that follow (they ride in the neuron launches)
+    chip.run(6, "simple")
+    for _ in range(6):
+        orc.step("simple")
+    before, pushed_before = chip.read_totals(), chip.device_layout()["pushed_steps"]
+    ref = {k: 0 for _, k in INT_KEYS}
+    ref_d = {k: 0.0 for k in DBL_KEYS}
+    # Every fourth split step has a flushing call between its halves.  The steps in between run without any read-back, so
+    # that level 2 of the reduction rides in the neuron launches and leaves decisions: the step with the flush is one the
+    # device decided to push (few events two and three steps earlier).
+    for t in range(16):
+        chip.step_neurons()
+        if t % 4 == 3:
+            (chip.synchronize, chip.device_layout, chip.read_totals)[(t // 4) % 3]()
+        chip.step_deliver("simple")
+        b = orc.step("simple")
+        for _, kb in INT_KEYS:
+            ref[kb] += b[kb]
+        for k in DBL_KEYS:
+            ref_d[k] += b[k]
+    assert np.array_equal(chip.status(), orc.status())
+    assert np.array_equal(chip.potentials(), orc.potentials())
+    after = chip.read_totals()
+    for ka, kb in INT_KEYS:
+        assert after[ka] - before[ka] == ref[kb], ka
+    for k in DBL_KEYS:
+        assert after[k] - before[k] == pytest.approx(ref_d[k], rel=1e-9, abs=1e-30), k
+    assert chip.device_layout()["pushed_steps"] - pushed_before >= 6  # incl. the four steps with a flush between their halves
