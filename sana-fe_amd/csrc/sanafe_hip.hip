@@ -120,6 +120,7 @@ struct sanafe_hip_chip
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     const void *event_fn{nullptr};   // event_deliver_kernel instantiation (chips with the event layout, DevImage::ev_*)
     int ev_lpb{4};                   // its lanes per block
+    int ev_waves{8};                 // its wavefronts per workgroup
     double ev_avg_block{0.0};        // words per (source neuron, core group) block
     uint32_t ev_grid{0};
     uint32_t deliver_block{0};
@@ -460,6 +461,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     if (c->syn_format != 7 || c->n_bitmap_slices == 0 || c->n_bitmap_slices != h.n_slices || c->has_delay || im.has_last || h.n_taps != 0 ||
             h.n_synapses == 0 || h.ax_lat_class == nullptr || h.n_slots / 64 == 0)
         return 0;
+    if (c->uni && c->neuron_model == SANAFE_SOMA_TRUENORTH) return 0; // (its neuron kernel has no registers to spare for the partial rows)
     for (uint32_t g = 0; g < h.n_slots; g++)
         if ((h.slot_cls[g] & 7u) == SANAFE_SOMA_HOST) return 0; // their spikes are set after the neuron launch
     // the dictionary, densely coded
@@ -552,8 +554,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     const uint32_t n_tiles = (uint32_t) ((N + EV_TILE - 1) / EV_TILE);
     uint32_t segments = 8;
     if (const char *env = std::getenv("SANAFE_EVENT_SEGMENTS")) segments = (uint32_t) std::max(1L, std::atol(env));
-    segments = std::min(segments, n_tiles);
-    segments = std::max(segments, (n_tiles + 63u) / 64u);
+    segments = std::min(std::min(segments, n_tiles), EV_MAX_SEGMENTS); // (one row of partials per segment, DevState::ev_part)
     // pass 2: offsets.  meta[n][g] = first unit of the block (relative to the neuron's base) | mask << 16; meta[n][NG] = end
     std::vector<uint32_t> meta(N * row, 0u);
     std::vector<uint32_t> base(N + 1, 0u);
@@ -662,6 +663,11 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
     TRY(dalloc(c, 8, &c->st.push_count));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
+    TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
+    TRY(dalloc(c, 1, &c->st.ev_done));
+    HIPCHK(hipMemset(c->st.ev_done, 0xff, sizeof(long long))); // -1: nothing pending
+    c->ev_waves = 8;
+    if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 16 ? 16 : std::atoi(env) == 4 ? 4 : 8;
     c->layout_bytes[9] = total_units * 16ull;
     c->layout_bytes[10] = meta.size() * 4ull + base.size() * 4ull;
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
@@ -1613,8 +1619,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->deliver_block = (uint32_t) v->block;
         if (im.ev_groups != 0u)
         {
-            if (im.ev_code_bits == 4u) c->event_fn = c->ev_lpb == 8 ? reinterpret_cast<const void *>(event_deliver_kernel<8, 4>) : reinterpret_cast<const void *>(event_deliver_kernel<4, 4>);
-            else c->event_fn = c->ev_lpb == 8 ? reinterpret_cast<const void *>(event_deliver_kernel<8, 5>) : reinterpret_cast<const void *>(event_deliver_kernel<4, 5>);
+#define SANAFE_EV(L, B, W) if (c->ev_lpb == L && im.ev_code_bits == B && c->ev_waves == W) c->event_fn = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W>)
+            SANAFE_EV(4, 4, 4); SANAFE_EV(4, 4, 8); SANAFE_EV(4, 4, 16); SANAFE_EV(8, 4, 4); SANAFE_EV(8, 4, 8); SANAFE_EV(8, 4, 16);
+            SANAFE_EV(4, 5, 4); SANAFE_EV(4, 5, 8); SANAFE_EV(4, 5, 16); SANAFE_EV(8, 5, 4); SANAFE_EV(8, 5, 8); SANAFE_EV(8, 5, 16);
+#undef SANAFE_EV
         }
     }
     HIPC(hipDeviceSynchronize());
@@ -1750,6 +1758,7 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     const size_t nslot = (size_t) ((sa.t + 1) % c->im.ring_slots);
     sa.ring_next = c->st.ring + nslot * c->im.n_slots;
     sa.rvalid_next = c->st.ring_valid + nslot * c->im.n_slots;
+    sa.ev_part = c->im.ev_groups != 0u ? c->st.ev_part : nullptr;
     if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
     if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
     const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
@@ -1783,7 +1792,7 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
         if (first + count == c->im.n_slices)
         {
             void *args[] = {&c->im, &c->st, &done};
-            HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(256), args, 0, c->stream));
+            HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(64u * (uint32_t) c->ev_waves), args, 0, c->stream));
         }
         return 0;
     }
@@ -1841,6 +1850,17 @@ static int flush_pending(sanafe_hip_chip *c)
     // (push / pull decisions need no reset here: level 2 of every step -- in a neuron launch or in reduce_kernel above --
     //  renews the word of the step three after it, reduce_l2)
     (void) flushed;
+    return 0;
+}
+
+// Chips with the event layout: a step delivered by events leaves the next step's input in DevState::ev_part; readers of the
+// time-step buffer on the host get it folded into the buffer row first.
+static int fold_event_partials(sanafe_hip_chip *c)
+{
+    if (c->im.ev_groups == 0u) return 0;
+    hipLaunchKernelGGL(event_fold_kernel, dim3((c->im.n_slots + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, (long long) c->t_host);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream));
     return 0;
 }
 
@@ -2482,6 +2502,7 @@ extern "C" int sanafe_hip_export_state(sanafe_hip_chip *c, sanafe_hip_state *o)
         return fail(SANAFE_HIP_ERR_INVALID, "null argument");
     HIPCHK(hipSetDevice(c->device));
     TRY(flush_pending(c));
+    TRY(fold_event_partials(c));
     const size_t n = c->im.n_slots, r = (size_t) c->im.ring_slots * n;
     o->timesteps = c->t_host;
     TRY(d2h(c, o->v, c->st.v, n));
@@ -2503,6 +2524,7 @@ extern "C" int sanafe_hip_import_state(sanafe_hip_chip *c, const sanafe_hip_stat
         return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     TRY(flush_pending(c));
+    if (c->im.ev_groups != 0u) HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream)); // the imported buffer rows hold all pending input
     const size_t n = c->im.n_slots, r = (size_t) c->im.ring_slots * n;
     TRY(h2d(c, c->st.v, in->v, n));
     TRY(h2d(c, c->st.icur, in->icur, n));
@@ -2531,6 +2553,7 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
     HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
     if (c->st.ring_last) HIPCHK(hipMemsetAsync(c->st.ring_last, 0, n * sizeof(uint32_t), c->stream));
     if (c->st.arrived) HIPCHK(hipMemsetAsync(c->st.arrived, 0, n, c->stream));
+    if (c->im.ev_groups != 0u) HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream)); // pending input of an event step is dropped like the buffer rows
     if (c->st.tap_v)
     {
         HIPCHK(hipMemsetAsync(c->st.tap_v, 0, (size_t) c->im.n_taps * 8 * sizeof(double), c->stream));

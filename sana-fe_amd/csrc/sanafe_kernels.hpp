@@ -272,7 +272,12 @@ struct DevState
     double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
     long long delay_log_cap;
+    // event-driven delivery (DevImage::ev_*): what a step delivered by events leaves for the NEXT step's neuron launch
+    uint32_t *ev_part;            // [EV_MAX_SEGMENTS][n_slots]: per segment of the source space and neuron, count * 2^ev_shift + sum
+                                  // of the weights that arrived (0: nothing); every workgroup stores all of its accumulators
+    long long *ev_done;           // Timestep::timestep of the last step that event_deliver_kernel delivered (-1: none pending)
 };
+constexpr uint32_t EV_MAX_SEGMENTS = 8;
 
 // Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles: Hillis-Steele inside
 // each 16-lane row, row_bcast:15 and row_bcast:31 across rows, total in lane 63.  Lanes without a source read
@@ -349,6 +354,7 @@ struct StepArgs
     int push_buf;        // (t - 1) % 3: the push decision word and the per-core counters of this step
     double *ring_next;   // the NEXT step's row of the time-step buffer (push chips: ring_slots >= 2), where pushed spikes land
     uint8_t *rvalid_next;
+    const uint32_t *ev_part; // chips with the event layout: DevState::ev_part (else NULL), n_slots entries per row
 };
 
 // A chip whose neurons all carry the same class word (one soma model, one parameter set, one cost class, one input
@@ -439,12 +445,26 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         if (MODEL != SANAFE_SOMA_TRUENORTH && im.any_refrac) rc_in = p_refrac[lane];
         if (!UNI && sa.ext_row != nullptr) ext_col = im.slot_ext[c0 + lane];
     }
+    // chips with the event layout: what event_deliver_kernel left per segment of the source space, loaded with everything
+    // else (used only when the PREVIOUS step was delivered by events: st.ev_done below)
+    uint32_t evp[EV_MAX_SEGMENTS];
+#pragma unroll
+    for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++) evp[q] = 0u;
+    // (not in the uniform TrueNorth instantiation, which sits at its 64-register budget: such chips get no event layout)
+    constexpr bool EV_OK = !(UNI && MODEL == SANAFE_SOMA_TRUENORTH);
+    const bool ev_chip = EV_OK && sa.ev_part != nullptr; // (a kernel argument: no load behind it)
+    if (ev_chip && active)
+    {
+#pragma unroll
+        for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++) evp[q] = sa.ev_part[(size_t) q * im.n_slots + c0 + lane];
+    }
     // push or pull for this step: written by reduce_l2 in the PREVIOUS neuron launch; the delivery launch and reduce_l1 read
     // the same word.  Loaded HERE, behind the per-slot loads: it is a dependent load (pointer, then word) that misses the
     // scalar cache in the first wavefronts of a launch, and a wait for it placed before the vector loads -- where the compiler
     // puts it when left alone -- costs every wavefront a memory round trip (4.5 us per launch on the 1 M neuron chip).
     asm volatile("" ::: "memory");
     const bool push_now = im.push_cap != 0u && im.ev_groups == 0u && (im.push_always != 0u || st.push_count[sa.push_buf] != 0u); // (event chips decide the same way, but their spikes are delivered by event_deliver_kernel)
+    const bool ev_in = ev_chip && *st.ev_done == sa.t - 1; // the previous step's input lies in the partial rows, not in the time-step buffer
     if (!UNI)
     {
         // ---- class tables -> LDS, in flight together with the slot loads ----
@@ -551,6 +571,25 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                     cur = in_value;
                     p_ring[lane] = 0.0;
                     p_rvalid[lane] = 0;
+                }
+                if (ev_in)
+                {
+                    // count * 2^shift + sum per segment (bounds proven per segment and accumulator): decoded one by one;
+                    // the sum of integers is the fp64 sum of the reference whatever the order
+                    long long tot = 0;
+                    uint32_t any = 0;
+#pragma unroll
+                    for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++)
+                    {
+                        const uint32_t n_ev = (evp[q] + (1u << (im.ev_shift - 1))) >> im.ev_shift;
+                        tot += (long long) (int) (evp[q] - (n_ev << im.ev_shift));
+                        any |= evp[q];
+                    }
+                    if (any != 0u)
+                    {
+                        has_in = true;
+                        cur = (double) tot; // (the buffer row of this step is empty: no other launch delivered into it)
+                    }
                 }
             }
             // host-generated value of a sequential source this neuron consumes at every update
@@ -1848,23 +1887,28 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 //        block starts, how many 16-byte units it holds, which cores it reaches; every lane takes one unit = 8 words and adds
 //        weight + 2^shift into the group's 32-bit integer accumulators (sums of integers: exact in any order).  Three stages
 //        in flight: the table entries of batch b + 2 and the words of batch b + 1 are loading while batch b is added.
-//   Write-back as in deliver_kernel (count and sum separate again), with atomics: the segments of a group share its neurons.
+//   Write-back: every accumulator (count * 2^shift + sum, untouched: 0) goes to the workgroup's segment row of
+//   DevState::ev_part with plain coalesced stores; the NEXT neuron launch adds a neuron's rows up (neuron_kernel: ev_in).
+//   The segments of a group share its neurons, and global fp64 atomics run memory-side at a fifth of the store rate: with
+//   atomics into the time-step buffer the write-back alone was ~13 us of a 38 us launch at 2 % activity.
 //   Messages and events per destination core go to the push counters that level 1 of the step reduction prices.
+//   WAVES wavefronts per workgroup share the accumulators: more loads in flight per CU without more rows to write back.
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t EV_TILE = 1024;      // source slots per tile: 16 per lane
-constexpr uint32_t EV_LIST_CAP = 1536;  // per wavefront: a tile adds at most 1,024 entries, the list is drained from 512 on
+constexpr uint32_t EV_LIST_CAP = 1536;  // per wavefront (16-bit entries): a tile adds at most 1,024, the list is drained from 512 on
 constexpr uint32_t EV_DRAIN_AT = 512;
 constexpr uint32_t EV_TRASH = 64;       // accumulators behind a group's own that padding words add into
-template <int LPB, int CODE_BITS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 8)))
+template <int LPB, int CODE_BITS, int WAVES>
+__global__ void __launch_bounds__(WAVES * WAVE)
 event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
     constexpr uint32_t ACC_MAX = 1u << (16 - CODE_BITS);
     constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
     constexpr uint32_t NB = WAVE / LPB; // neurons per batch
+    constexpr uint32_t BLOCK = WAVES * WAVE;
     __shared__ uint32_t s_acc[ACC_MAX];
     __shared__ uint16_t s_lut16[32];
-    __shared__ uint16_t s_list[4][EV_LIST_CAP];
+    __shared__ uint16_t s_list[WAVES][EV_LIST_CAP];
     __shared__ uint32_t s_msgs[16], s_events[16];
     if (im.ev_always == 0u && st.push_count[(uint32_t) (done % 3)] == 0u) return; // this step is streamed by deliver_kernel
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -1873,14 +1917,14 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     const uint32_t gpx = (im.ev_groups + 7u) / 8u;
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
     const uint32_t g = xcd * gpx + k % gpx, seg = k / gpx;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *st.ev_done = done + 1; // the next neuron launch reads its input from the partial rows
     if (g >= im.ev_groups) return; // (workgroup-uniform)
     const EvGroup eg = im.ev_group[g];
-    for (uint32_t i = threadIdx.x; i < ACC_MAX; i += 256) s_acc[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < ACC_MAX; i += BLOCK) s_acc[i] = 0u;
     if (threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.ev_lut[threadIdx.x] + (1 << im.ev_shift));
     if (threadIdx.x < 16) s_msgs[threadIdx.x] = s_events[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
-    const uint32_t seg_slot0 = tile0 * EV_TILE;
     const uint32_t row = im.ev_groups + 1u; // entries of a neuron in ev_meta
     uint16_t *list = s_list[wave];
     const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
@@ -1915,11 +1959,13 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         uint32_t unit0, units;
     };
     const uint4 *words = reinterpret_cast<const uint4 *>(im.ev_words);
-    auto drain = [&](uint32_t len) {
+    // list entries: source slot relative to the first slot of tile `list_tile0` (16 bits: the list is drained before it spans
+    // 64 tiles)
+    auto drain = [&](uint32_t len, uint32_t list_slot0) {
         wave_lds_fence(); // the list entries the lanes wrote
         auto fetch_meta = [&](uint32_t b, Meta &m) {
             m.have = b + j < len;
-            const uint32_t f = seg_slot0 + (uint32_t) list[m.have ? b + j : b];
+            const uint32_t f = list_slot0 + (uint32_t) list[m.have ? b + j : b];
             const uint32_t *mrow = im.ev_meta + (size_t) f * row + g;
             m.m0 = mrow[0];
             m.m1 = mrow[1];
@@ -1954,9 +2000,15 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         }
         wave_lds_fence(); // the list is rewritten
     };
-    uint32_t len = 0;
-    for (uint32_t tile = tile0 + wave; tile < tile1; tile += 4u) // (wave-uniform bounds)
+    uint32_t len = 0, list_tile0 = tile0;
+    for (uint32_t tile = tile0 + wave; tile < tile1; tile += (uint32_t) WAVES) // (wave-uniform bounds)
     {
+        if (len > 0u && tile - list_tile0 >= 64u)
+        {
+            drain(len, list_tile0 * EV_TILE);
+            len = 0;
+        }
+        if (len == 0u) list_tile0 = tile;
         // 16 slots per lane: lanes 2i and 2i + 1 share a word of the bitmap
         const uint32_t w32 = st.bits_global[tile * (EV_TILE / 32u) + (lane >> 1)];
         uint32_t half = (w32 >> (16u * (lane & 1u))) & 0xffffu;
@@ -1964,7 +2016,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         const uint32_t incl = wave_inclusive_scan(cnt);
         const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
         uint32_t pos = len + incl - cnt;
-        const uint32_t rel0 = (tile - tile0) * EV_TILE + lane * 16u;
+        const uint32_t rel0 = (tile - list_tile0) * EV_TILE + lane * 16u;
         while (half != 0u)
         {
             list[pos++] = (uint16_t) (rel0 + (uint32_t) __builtin_ctz(half));
@@ -1973,33 +2025,26 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         len += total;
         if (len >= EV_DRAIN_AT)
         {
-            drain(len);
+            drain(len, list_tile0 * EV_TILE);
             len = 0;
         }
     }
-    if (len > 0u) drain(len);
+    if (len > 0u) drain(len, list_tile0 * EV_TILE);
     // messages per core of the group: lanes with the same q hold counts of the same cores
 #pragma unroll
     for (uint32_t mm = 0; mm < (16 + LPB - 1) / LPB; mm++)
         if (msg_cnt[mm] != 0u && q + mm * LPB < 16u) atomicAdd(&s_msgs[q + mm * LPB], msg_cnt[mm]);
     __syncthreads(); // every wavefront's additions are in the accumulators
-    const long long t = done + 1;
-    const size_t ring_row = (size_t) ((t + 1) % im.ring_slots) * im.n_slots;
-    for (uint32_t i0 = wave * WAVE; i0 < eg.n_acc; i0 += 256u) // (n_acc: a multiple of 64 -> wave-uniform)
+    // Every accumulator of the group, touched or not, goes to this segment's row of the partials (plain coalesced stores: the
+    // segments of a group share its neurons, and global fp64 atomics run at a fifth of the store rate); the next neuron launch
+    // adds a neuron's rows up.  Event counts per core: the accumulators hold them.
+    uint32_t *part = st.ev_part + (size_t) seg * im.n_slots + eg.slot0;
+    for (uint32_t i0 = wave * WAVE; i0 < eg.n_acc; i0 += BLOCK) // (n_acc: a multiple of 64 -> wave-uniform)
     {
-        const uint32_t i = i0 + lane;
-        const uint32_t v = s_acc[i];
-        uint32_t events = 0;
-        if (v != 0u)
-        {
-            // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (proven by the host per segment and accumulator)
-            events = (v + (1u << (im.ev_shift - 1))) >> im.ev_shift;
-            const double sum = (double) (int) (v - (events << im.ev_shift));
-            const size_t gi = ring_row + eg.slot0 + i;
-            if (im.ev_segments > 1u) atomicAdd(&st.ring[gi], sum);
-            else st.ring[gi] = sum; // (no synaptic delays: the neuron launch left every consumed entry at 0.0)
-            st.ring_valid[gi] = 1;
-        }
+        const uint32_t v = s_acc[i0 + lane];
+        part[i0 + lane] = v;
+        // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (proven by the host per segment and accumulator)
+        const uint32_t events = (v + (1u << (im.ev_shift - 1))) >> im.ev_shift;
         const long long ev = wave_sum((long long) events);
         if (lane == 0 && ev != 0) atomicAdd(&s_events[im.ev_chunk_core[(eg.slot0 + i0) >> 6] - eg.core0], (uint32_t) ev);
     }
@@ -2010,6 +2055,28 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         if (s_msgs[threadIdx.x] != 0u) atomicAdd(&cnt[0], s_msgs[threadIdx.x]);
         if (s_events[threadIdx.x] != 0u) atomicAdd(&cnt[1], s_events[threadIdx.x]);
     }
+}
+
+// What a step delivered by events left in the partial rows, folded into the time-step buffer (state export, or any other
+// reader of the buffer on the host): one thread per slot.
+__global__ void event_fold_kernel(DevImage im, DevState st, long long t_done)
+{
+    if (*st.ev_done != t_done) return;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= im.n_slots) return;
+    long long tot = 0;
+    uint32_t any = 0;
+    for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++)
+    {
+        const uint32_t v = st.ev_part[(size_t) q * im.n_slots + g];
+        const uint32_t n_ev = (v + (1u << (im.ev_shift - 1))) >> im.ev_shift;
+        tot += (long long) (int) (v - (n_ev << im.ev_shift));
+        any |= v;
+    }
+    if (any == 0u) return;
+    const size_t gi = (size_t) ((t_done + 1) % im.ring_slots) * im.n_slots + g;
+    st.ring[gi] = (double) tot;
+    st.ring_valid[gi] = 1;
 }
 
 // ---------------------------------------------------------------------------------------
