@@ -37,6 +37,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cmath>
@@ -120,7 +121,13 @@ struct sanafe_hip_chip
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     const void *event_fn{nullptr};   // event_deliver_kernel instantiation (chips with the event layout, DevImage::ev_*)
     int ev_lpb{4};                   // its lanes per block
-    int ev_waves{8};                 // its wavefronts per workgroup
+    int ev_waves{16};                // its wavefronts per workgroup
+    // push / event decisions (DevImage::push_*): made here, on the host, from the events the device publishes
+    long long *h_events{nullptr};    // pinned ring DevState::host_events points at
+    long long epoch_first_step{1};   // Timestep::timestep of the first step whose events this chip's ring can hold
+    int cur_pushed{0};               // mode of the step whose neuron launch went out last
+    long long pushed_steps{0};       // steps delivered by the push path / the event kernel since create
+    long long ev_pending{-1};        // t_host after the step whose input still lies in DevState::ev_part (-1: none)
     double ev_avg_block{0.0};        // words per (source neuron, core group) block
     uint32_t ev_grid{0};
     uint32_t deliver_block{0};
@@ -217,15 +224,12 @@ struct DeliverVariant
 const DeliverVariant deliver_variants[] = {
         SANAFE_DV_FORMAT(0), SANAFE_DV_FORMAT(1), SANAFE_DV_FORMAT(2), SANAFE_DV_FORMAT(3), SANAFE_DV_FORMAT(4), SANAFE_DV_FORMAT(6),
         SANAFE_DV_FORMAT(7), SANAFE_DV_IACC(0), SANAFE_DV_IACC(3),
-        // bitmap axon records (format 7), with and without the push-delivery prologue
+        // bitmap axon records (format 7)
         SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, false), SANAFE_DVX(7, true, false, DELIVER_BLOCK, true, false),
-        SANAFE_DVX(7, false, false, 64, true, false), SANAFE_DVX(7, false, false, DELIVER_BLOCK, true, true),
-        SANAFE_DVX(7, false, false, 64, true, true),
+        SANAFE_DVX(7, false, false, 64, true, false),
         // ... on sub-accumulators (cores of at most 256 neurons, no synaptic delays)
-        SANAFE_DVS(false), SANAFE_DVS(true),
-        // push-delivery prologue on the integer formats (no synaptic delays, no last-event cores)
-        SANAFE_DVX(7, false, false, DELIVER_BLOCK, false, true), SANAFE_DVX(7, false, false, 64, false, true),
-        SANAFE_DVX(0, false, true, DELIVER_BLOCK, false, true), SANAFE_DVX(3, false, true, DELIVER_BLOCK, false, true)};
+        SANAFE_DVS(false)};
+// (no instantiation with the PUSH prologue any more: the host decides per step and does not launch the kernel on pushed steps)
 #undef SANAFE_DV
 #undef SANAFE_DVX
 #undef SANAFE_DVS
@@ -439,7 +443,6 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // a pushed event costs three atomics inside the neuron launch; the pull path one probe per inbound axon of the chip, whatever the activity
     im.push_max_events = (uint32_t) std::min<uint64_t>(16384, std::max<uint64_t>(256, h.n_axons / 128));
     if (const char *env = std::getenv("SANAFE_PUSH_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0L, std::atol(env));
-    TRY(dalloc(c, 8, &c->st.push_count)); // [0..2] decisions (0: pull), [6] steps delivered by the push path
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     return 0;
 }
@@ -552,7 +555,18 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     }
     // segments of the source space: 1,024-slot tiles, at most 64 per segment (16-bit list entries)
     const uint32_t n_tiles = (uint32_t) ((N + EV_TILE - 1) / EV_TILE);
+    // grid = groups x segments workgroups, two resident per CU (65 KB of LDS each) and each running for the whole launch on a
+    // busy step: the segment count in 4 .. 8 that fills the 256 CUs' slots most evenly (69 groups: 7 -> 483 of 512 slots,
+    // where 8 -> 552 would leave a third of the CUs with three workgroups' work and the others with two)
     uint32_t segments = 8;
+    {
+        double best = 0.0;
+        for (uint32_t sg = 4; sg <= EV_MAX_SEGMENTS; sg++)
+        {
+            const double wgs = (double) NG * sg, fill = wgs / (std::ceil(wgs / 512.0) * 512.0);
+            if (fill >= best) best = fill, segments = sg;
+        }
+    }
     if (const char *env = std::getenv("SANAFE_EVENT_SEGMENTS")) segments = (uint32_t) std::max(1L, std::atol(env));
     segments = std::min(std::min(segments, n_tiles), EV_MAX_SEGMENTS); // (one row of partials per segment, DevState::ev_part)
     // pass 2: offsets.  meta[n][g] = first unit of the block (relative to the neuron's base) | mask << 16; meta[n][NG] = end
@@ -659,15 +673,12 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     im.push_cap = h.n_slots / WAVE;
     im.push_always = im.ev_always;
     // the gather moves a few times the bytes of the stream per event: up to this many synaptic events, a step goes by events
-    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, h.n_synapses / 8u);
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, h.n_synapses / 4u);
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
-    TRY(dalloc(c, 8, &c->st.push_count));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
-    TRY(dalloc(c, 1, &c->st.ev_done));
-    HIPCHK(hipMemset(c->st.ev_done, 0xff, sizeof(long long))); // -1: nothing pending
-    c->ev_waves = 8;
-    if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 16 ? 16 : std::atoi(env) == 4 ? 4 : 8;
+    c->ev_waves = 16;
+    if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 8 ? 8 : std::atoi(env) == 4 ? 4 : 16;
     c->layout_bytes[9] = total_units * 16ull;
     c->layout_bytes[10] = meta.size() * 4ull + base.size() * 4ull;
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
@@ -1568,7 +1579,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     // The one delivery kernel this chip launches, picked from the table every instantiation lives in (deliver_variants):
     // opt in to its dynamic LDS and check dynamic + STATIC shared memory against the 160 KiB of a CU here, not at the
     // first launch.
-    st.push_count = st.push_core_cnt = nullptr;
+    st.push_core_cnt = nullptr;
+    st.host_events = nullptr;
+    st.ev_part = nullptr;
     im.ev_groups = 0;
     im.ev_always = 0;
     {
@@ -1578,6 +1591,13 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (im.ev_groups == 0u) TRYC(build_push(c, h));
         // chips too big for push tables (a global atomic per event) get the event layout (LDS accumulators) when it pays
         if (im.ev_groups == 0u && im.push_cap == 0u && !force_event) TRYC(build_event(c, h));
+        if (im.push_cap != 0u && im.push_always == 0u)
+        {
+            // the ring the device publishes every step's event count in (reduce_l2), read by the launch loop
+            HIPC(hipHostMalloc(reinterpret_cast<void **>(&c->h_events), (size_t) HOST_EVENT_RING * 2 * sizeof(long long), hipHostMallocMapped));
+            std::memset(c->h_events, 0, (size_t) HOST_EVENT_RING * 2 * sizeof(long long));
+            HIPC(hipHostGetDevicePointer(reinterpret_cast<void **>(&st.host_events), c->h_events, 0));
+        }
     }
     if (c->syn_format == 8)
     {
@@ -1605,7 +1625,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             if (std::atoi(env) == 0) sub = false;
         c->sub_accumulators = sub;
         const DeliverVariant *v = find_deliver_variant(c->syn_format, !im.has_last && c->has_delay, im.has_last != 0, iacc, use_small ? 64 : DELIVER_BLOCK,
-                c->n_bitmap_slices > 0, im.push_cap != 0u, sub);
+                c->n_bitmap_slices > 0, false, sub);
         if (v == nullptr)
             return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "no delivery kernel for format %d (delay %d, last %d, integer accumulators %d)",
                     c->syn_format, (int) c->has_delay, im.has_last, (int) iacc));
@@ -1646,6 +1666,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
                  (void *) c->d_host_b, (void *) c->d_host_costs, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
         if (p) (void) hipFree(p);
+    if (c->h_events) (void) hipHostFree(c->h_events);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1738,6 +1759,33 @@ extern "C" int sanafe_hip_read_step_state(sanafe_hip_chip *c, int64_t first, int
     return 0;
 }
 
+// Push / pull (event / stream) for the step with Timestep::timestep `t`: pushed when step t - DECISION_LAG caused at most
+// push_max_events synaptic events.  A pure function of the simulation's own history, so every run decides alike; the count
+// comes from the pinned ring reduce_l2 publishes in.  Level 2 of step t - DECISION_LAG rode in a neuron launch enqueued
+// DECISION_LAG - 2 steps ago (or in a flush): if the device has not got there yet, wait -- the host then leads the device by
+// at most DECISION_LAG - 2 steps, which is queue enough to hide the launch costs.
+static int decide_pushed(sanafe_hip_chip *c, long long t)
+{
+    if (c->im.push_cap == 0u) return 0;
+    if (c->im.push_always != 0u) return 1;
+    const long long n = t - DECISION_LAG;
+    if (n < c->epoch_first_step || c->h_events == nullptr) return 0; // no history yet: pull
+    volatile long long *e = c->h_events + 2 * (n % HOST_EVENT_RING);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned long long spins = 0;; spins++)
+    {
+        if (__atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) return __atomic_load_n(&e[0], __ATOMIC_RELAXED) <= (long long) c->im.push_max_events ? 1 : 0;
+        if ((spins & 0x3fffu) == 0x3fffu)
+        {
+            // the stream is idle and the entry is not there (a step reduced before this chip's ring existed), or the device
+            // is stuck (the next synchronising call reports it): pull
+            const bool idle = hipStreamQuery(c->stream) == hipSuccess;
+            if (idle && __atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) continue;
+            if (idle || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return 0;
+        }
+    }
+}
+
 // ---- one timestep = neuron launch (which first reduces the previous step) + delivery launch ----
 static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 {
@@ -1752,13 +1800,15 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     sa.t = c->t_host + 1;
     sa.parity = (int) (c->t_host & 1);
     sa.push_buf = (int) (c->t_host % 3);
+    c->cur_pushed = decide_pushed(c, sa.t);
+    sa.pushed = (c->cur_pushed && c->im.ev_groups == 0u) ? 1 : 0; // (event chips: event_deliver_kernel delivers, not this launch)
     const size_t rslot = (size_t) (sa.t % c->im.ring_slots);
     sa.ring = c->st.ring + rslot * c->im.n_slots;
     sa.rvalid = c->st.ring_valid + rslot * c->im.n_slots;
     const size_t nslot = (size_t) ((sa.t + 1) % c->im.ring_slots);
     sa.ring_next = c->st.ring + nslot * c->im.n_slots;
     sa.rvalid_next = c->st.ring_valid + nslot * c->im.n_slots;
-    sa.ev_part = c->im.ev_groups != 0u ? c->st.ev_part : nullptr;
+    sa.ev_part = (c->im.ev_groups != 0u && c->ev_pending == c->t_host) ? c->st.ev_part : nullptr; // the previous step went by events
     if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
     if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
     const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
@@ -1778,25 +1828,21 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
 // Delivers the slices [first, first + count) of the launch order.
 static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
-    if (c->im.ev_groups != 0u)
+    if (c->im.ev_groups != 0u && c->cur_pushed)
     {
-        // Chips with the event layout: the streaming kernel (its PUSH instantiation returns at once on a step the device
-        // decided to deliver by events) and the event kernel (returns at once on the others); both read the word reduce_l2
-        // left for this step.  The event kernel takes the whole source space at once: it goes with the last slices.
-        long long done = c->t_host;
-        if (count > 0 && c->im.ev_always == 0u)
-        {
-            void *args[] = {&c->im, &c->st, &done, &first};
-            HIPCHK(hipLaunchKernel(c->deliver_fn, dim3(count), dim3(c->deliver_block), args, c->deliver_lds, c->stream));
-        }
+        // a step the host decided to deliver by events: the event kernel takes the whole source space at once -- it goes with
+        // the last slices (tile-sharded chips deliver in two calls, local slices first) -- and leaves the next step's input in
+        // DevState::ev_part
         if (first + count == c->im.n_slices)
         {
+            long long done = c->t_host;
             void *args[] = {&c->im, &c->st, &done};
             HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(64u * (uint32_t) c->ev_waves), args, 0, c->stream));
+            c->ev_pending = c->t_host + 1;
         }
         return 0;
     }
-    if (c->im.push_cap != 0u && c->im.push_always != 0u) return 0; // the neuron launch delivered the step's spikes itself
+    if (c->cur_pushed) return 0; // the neuron launch delivered the step's spikes itself
     if (c->syn_format == 8)
     {
         // ordered delivery: one launch for the whole chip -- every wavefront folds an accumulator group, then walks
@@ -1833,6 +1879,8 @@ static void finish_step(sanafe_hip_chip *c, int simple_timing, int record, long 
     c->pend1.record = record;
     c->pend1.parity = (int) (c->t_host & 1);
     c->pend1.push_buf = (int) (c->t_host % 3);
+    c->pend1.pushed = c->cur_pushed;
+    c->pushed_steps += c->cur_pushed ? 1 : 0;
     c->pend1.rec_index = rec_index;
     c->t_host += 1;
 }
@@ -1857,10 +1905,10 @@ static int flush_pending(sanafe_hip_chip *c)
 // time-step buffer on the host get it folded into the buffer row first.
 static int fold_event_partials(sanafe_hip_chip *c)
 {
-    if (c->im.ev_groups == 0u) return 0;
+    if (c->im.ev_groups == 0u || c->ev_pending != c->t_host) return 0;
     hipLaunchKernelGGL(event_fold_kernel, dim3((c->im.n_slots + 255) / 256), dim3(256), 0, c->stream, c->im, c->st, (long long) c->t_host);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream));
+    c->ev_pending = -1;
     return 0;
 }
 
@@ -1961,13 +2009,7 @@ extern "C" int sanafe_hip_get_push_info(sanafe_hip_chip *c, uint32_t *enabled, u
     if (pushed_steps)
     {
         *pushed_steps = 0;
-        if (c->im.push_cap != 0u)
-        {
-            HIPCHK(hipSetDevice(c->device));
-            TRY(flush_pending(c));
-            HIPCHK(hipMemcpyAsync(pushed_steps, c->st.push_count + 6, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(hipStreamSynchronize(c->stream));
-        }
+        if (c->im.push_cap != 0u) *pushed_steps = (uint32_t) c->pushed_steps; // (counted where the decision is made: on the host)
     }
     return 0;
 }
@@ -2524,7 +2566,7 @@ extern "C" int sanafe_hip_import_state(sanafe_hip_chip *c, const sanafe_hip_stat
         return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
     HIPCHK(hipSetDevice(c->device));
     TRY(flush_pending(c));
-    if (c->im.ev_groups != 0u) HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream)); // the imported buffer rows hold all pending input
+    c->ev_pending = -1; // the imported buffer rows hold all pending input
     const size_t n = c->im.n_slots, r = (size_t) c->im.ring_slots * n;
     TRY(h2d(c, c->st.v, in->v, n));
     TRY(h2d(c, c->st.icur, in->icur, n));
@@ -2538,6 +2580,7 @@ extern "C" int sanafe_hip_import_state(sanafe_hip_chip *c, const sanafe_hip_stat
     const long long t = in->timesteps;
     TRY(h2d(c, c->st.t, &t, 1));
     c->t_host = t; // the step numbering (Timestep::timestep, ring rows, step parity) continues from there
+    c->epoch_first_step = t + 1; // (the event counts of earlier steps are not in this chip's ring)
     return 0;
 }
 
@@ -2553,7 +2596,7 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
     HIPCHK(hipMemsetAsync(c->st.ring_valid, 0, (size_t) c->im.ring_slots * n, c->stream));
     if (c->st.ring_last) HIPCHK(hipMemsetAsync(c->st.ring_last, 0, n * sizeof(uint32_t), c->stream));
     if (c->st.arrived) HIPCHK(hipMemsetAsync(c->st.arrived, 0, n, c->stream));
-    if (c->im.ev_groups != 0u) HIPCHK(hipMemsetAsync(c->st.ev_done, 0xff, sizeof(long long), c->stream)); // pending input of an event step is dropped like the buffer rows
+    c->ev_pending = -1; // pending input of an event step is dropped like the buffer rows
     if (c->st.tap_v)
     {
         HIPCHK(hipMemsetAsync(c->st.tap_v, 0, (size_t) c->im.n_taps * 8 * sizeof(double), c->stream));

@@ -150,9 +150,11 @@ struct DevImage
     // spikes itself -- the wavefront that updated a 64-slot chunk walks the static out-synapse lists of the neurons that fired
     // and adds their weights to the NEXT step's row of the time-step buffer (push chips keep two rows, so no wavefront of the
     // launch still reads what another one adds to) -- and the delivery launch of the step, which would probe every inbound
-    // axon of the chip, returns at once.  Which path a step takes is decided on the device from the synaptic events of the
-    // step THREE before it (reduce_l2 of that step rides in the previous neuron launch and leaves one word that the neuron
-    // launch, the delivery launch and reduce_l1 of the step all read).
+    // axon of the chip, is not launched at all.  Which path a step takes is decided ON THE HOST, deterministically, from the
+    // synaptic events of the step DECISION_LAG before it: reduce_l2 publishes every step's event count in a pinned ring
+    // (DevState::host_events), the launch loop reads the entry of step s - DECISION_LAG before it launches step s (it waits
+    // for it if it has to: the host then runs at most DECISION_LAG - 2 steps ahead of the device) and passes the mode to the
+    // neuron launch (StepArgs::pushed) and to level 1 of the step's reduction (PendStep::pushed).
     // Only built for chips where the result cannot depend on the order of the additions and the per-core message costs are
     // integers times a constant: integer weights, no synaptic delays / last-event cores / taps / host units, one latency
     // class per core, one GPU, ring_slots >= 2.  push_cap == 0: not built.
@@ -160,8 +162,8 @@ struct DevImage
     uint32_t push_always;         // 1: every step is pushed and the chip has NO delivery launch (chips with so few synapses per
                                   // neuron that even a step in which every neuron fires costs about what one probe of all
                                   // inbound axons costs: C4 has one synapse per neuron)
-    uint32_t push_max_events;     // a step is pushed when the step THREE before it caused at most this many synaptic events
-                                  // (the prediction only picks the faster path: both paths are exact for any activity)
+    uint32_t push_max_events;     // a step is pushed when the step DECISION_LAG before it caused at most this many synaptic
+                                  // events (the prediction only picks the faster path: both paths are exact for any activity)
     const uint32_t *push_ptr;     // [n_slots + 1] out-synapses of each neuron
     const struct PushEntry *push_syn; // post slot, destination core | first-synapse-of-its-axon flag, weight
     const double *core_ain_lat;   // [n_cores] axon-in latency per message
@@ -183,7 +185,7 @@ struct DevImage
     // one contiguous, 16-byte aligned BLOCK, the blocks of a neuron group after group.  A step with few spikes then reads the
     // spike bitmap, per (fired neuron, group) one 8-byte table entry, and that neuron's blocks -- work and bytes in proportion
     // to the step's synaptic events instead of to the chip's synapses.  Which kernel delivers a step is decided on the device
-    // like push delivery (push_count, push_max_events); both are exact for any activity.  ev_groups == 0: not built.
+    // by the host like push delivery (push_max_events); both are exact for any activity.  ev_groups == 0: not built.
     uint32_t ev_groups;           // core groups
     uint32_t ev_segments;         // the source space is cut into this many segments of ev_seg_tiles tiles: grid = groups x segments
     uint32_t ev_seg_tiles;        // 1,024-slot tiles of the global source space per segment (<= 64: list entries are 16 bits)
@@ -238,7 +240,8 @@ struct PendStep
 {
     int valid;          // 0: nothing to do
     int simple_timing, record, parity;
-    int push_buf;        // step number % 3: the push decision word and per-core counters of that step
+    int push_buf;        // step number % 3: the per-core push counters of that step
+    int pushed;          // the step was delivered by the push path / the event kernel: level 1 prices the per-core counters
     long long rec_index; // record slot of that step
 };
 
@@ -266,18 +269,20 @@ struct DevState
     uint32_t *spike_log;          // [log_cap][n_slots/32]
     uint8_t *status_log;          // [log_cap][n_slots] NeuronStatus per step (record & 2), or NULL
     long long log_cap;
-    // push delivery, by step number % 3
-    uint32_t *push_count;         // [0..2]: 1 = the step with that number % 3 is pushed; [6]: steps pushed so far (diagnostics)
-    uint32_t *push_core_cnt;      // [3][n_cores][2]: messages, events delivered to each core by the push path
+    // push / event delivery, by step number % 3
+    uint32_t *push_core_cnt;      // [3][n_cores][2]: messages, events delivered to each core by the push path / the event kernel
+    long long *host_events;       // pinned host memory, [HOST_EVENT_RING][2]: synaptic events and Timestep::timestep of the steps
+                                  // reduced last (written by reduce_l2, read by the launch loop: the push / pull decision), or NULL
     double *host_proc;            // [2][n_cores] by step parity: message-processing delay of cores that run on the host, or NULL
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
     long long delay_log_cap;
     // event-driven delivery (DevImage::ev_*): what a step delivered by events leaves for the NEXT step's neuron launch
     uint32_t *ev_part;            // [EV_MAX_SEGMENTS][n_slots]: per segment of the source space and neuron, count * 2^ev_shift + sum
                                   // of the weights that arrived (0: nothing); every workgroup stores all of its accumulators
-    long long *ev_done;           // Timestep::timestep of the last step that event_deliver_kernel delivered (-1: none pending)
 };
 constexpr uint32_t EV_MAX_SEGMENTS = 8;
+constexpr long long DECISION_LAG = 16;    // step s is pushed / delivered by events when step s - DECISION_LAG caused few events
+constexpr long long HOST_EVENT_RING = 64; // entries of DevState::host_events (the host runs < DECISION_LAG steps ahead)
 
 // Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles: Hillis-Steele inside
 // each 16-lane row, row_bcast:15 and row_bcast:31 across rows, total in lane 63.  Lanes without a source read
@@ -338,8 +343,8 @@ __device__ __forceinline__ double synapse_weight_at(const DevImage &im, unsigned
     return (double) ((int) im.syn_meta[pos] >> (im.syn_format == 0 ? 24 : 20));
 }
 
-__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf);
-__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev, int decide_buf);
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf, int pushed);
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev);
 
 // Per-launch values the host works out (no 64-bit division or row arithmetic on the device).
 struct StepArgs
@@ -351,10 +356,11 @@ struct StepArgs
     const int *ext_row;  // external stream values of this step, or NULL
     long long t;         // Timestep::timestep of this step (steps simulated before it + 1)
     int parity;          // (t - 1) & 1: which half of the partials this step writes
-    int push_buf;        // (t - 1) % 3: the push decision word and the per-core counters of this step
+    int push_buf;        // (t - 1) % 3: the per-core push counters of this step
+    int pushed;          // this step's spikes are pushed by this launch (chips with push tables; decided by the host)
     double *ring_next;   // the NEXT step's row of the time-step buffer (push chips: ring_slots >= 2), where pushed spikes land
     uint8_t *rvalid_next;
-    const uint32_t *ev_part; // chips with the event layout: DevState::ev_part (else NULL), n_slots entries per row
+    const uint32_t *ev_part; // the previous step was delivered by events: DevState::ev_part (else NULL), n_slots entries per row
 };
 
 // A chip whose neurons all carry the same class word (one soma model, one parameter set, one cost class, one input
@@ -395,9 +401,9 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // scalar
     if (blockIdx.x < im.n_reduce_wgs) // workgroup-uniform
     {
-        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, l2.push_buf); // (step s decides for step s + 3: the same slot)
+        if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
         const uint32_t group = blockIdx.x * (NEURON_BLOCK / WAVE) + wave;
-        if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
+        if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf, l1.pushed);
         return;
     }
     __shared__ sanafe_hip_soma_class s_soma[UNI ? 1 : SOMA_LDS_MAX];
@@ -445,26 +451,21 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         if (MODEL != SANAFE_SOMA_TRUENORTH && im.any_refrac) rc_in = p_refrac[lane];
         if (!UNI && sa.ext_row != nullptr) ext_col = im.slot_ext[c0 + lane];
     }
-    // chips with the event layout: what event_deliver_kernel left per segment of the source space, loaded with everything
-    // else (used only when the PREVIOUS step was delivered by events: st.ev_done below)
+    // the PREVIOUS step was delivered by events (the host knows: sa.ev_part): what event_deliver_kernel left per segment of
+    // the source space, loaded with everything else
     uint32_t evp[EV_MAX_SEGMENTS];
 #pragma unroll
     for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++) evp[q] = 0u;
     // (not in the uniform TrueNorth instantiation, which sits at its 64-register budget: such chips get no event layout)
     constexpr bool EV_OK = !(UNI && MODEL == SANAFE_SOMA_TRUENORTH);
-    const bool ev_chip = EV_OK && sa.ev_part != nullptr; // (a kernel argument: no load behind it)
-    if (ev_chip && active)
+    const bool ev_in = EV_OK && sa.ev_part != nullptr; // (a kernel argument: no load behind it)
+    if (ev_in && active)
     {
 #pragma unroll
         for (uint32_t q = 0; q < EV_MAX_SEGMENTS; q++) evp[q] = sa.ev_part[(size_t) q * im.n_slots + c0 + lane];
     }
-    // push or pull for this step: written by reduce_l2 in the PREVIOUS neuron launch; the delivery launch and reduce_l1 read
-    // the same word.  Loaded HERE, behind the per-slot loads: it is a dependent load (pointer, then word) that misses the
-    // scalar cache in the first wavefronts of a launch, and a wait for it placed before the vector loads -- where the compiler
-    // puts it when left alone -- costs every wavefront a memory round trip (4.5 us per launch on the 1 M neuron chip).
-    asm volatile("" ::: "memory");
-    const bool push_now = im.push_cap != 0u && im.ev_groups == 0u && (im.push_always != 0u || st.push_count[sa.push_buf] != 0u); // (event chips decide the same way, but their spikes are delivered by event_deliver_kernel)
-    const bool ev_in = ev_chip && *st.ev_done == sa.t - 1; // the previous step's input lies in the partial rows, not in the time-step buffer
+    // push or pull for this step: decided by the host (DevImage::push_*), a kernel argument
+    const bool push_now = sa.pushed != 0;
     if (!UNI)
     {
         // ---- class tables -> LDS, in flight together with the slot loads ----
@@ -918,7 +919,7 @@ __device__ __forceinline__ uint4 load_stream16(const uint4 *p)
 // ~256 axons per core) -- most of the four wavefronts would idle and hold wave slots.
 // BITMAP: every compact slice of the chip is on bitmap axon records (SliceDesc::mode 2; format 7 only) -- compiled apart from
 // the 2-byte delta records so that neither phase A pays for the other's registers.  PUSH: the chip has push-delivery tables
-// (DevImage::push_*); the kernel starts with the per-step push / pull decision.
+// (DevImage::push_*) -- no longer used: the host decides per step and does not launch this kernel on pushed steps.
 // SUB: bitmap records on cores of at most SUB_MAX_NEURONS neurons -- every accumulator is spread over 16 sub-accumulators, picked by
 // the upper four bits of the word's weight code, 64 bytes per neuron in STATIC LDS: the accumulator's LDS address is then the
 // word itself with its low two bits masked (one instruction per word instead of a bit-field extract and a shift-add: 70 -> 62
@@ -958,11 +959,6 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
     if (SYN_FMT == 6 && threadIdx.x < 32) s_lut[threadIdx.x] = im.weight_lut[threadIdx.x]; // visible after the barrier below
     if (SYN_FMT == 7 && threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.weight_lut[threadIdx.x] + (1 << im.acc_shift));
 
-    if constexpr (PUSH)
-    {
-        // ---- few spikes: the neuron launch of this step pushed its spikes itself (neuron_kernel); nothing to deliver ----
-        if (st.push_count[(uint32_t) (done % 3)] != 0u) return; // the same decision in the neuron launch and in reduce_l1
-    }
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6)); // a scalar: chunk offsets and bases stay in SGPRs
     // Descriptors are in launch order: slices whose axons all start on this GPU first (delivered while the
@@ -1910,14 +1906,12 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     __shared__ uint16_t s_lut16[32];
     __shared__ uint16_t s_list[WAVES][EV_LIST_CAP];
     __shared__ uint32_t s_msgs[16], s_events[16];
-    if (im.ev_always == 0u && st.push_count[(uint32_t) (done % 3)] == 0u) return; // this step is streamed by deliver_kernel
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     // workgroup -> (group, segment): blocks b and b + 8 share an XCD
     const uint32_t gpx = (im.ev_groups + 7u) / 8u;
     const uint32_t xcd = blockIdx.x & 7u, k = blockIdx.x >> 3;
     const uint32_t g = xcd * gpx + k % gpx, seg = k / gpx;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *st.ev_done = done + 1; // the next neuron launch reads its input from the partial rows
     if (g >= im.ev_groups) return; // (workgroup-uniform)
     const EvGroup eg = im.ev_group[g];
     for (uint32_t i = threadIdx.x; i < ACC_MAX; i += BLOCK) s_acc[i] = 0u;
@@ -2001,32 +1995,46 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         wave_lds_fence(); // the list is rewritten
     };
     uint32_t len = 0, list_tile0 = tile0;
-    for (uint32_t tile = tile0 + wave; tile < tile1; tile += (uint32_t) WAVES) // (wave-uniform bounds)
+    // the wavefront's tiles, four at a time: their bitmap words are loaded together (one memory round trip, not four)
+    constexpr uint32_t TB = 4;
+    for (uint32_t tb = tile0 + wave; tb < tile1; tb += TB * (uint32_t) WAVES) // (wave-uniform bounds)
     {
-        if (len > 0u && tile - list_tile0 >= 64u)
+        uint32_t w4[TB];
+#pragma unroll
+        for (uint32_t u = 0; u < TB; u++)
         {
-            drain(len, list_tile0 * EV_TILE);
-            len = 0;
+            const uint32_t tile = tb + u * (uint32_t) WAVES;
+            w4[u] = st.bits_global[(tile < tile1 ? tile : tb) * (EV_TILE / 32u) + (lane >> 1)];
         }
-        if (len == 0u) list_tile0 = tile;
-        // 16 slots per lane: lanes 2i and 2i + 1 share a word of the bitmap
-        const uint32_t w32 = st.bits_global[tile * (EV_TILE / 32u) + (lane >> 1)];
-        uint32_t half = (w32 >> (16u * (lane & 1u))) & 0xffffu;
-        const uint32_t cnt = (uint32_t) __popc(half);
-        const uint32_t incl = wave_inclusive_scan(cnt);
-        const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
-        uint32_t pos = len + incl - cnt;
-        const uint32_t rel0 = (tile - list_tile0) * EV_TILE + lane * 16u;
-        while (half != 0u)
+#pragma unroll
+        for (uint32_t u = 0; u < TB; u++)
         {
-            list[pos++] = (uint16_t) (rel0 + (uint32_t) __builtin_ctz(half));
-            half &= half - 1u;
-        }
-        len += total;
-        if (len >= EV_DRAIN_AT)
-        {
-            drain(len, list_tile0 * EV_TILE);
-            len = 0;
+            const uint32_t tile = tb + u * (uint32_t) WAVES;
+            if (tile >= tile1) break;
+            if (len > 0u && tile - list_tile0 >= 64u)
+            {
+                drain(len, list_tile0 * EV_TILE);
+                len = 0;
+            }
+            if (len == 0u) list_tile0 = tile;
+            // 16 slots per lane: lanes 2i and 2i + 1 share a word of the bitmap
+            uint32_t half = (w4[u] >> (16u * (lane & 1u))) & 0xffffu;
+            const uint32_t cnt = (uint32_t) __popc(half);
+            const uint32_t incl = wave_inclusive_scan(cnt);
+            const uint32_t total = (uint32_t) __builtin_amdgcn_readlane((int) incl, WAVE - 1);
+            uint32_t pos = len + incl - cnt;
+            const uint32_t rel0 = (tile - list_tile0) * EV_TILE + lane * 16u;
+            while (half != 0u)
+            {
+                list[pos++] = (uint16_t) (rel0 + (uint32_t) __builtin_ctz(half));
+                half &= half - 1u;
+            }
+            len += total;
+            if (len >= EV_DRAIN_AT)
+            {
+                drain(len, list_tile0 * EV_TILE);
+                len = 0;
+            }
         }
     }
     if (len > 0u) drain(len, list_tile0 * EV_TILE);
@@ -2061,7 +2069,6 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
 // reader of the buffer on the host): one thread per slot.
 __global__ void event_fold_kernel(DevImage im, DevState st, long long t_done)
 {
-    if (*st.ev_done != t_done) return;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= im.n_slots) return;
     long long tot = 0;
@@ -2326,7 +2333,7 @@ ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulat
 // partials in workgroup order, the generation-delay sum of its messages incl. the placeholder
 // (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81) and the processing-delay sum of its
 // delivery slices in slice (= reference delivery) order.
-__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf)
+__device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf, int pushed_step)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const uint32_t c = group * WAVE + (uint32_t) lane;
@@ -2356,8 +2363,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
         gen = lat + (double) packets * out_lat;
         // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
         const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
-        bool pushed = false;
-        if (im.push_cap != 0u) pushed = im.push_always != 0u || st.push_count[push_buf] != 0u; // the neuron and delivery launches of the step read the same word
+        const bool pushed = pushed_step != 0; // (the host's decision: the same value went to the step's own launches)
         if (pushed)
         {
             // the push path counted this core's messages and events: integers times the core's constants
@@ -2365,7 +2371,6 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
             proc = (double) cnt[1] * im.core_event_lat[c] + (double) cnt[0] * im.core_ain_lat[c];
             cnt[0] = 0u;
             cnt[1] = 0u;
-            if (c == 0u) st.push_count[6] += 1u; // diagnostics: steps delivered by the push path (sanafe_hip_get_push_info)
         }
         else if (s1 - s0 <= 2u)
         {
@@ -2418,7 +2423,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
 
 // Level 2: one wavefront folds the groups (lane = group, further groups in rounds of 64) into the Timestep
 // totals, applies the simple timing model, accumulates RunData and writes the step record.
-__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev, int decide_buf /* -1: none */)
+__device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep &prev)
 {
     const int lane = threadIdx.x & (WAVE - 1);
     const GroupPart *gp = st.group_part + (size_t) prev.parity * im.n_groups;
@@ -2488,12 +2493,14 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
             st.step_log[prev.rec_index % st.log_cap] = ts;
             *st.rec = prev.rec_index + 1;
         }
-        // push (or event delivery) or pull for the step THREE after this one -- the step whose number % 3 is this step's, so the
-        // word this step's own launches read is renewed once all of them are done (level 1 of this step ran in an earlier
-        // launch).  Whoever runs level 2 decides: the neuron launch two steps later or reduce_kernel (a flush), so a caller
-        // that flushes after every step still gets fresh decisions, and a flush in the middle of a split step (level 2 of the
-        // step BEFORE it) leaves that step's own word alone.
-        if (im.push_cap != 0u && decide_buf >= 0) st.push_count[decide_buf] = (events <= (long long) im.push_max_events) ? 1u : 0u;
+        // the step's synaptic events, for the host's push / pull (event / stream) decision DECISION_LAG steps from now:
+        // value first, then the step number it belongs to (the host waits for the number)
+        if (st.host_events != nullptr)
+        {
+            long long *e = st.host_events + 2 * ((*st.t + 1) % HOST_EVENT_RING);
+            __hip_atomic_store(&e[0], events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&e[1], *st.t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;
     }
@@ -2514,9 +2521,9 @@ __global__ void state_log_kernel(const double *v, const double *icur, const uint
 __global__ void __launch_bounds__(REDUCE_BLOCK) reduce_kernel(DevImage im, DevState st, PendStep l1, PendStep l2)
 {
     const int wave = threadIdx.x >> 6;
-    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2, l2.push_buf);
+    if (blockIdx.x == 0 && wave == 0 && l2.valid) reduce_l2(im, st, l2);
     const uint32_t group = blockIdx.x * (REDUCE_BLOCK / WAVE) + (uint32_t) wave;
-    if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf);
+    if (l1.valid && group < im.n_groups) reduce_l1(im, st, l1.parity, group, l1.push_buf, l1.pushed);
 }
 
 // `taps` dendrites, after the delivery launch of step t (one thread per neuron): advance the RC line by one step

@@ -40,16 +40,19 @@ def test_every_step_by_events_matches_the_oracle(S, monkeypatch, p_fire, segment
 
 
 def test_event_or_stream_decided_per_step(S, monkeypatch):
-    """SANAFE_EVENT=1: the device decides per step (few events three steps earlier -> events).  One sim() call, so the
-    decision rides in the step pipeline; a network whose activity starts high and settles, so both kernels run.  Same
-    result as the oracle and as the chip without the event layout."""
+    """SANAFE_EVENT=1: decided per step (few events sixteen steps earlier -> events) by the host, from the event counts the
+    device publishes, while the device runs ahead: one sim() call.  A network whose activity grows, so both kernels run.
+    Same result as the oracle and as the chip without the event layout."""
     monkeypatch.setenv("SANAFE_EVENT", "1")
     monkeypatch.setenv("SANAFE_EVENT_MAX_EVENTS", "7400")  # 4,530 events in step 1, 7,000-8,100 from step 9 on
     arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.05, seed=52)
     chip, orc, tot = check_batched(S, arch, net, steps=40)
     lay = chip.device_layout()
     assert lay["event_layout"] is not None and not lay["event_layout"]["always"], lay
-    assert 6 <= lay["pushed_steps"] <= 36, lay  # some steps by events, the first three (no decision yet) and the busy ones streamed
+    # step t goes by events when step t - 16 caused at most SANAFE_EVENT_MAX_EVENTS events: the first sixteen and the busy ones stream
+    ev = chip.step_totals(0, 40)["spikes"]
+    expect = sum(1 for t in range(16, 40) if ev[t - 16] <= 7400)
+    assert lay["pushed_steps"] == expect and 4 <= expect <= 20, (lay, expect)
     monkeypatch.setenv("SANAFE_EVENT", "0")
     monkeypatch.setenv("SANAFE_PUSH", "0")
     plain = S.SpikingChip(arch)
@@ -79,7 +82,7 @@ def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire):
     lay, info = chip.device_layout(), chip.info()
     ev = lay["event_layout"]
     assert lay["syn_format"] == 7 and lay["n_bitmap_slices"] == info["n_slices"] and ev is not None and ev["always"], lay
-    assert ev["groups"] == 69 and ev["segments"] == 8 and ev["code_bits"] == 4, ev  # 15 cores of 256 per group, 16 weight values
+    assert ev["groups"] == 69 and ev["segments"] == 7 and ev["code_bits"] == 4, ev  # 15 cores of 256 per group (7 segments: 483 workgroups on 512 slots), 16 weight values
     fired = 0
     for t in range(10):
         a, b = chip.run(1, "simple", record=True), orc.step("simple")
@@ -96,10 +99,11 @@ def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire):
 
 @pytest.mark.parametrize("kind", ["push", "event"])
 def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind):
-    """sanafe_hip_step_neurons, then a call that flushes the pending reductions (synchronize, device_layout's
-    push info, read_totals), then sanafe_hip_step_deliver.  The flush must not clear the push / pull word the neuron launch
-    has already read: the delivery launch and level 1 of the step reduction have to see the same decision, or a pushed step
-    is delivered twice and its per-core counters leak into a later step.  Against the oracle and against SANAFE_PUSH=0."""
+    """sanafe_hip_step_neurons, then a call that flushes the pending reductions (synchronize, device_layout,
+    read_totals), then sanafe_hip_step_deliver.  The two halves and level 1 of the step's reduction must agree on push or
+    pull -- with a decision word on the device a flush between the halves cleared it, a pushed step was delivered twice and
+    its per-core counters leaked into a later step.  The mode is now decided once per step on the host (launch_neurons) and
+    travels as a kernel argument.  Against the oracle."""
     if kind == "push":
         arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
         monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")
@@ -113,20 +117,17 @@ def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind
     lay = chip.device_layout()
     assert lay["push_enabled"] and not lay["push_only"], lay
     assert (lay["event_layout"] is not None) == (kind == "event")
-    # a few whole steps first, in ONE call, so that decisions exist for the steps that follow (they ride in the neuron launches)
     chip.run(6, "simple")
     for _ in range(6):
         orc.step("simple")
     before, pushed_before = chip.read_totals(), chip.device_layout()["pushed_steps"]
+    assert pushed_before == 0  # (no history yet: the first sixteen steps pull)
     ref = {k: 0 for _, k in INT_KEYS}
     ref_d = {k: 0.0 for k in DBL_KEYS}
-    # Every fourth split step has a flushing call between its halves.  The steps in between run without any read-back, so
-    # that level 2 of the reduction rides in the neuron launches and leaves decisions: the step with the flush is one the
-    # device decided to push (few events two and three steps earlier).
     for t in range(16):
         chip.step_neurons()
-        if t % 4 == 3:
-            (chip.synchronize, chip.device_layout, chip.read_totals)[(t // 4) % 3]()
+        if t % 2 == 1:
+            (chip.synchronize, chip.device_layout, chip.read_totals)[(t // 2) % 3]()
         chip.step_deliver("simple")
         b = orc.step("simple")
         for _, kb in INT_KEYS:
@@ -140,4 +141,4 @@ def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind
         assert after[ka] - before[ka] == ref[kb], ka
     for k in DBL_KEYS:
         assert after[k] - before[k] == pytest.approx(ref_d[k], rel=1e-9, abs=1e-30), k
-    assert chip.device_layout()["pushed_steps"] - pushed_before >= 6  # incl. the four steps with a flush between their halves
+    assert chip.device_layout()["pushed_steps"] == 6  # steps 17 .. 22: the steps sixteen before them caused few events

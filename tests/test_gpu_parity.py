@@ -234,9 +234,9 @@ def test_random_configurations(S, seed, monkeypatch):
 def test_push_delivery_on_steps_with_few_spikes(S, monkeypatch, net_kind):
     """C4-like activity (a fraction of a percent of the neurons fire): the NEURON launch delivers the spikes itself -- the
     wavefront of a 64-slot chunk walks the out-synapse lists of its fired neurons and adds to the next step's row of the
-    time-step buffer -- and the delivery launch, which probes every inbound axon, returns at once (push or pull decided per
-    step on the device from the events of the step three before), or is not launched at all on chips with at most one
-    synapse per neuron (push-only: TrueNorth's one edge per neuron).  Same spikes, potentials, counters, energies and sim_time
+    time-step buffer -- and the delivery launch, which probes every inbound axon, is not launched (push or pull decided per
+    step by the host from the events of the step sixteen before, which the device publishes in a pinned ring), or never
+    launched at all on chips with at most one synapse per neuron (push-only: TrueNorth's one edge per neuron).  Same spikes, potentials, counters, energies and sim_time
     as the oracle and as the pull path (SANAFE_PUSH=0)."""
     if net_kind.startswith("truenorth"):
         arch, net = nets.truenorth_net(S, n_tiles=32, neurons_per_core=256)
@@ -246,11 +246,14 @@ def test_push_delivery_on_steps_with_few_spikes(S, monkeypatch, net_kind):
     else:
         arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
         monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")  # (a chip this small would pull: one probe per axon is cheap)
-    chip, orc, tot = check_batched(S, arch, net, steps=40)  # one sim() call: the decision rides in the step pipeline
+    chip, orc, tot = check_batched(S, arch, net, steps=40)  # one sim() call: the host decides while the device runs
     lay = chip.device_layout()
     assert lay["push_enabled"] and lay["push_only"] == (net_kind == "truenorth_push_only"), lay
-    lo, hi = {"truenorth_push_only": (40, 40), "truenorth": (25, 37), "loihi_sparse": (25, 40)}[net_kind]
-    assert lo <= lay["pushed_steps"] <= hi, lay
+    # step t is pushed when step t - 16 caused at most SANAFE_PUSH_MAX_EVENTS events: a pure function of the run
+    ev = chip.step_totals(0, 40)["spikes"]
+    limit = int(os.environ["SANAFE_PUSH_MAX_EVENTS"])
+    expect = 40 if net_kind == "truenorth_push_only" else sum(1 for t in range(16, 40) if ev[t - 16] <= limit)
+    assert lay["pushed_steps"] == expect and (expect >= 12 or net_kind == "truenorth"), (lay, expect)
     monkeypatch.setenv("SANAFE_PUSH", "0")
     pull = S.SpikingChip(arch)
     pull.load(net)
