@@ -167,14 +167,16 @@ def _time_oracle(chip, timing, seconds, repeats=3):
         chip.step(timing)
     runs = []
     for _ in range(repeats):
-        steps, events, updates, t0 = 0, 0, 0, time.perf_counter()
+        steps, events, updates, msgs, t0 = 0, 0, 0, 0, time.perf_counter()
         while time.perf_counter() - t0 < seconds / repeats:
             r = chip.step(timing)
             steps += 1
             events += r["spike_count"]
             updates += r["neurons_updated"]
+            msgs += r["packets_sent"]
         dt = time.perf_counter() - t0
-        runs.append(dict(steps=steps, seconds=dt, events_per_s=events / dt, updates_per_s=updates / dt, steps_per_s=steps / dt))
+        runs.append(dict(steps=steps, seconds=dt, events_per_s=events / dt, updates_per_s=updates / dt, steps_per_s=steps / dt,
+                         messages_per_s=msgs / dt))
     runs.sort(key=lambda r: r["steps_per_s"])
     med = runs[len(runs) // 2]
     med["all_steps_per_s"] = [r["steps_per_s"] for r in runs]
@@ -215,10 +217,14 @@ def cpu_baseline(S, args):
     deg = max(8, n // 100)
     arch = S.presets.loihi_large(n_tiles=32, n_inputs=4, width=8, height=4)
     net = S.Network("sample")
-    g = net.create_neuron_group("n", n, {"threshold": 64, "reset": 0, "force_update": True}, "loihi_sparse_synapse",
-                                "loihi_dendrites_delay", False, True, "loihi_lif")
+    attrs = {"threshold": 64, "reset": 0, "force_update": True} if args.target_activity is None else \
+        {"threshold": ACTIVITY_THRESHOLD, "reset_mode": "soft", "force_update": True}
+    g = net.create_neuron_group("n", n, attrs, "loihi_sparse_synapse", "loihi_dendrites_delay", False, True, "loihi_lif")
     rng = np.random.default_rng(args.seed)
-    g.set_attribute_column("bias", np.where(rng.random(n) < args.p_fire, 128.0, 0.0), integer=True)
+    if args.target_activity is None:
+        g.set_attribute_column("bias", np.where(rng.random(n) < args.p_fire, 128.0, 0.0), integer=True)
+    else:
+        g.set_attribute_column("bias", activity_biases(n, args.target_activity, args.seed), integer=True)
     src, dst, w = S.chip.generate_random_edges(n, deg, args.seed)
     net.add_edges(src, dst, w, "loihi_sparse_synapse")
     ac = arch.cores()
@@ -233,16 +239,17 @@ def cpu_baseline(S, args):
     for threads in sorted({1, n_all}):
         chip.set_threads(threads)
         # a third of the budget for the single-threaded windows, the rest for all cores (their steps are short)
-        m = _time_oracle(chip, "simple", args.cpu_seconds * (0.6 if threads == 1 else 0.4))
+        m = _time_oracle(chip, args.timing, args.cpu_seconds * (0.6 if threads == 1 else 0.4))
         m["threads"] = threads
         runs[threads] = m
     best = max(runs.values(), key=lambda r: r["events_per_s"])
     best = dict(best)
     best["runs"] = runs
     best["build_s"] = build_s
-    best["sample"] = ("oracle (C++ port of the reference loop, OpenMP over cores like src/chip.cpp:629-632, 675-678) on %d LIF "
-                      "neurons / %d cores, out-degree %d (%d synapses, built in %.1f s): median of 3 windows per thread count"
-                      % (n, cores, deg, n * deg, build_s))
+    best["sample"] = ("oracle (C++ port of the reference loop, OpenMP over cores like src/chip.cpp:629-632, 675-678), %s timing "
+                      "(the whole step: neuron + message processing and, under detailed timing, the NoC schedule of "
+                      "src/schedule.cpp:208-620) on %d LIF neurons / %d cores, out-degree %d (%d synapses, built in %.1f s): median "
+                      "of 3 windows per thread count" % (args.timing, n, cores, deg, n * deg, build_s))
     return best
 
 
@@ -657,7 +664,7 @@ def main():
                            contract_deliver / max(1.0, design_deliver)))
 
     cpu = None
-    if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3" and args.timing == "simple":
+    if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c3":
         c = cpu_baseline(S, args)
         events_per_step = agg["spikes"] / args.steps
 
@@ -668,6 +675,7 @@ def main():
                          "step of the GPU workload (%.3g)" % (c["threads"], c["events_per_s"], events_per_step),
                "by_threads": {str(t): {"value": scaled(m), "timesteps_per_s_on_sample": m["steps_per_s"],
                                        "synaptic_events_per_s": m["events_per_s"], "neuron_updates_per_s": m["updates_per_s"],
+                                       "messages_per_s": m["messages_per_s"],
                                        "timesteps_per_s_windows": m["all_steps_per_s"]} for t, m in c["runs"].items()}}
 
     if rank == 0 and not multi and not args.no_cpu_baseline and args.workload == "c2":

@@ -19,12 +19,12 @@ for sub in ("p1", "p2"):
     for f in glob.glob(os.path.join(out, sub, "**", "*counter_collection.csv"), recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            name = "deliver" if "deliver_kernel" in k else "neuron" if "neuron_kernel" in k else "reduce" if "reduce_kernel" in k else None
+            name = "event_deliver" if "event_deliver_kernel" in k else "deliver" if "deliver_kernel" in k else "neuron" if "neuron_kernel" in k else "reduce" if "reduce_kernel" in k else None
             if not name:
                 continue
             d = res.setdefault(name, {}).setdefault(row["Counter_Name"], [0.0, 0])
             d[0] += float(row["Counter_Value"]); d[1] += 1
 summary = {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in res.items()}
 json.dump(summary, open(os.path.join(out, "sq_summary.json"), "w"), indent=1)
-print(json.dumps(summary.get("deliver", {}), indent=1))
+print(json.dumps({k: summary[k] for k in ("event_deliver", "deliver") if k in summary}, indent=1))
 PY

@@ -672,8 +672,10 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // the per-step decision rides on the push machinery (reduce_l2 decides, reduce_l1 prices the per-core counters)
     im.push_cap = h.n_slots / WAVE;
     im.push_always = im.ev_always;
-    // the gather moves a few times the bytes of the stream per event: up to this many synaptic events, a step goes by events
-    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, h.n_synapses / 4u);
+    // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~12 us + 0.87 us per million events,
+    // the streaming kernel 245 us whatever the activity (and up to 0.8 ms when so few axons spike that its windows fall back
+    // to the gather path): they cross at ~39 % of the neurons firing, 0.39 events per synapse and step
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.37));
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
@@ -937,6 +939,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 c->us.bias_uniform = same_bias ? 1u : 0u;
                 c->us.bias = bias0;
             }
+            im.uni_costing = c->uni ? 1 : 0;
+            if (c->uni) im.uni_cost = c->us.c;
+            else std::memset(&im.uni_cost, 0, sizeof im.uni_cost);
             c->h_soma_classes.assign(h.soma_classes, h.soma_classes + h.n_soma_classes);
         }
         im.spike_energy = 0;
@@ -1590,7 +1595,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         if (force_event) TRYC(build_event(c, h));
         if (im.ev_groups == 0u) TRYC(build_push(c, h));
         // chips too big for push tables (a global atomic per event) get the event layout (LDS accumulators) when it pays
-        if (im.ev_groups == 0u && im.push_cap == 0u && !force_event) TRYC(build_event(c, h));
+        // (SANAFE_PUSH=0 -- the A/B switch for "streaming delivery only" -- keeps the event layout away as well)
+        const bool push_off = std::getenv("SANAFE_PUSH") != nullptr && std::atoi(std::getenv("SANAFE_PUSH")) == 0;
+        if (im.ev_groups == 0u && im.push_cap == 0u && !force_event && !push_off) TRYC(build_event(c, h));
         if (im.push_cap != 0u && im.push_always == 0u)
         {
             // the ring the device publishes every step's event count in (reduce_l2), read by the launch loop
@@ -2304,9 +2311,15 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
         for (uint32_t k = 0; k < c->im.n_cores; k++)
         {
             double lat = 0.0;
-            long long packets = 0;
+            long long packets = 0, counted = 0, upd = 0, fired = 0;
             for (size_t w = (size_t) c->h_core_wg_beg[k] * PARTS_PER_WG; w < (size_t) c->h_core_wg_beg[k + 1] * PARTS_PER_WG; w++)
-                lat += wp[w].lat, packets += wp[w].packets;
+                lat += wp[w].lat, packets += wp[w].packets, counted += wp[w].counted, upd += wp[w].updated, fired += wp[w].fired;
+            if (c->im.uni_costing && counted != 0) // uniform chips: the default costing is priced per core (reduce_l1)
+            {
+                const sanafe_hip_cost_class &cc = c->im.uni_cost;
+                const double n_all = (double) counted, n_f = (double) fired, n_u = (double) (upd - fired), n_i = (double) (counted - upd);
+                lat += n_all * (0.0 + cc.dendrite_latency) + ((n_i * cc.soma_latency[0] + n_u * cc.soma_latency[1]) + n_f * cc.soma_latency[2]);
+            }
             gen_sum[k] = lat + (double) packets * c->h_core_out_lat[k];
         }
     }

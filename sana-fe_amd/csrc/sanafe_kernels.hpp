@@ -33,6 +33,8 @@ struct WgPart
 {
     double e_soma, e_dend, e_syn, e_net, lat;
     long long updated, fired, packets, hops, events;
+    long long counted; // uniform chips (DevImage::uni_costing): neurons the default costing covers; level 1 of the step
+    long long pad;     // reduction prices them per core (idle = counted - updated, updated-only = updated - fired, fired)
 };
 // Level-1 result of the step reduction: 64 consecutive cores folded by one wavefront.
 struct GroupPart
@@ -76,6 +78,10 @@ struct DevImage
     int has_lif;             // some slot runs the LIF soma (its input current `icur` is state)
     int spike_energy;        // bit 0/1/2: some neuron's spike costs synapse / network / message-side dendrite energy
     int any_refrac;          // some soma class has refractory_delay > 0 (otherwise `refrac` is never touched)
+    int uni_costing;         // every neuron carries the cost class `uni_cost` (UniformSoma chips): the neuron launch leaves
+                             // COUNTS per wavefront and level 1 of the step reduction prices them once per core, instead of
+                             // a dozen fp64 operations per wavefront (src/pipeline.hpp:574-731)
+    sanafe_hip_cost_class uni_cost;
     double sync_delay;
     const WgDesc *wg_desc;          // [n_wgs]
     const uint32_t *core_wg_beg;    // [n_cores + 1] neuron workgroups of each core
@@ -488,7 +494,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     }
 
     double e_soma = 0.0, e_dend = 0.0, e_syn = 0.0, e_net = 0.0, lat = 0.0;
-    long long n_pack = 0, n_hops = 0, n_ev = 0, n_upd = 0, n_fire = 0;
+    long long n_pack = 0, n_hops = 0, n_ev = 0, n_upd = 0, n_fire = 0, n_counted = 0;
     if (active)
     {
         const uint32_t model = cls & 7u; // padding slots carry SANAFE_SOMA_NONE
@@ -732,11 +738,14 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
             n_fire = __popcll(fired_mask);
             const uint32_t ccid = (cls >> 6) & 1023u;
             const uint32_t cc0 = UNI ? 0u : (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
-            if (UNI || __ballot(counted && ccid != cc0) == 0ull)
+            if (UNI)
+            {
+                n_counted = __popcll(m_cnt); // priced per core by reduce_l1 (DevImage::uni_costing)
+            }
+            else if (__ballot(counted && ccid != cc0) == 0ull)
             {
                 sanafe_hip_cost_class c0c;
-                if (UNI) c0c = us.c;
-                else if (cost_lds) c0c = s_cost[cc0];
+                if (cost_lds) c0c = s_cost[cc0];
                 else c0c = im.cost_classes[cc0];
                 const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_mask),
                              n_u = (double) __popcll(m_upd & ~fired_mask), n_i = (double) __popcll(m_cnt & ~m_upd);
@@ -832,6 +841,8 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         part.packets = n_pack;
         part.hops = n_hops;
         part.events = n_ev;
+        part.counted = n_counted;
+        part.pad = 0;
         st.wg_part[((size_t) sa.parity * im.n_wgs + wg) * PARTS_PER_WG + wave] = part;
     }
 }
@@ -2346,6 +2357,7 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
         const uint32_t s0 = im.core_slice_beg[c], s1 = im.core_slice_beg[c + 1];
         const double out_lat = im.core_axon_out_latency[c];
         double lat = 0;
+        long long counted = 0;
         for (uint32_t w = w0; w < w1; w++)
         {
             const WgPart p = part[w];
@@ -2359,6 +2371,16 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
             packets += p.packets;
             hops += p.hops;
             events += p.events;
+            counted += p.counted;
+        }
+        if (im.uni_costing && counted != 0)
+        {
+            // default costing of the core's neurons (src/pipeline.hpp:574-731), from their counts by soma activity
+            const sanafe_hip_cost_class &cc = im.uni_cost;
+            const double n_all = (double) counted, n_f = (double) fired, n_u = (double) (upd - fired), n_i = (double) (counted - upd);
+            e_soma += (n_i * cc.soma_energy[0] + n_u * cc.soma_energy[1]) + n_f * cc.soma_energy[2];
+            e_dend += n_all * cc.dendrite_energy;
+            lat += n_all * (0.0 + cc.dendrite_latency) + ((n_i * cc.soma_latency[0] + n_u * cc.soma_latency[1]) + n_f * cc.soma_latency[2]);
         }
         gen = lat + (double) packets * out_lat;
         // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order

@@ -34,3 +34,25 @@ def test_bench_fails_when_a_rank_fails():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
     p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert p.returncode != 0
+
+
+@pytest.mark.parametrize("workload,extra", [("c4", ["--tiles-per-gpu", "32"]),
+                                            ("c3", ["--cores-per-gpu", "16", "--neurons-per-core", "256", "--out-degree", "64"])])
+def test_bench_force_dist_with_rccl_at_world_size_one(workload, extra):
+    """The exact process shape of the driver's `--gpus N` runs, at N = 1: torch (which carries its own
+    RCCL) + a gloo process group for the control plane + the product's dlopen'ed librccl (RTLD_DEEPBIND) set up through
+    comm_init_torch(..., "rccl") -- the unique id travels through the process group, ncclCommInitRank, and every step's
+    in-place all-gather of the spike bitmap runs on the chip's stream inside sim()."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-dist", "--exchange", "nccl", "--workload", workload,
+           "--steps", "12", "--warmup", "3", "--no-cpu-baseline"] + extra
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["MASTER_PORT"] = "29517"
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 12 and d["value"] > 0
+    assert d["config"]["exchange"].startswith("in-place RCCL all-gather")
+    n = 32 * 256 if workload == "c4" else 16 * 256
+    assert d["config"]["neurons"] == n and d["totals_in_timed_region"]["neurons_updated"] == 12 * n

@@ -67,12 +67,18 @@ def test_hot_kernels_keep_their_occupancy_and_do_not_spill(isa):
     assert len(neuron) == 5
     for name, (vgprs, scratch) in neuron.items():
         assert vgprs <= 64 and scratch == 0, (name, vgprs, scratch)
-    deliver = {k: v for k, v in meta.items() if "deliver_kernelILi" in k}
-    assert len(deliver) >= 40
+    deliver = {k: v for k, v in meta.items() if "deliver_kernelILi" in k and "event_deliver" not in k}
+    assert len(deliver) >= 36  # every instantiation launch_deliver can pick (deliver_variants)
     for name, (vgprs, scratch) in deliver.items():
         assert vgprs <= 96 and scratch <= 16, (name, vgprs, scratch)
-    # format 7 on bitmap records, 256 threads, with and without push prologue / sub-accumulators
+    # format 7 on bitmap records, 256 threads, with and without sub-accumulators (the PUSH prologue is gone: the host decides)
     hot = {k: v for k, v in deliver.items() if "deliver_kernelILi7ELb0ELb0ELb0ELi256ELb1E" in k}
-    assert len(hot) == 4
+    assert len(hot) == 2
     for name, (vgprs, scratch) in hot.items():
         assert vgprs <= 80 and scratch == 0, (name, vgprs, scratch)
+    # event-driven delivery: 4 / 8 lanes per block x 4 / 5 code bits x 4 / 8 / 16 wavefronts, 64 registers (8 wavefronts per
+    # SIMD: two 16-wavefront workgroups per CU), no scratch
+    event = {k: v for k, v in meta.items() if "event_deliver_kernel" in k}
+    assert len(event) == 12
+    for name, (vgprs, scratch) in event.items():
+        assert vgprs <= 64 and scratch == 0, (name, vgprs, scratch)
