@@ -951,7 +951,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
             if (h.slot_packets[g] >= (1u << 18)) return bail(fail(SANAFE_HIP_ERR_UNSUPPORTED, "slot %u: a spike fans out to 2^18 cores or more", g));
         }
         im.n_wgs = (uint32_t) wgs.size();
-        im.n_groups = (h.n_cores + WAVE - 1) / WAVE;
+        im.n_groups = (h.n_cores + L1_CORES - 1) / L1_CORES;
         im.n_reduce_wgs = (im.n_groups + (NEURON_BLOCK / WAVE) - 1) / (NEURON_BLOCK / WAVE);
         TRYC(upload(c, wgs.data(), wgs.size(), &im.wg_desc));
         TRYC(upload(c, wg_beg.data(), wg_beg.size(), &im.core_wg_beg));
@@ -1766,8 +1766,8 @@ extern "C" int sanafe_hip_read_step_state(sanafe_hip_chip *c, int64_t first, int
     return 0;
 }
 
-// Push / pull (event / stream) for the step with Timestep::timestep `t`: pushed when step t - DECISION_LAG caused at most
-// push_max_events synaptic events.  A pure function of the simulation's own history, so every run decides alike; the count
+// Push / pull (event / stream) for the step with Timestep::timestep `t`: pushed when step t - DECISION_LAG (rounded down to a
+// multiple of DECISION_STRIDE: every fourth step publishes) caused at most push_max_events synaptic events.  A pure function of the simulation's own history, so every run decides alike; the count
 // comes from the pinned ring reduce_l2 publishes in.  Level 2 of step t - DECISION_LAG rode in a neuron launch enqueued
 // DECISION_LAG - 2 steps ago (or in a flush): if the device has not got there yet, wait -- the host then leads the device by
 // at most DECISION_LAG - 2 steps, which is queue enough to hide the launch costs.
@@ -1775,7 +1775,7 @@ static int decide_pushed(sanafe_hip_chip *c, long long t)
 {
     if (c->im.push_cap == 0u) return 0;
     if (c->im.push_always != 0u) return 1;
-    const long long n = t - DECISION_LAG;
+    const long long n = (t - DECISION_LAG) / DECISION_STRIDE * DECISION_STRIDE; // the last step at or before t - LAG that published
     if (n < c->epoch_first_step || c->h_events == nullptr) return 0; // no history yet: pull
     volatile long long *e = c->h_events + 2 * (n % HOST_EVENT_RING);
     const auto t0 = std::chrono::steady_clock::now();
@@ -1784,11 +1784,15 @@ static int decide_pushed(sanafe_hip_chip *c, long long t)
         if (__atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) return __atomic_load_n(&e[0], __ATOMIC_RELAXED) <= (long long) c->im.push_max_events ? 1 : 0;
         if ((spins & 0x3fffu) == 0x3fffu)
         {
-            // the stream is idle and the entry is not there (a step reduced before this chip's ring existed), or the device
-            // is stuck (the next synchronising call reports it): pull
+            // Waited long (the device normally publishes within a few steps' time): is the stream idle and the entry not there
+            // (a step reduced before this chip's ring existed), or the device stuck (the next synchronising call reports it)?
+            // Then pull.  (No hipStreamQuery in the common case: on this runtime every query costs the device ~3 us of the
+            // step it interrupts -- C2 ran 17 % slower with a query every few thousand spins.)
+            const auto waited = std::chrono::steady_clock::now() - t0;
+            if (waited < std::chrono::milliseconds(50)) continue;
             const bool idle = hipStreamQuery(c->stream) == hipSuccess;
             if (idle && __atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) continue;
-            if (idle || std::chrono::steady_clock::now() - t0 > std::chrono::seconds(20)) return 0;
+            if (idle || waited > std::chrono::seconds(20)) return 0;
         }
     }
 }
@@ -2310,10 +2314,12 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
         TRY(d2h(c, wp.data(), c->st.wg_part + last_parity * n_parts, n_parts));
         for (uint32_t k = 0; k < c->im.n_cores; k++)
         {
-            double lat = 0.0;
+            double lat4[4] = {0.0, 0.0, 0.0, 0.0};
             long long packets = 0, counted = 0, upd = 0, fired = 0;
-            for (size_t w = (size_t) c->h_core_wg_beg[k] * PARTS_PER_WG; w < (size_t) c->h_core_wg_beg[k + 1] * PARTS_PER_WG; w++)
-                lat += wp[w].lat, packets += wp[w].packets, counted += wp[w].counted, upd += wp[w].updated, fired += wp[w].fired;
+            const size_t wb = (size_t) c->h_core_wg_beg[k] * PARTS_PER_WG;
+            for (size_t w = wb; w < (size_t) c->h_core_wg_beg[k + 1] * PARTS_PER_WG; w++)
+                lat4[(w - wb) & 3u] += wp[w].lat, packets += wp[w].packets, counted += wp[w].counted, upd += wp[w].updated, fired += wp[w].fired;
+            double lat = (lat4[0] + lat4[1]) + (lat4[2] + lat4[3]); // (reduce_l1: four lane-strided sums per core)
             if (c->im.uni_costing && counted != 0) // uniform chips: the default costing is priced per core (reduce_l1)
             {
                 const sanafe_hip_cost_class &cc = c->im.uni_cost;
@@ -2333,20 +2339,18 @@ extern "C" int sanafe_hip_read_core_delays(sanafe_hip_chip *c, double *gen_sum, 
         TRY(d2h(c, sp.data(), c->st.slice_proc + last_parity * c->im.n_slices, c->im.n_slices));
         for (uint32_t k = 0; k < c->im.n_cores; k++)
         {
-            // the association of reduce_l1
+            // the association of reduce_l1: lane q of the core's quad takes slices q, q + 4, ... in two running sums
             const uint32_t s0 = c->h_core_slice_beg[k], s1 = c->h_core_slice_beg[k + 1];
-            double p = 0.0;
-            if (s1 - s0 <= 2u)
+            double lane_sum[4];
+            for (uint32_t q = 0; q < 4u; q++)
             {
-                for (uint32_t q = s0; q < s1; q++) p += sp[q];
+                double a0 = 0.0, a1 = 0.0;
+                uint32_t s = s0 + q;
+                for (; s + 4u < s1; s += 8u) a0 += sp[s], a1 += sp[s + 4u];
+                if (s < s1) a0 += sp[s];
+                lane_sum[q] = a0 + a1;
             }
-            else
-            {
-                double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (uint32_t q = s0; q < s1; q++) a[(q - s0) & 7u] += sp[q];
-                p = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-            }
-            proc_sum[k] = p;
+            proc_sum[k] = (lane_sum[0] + lane_sum[1]) + (lane_sum[2] + lane_sum[3]);
         }
     }
     return 0;

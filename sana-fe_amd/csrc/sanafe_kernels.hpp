@@ -9,6 +9,7 @@ constexpr int PARTS_PER_WG = NEURON_BLOCK / WAVE; // step partials: one per wave
 constexpr int DELIVER_BLOCK = 256;
 constexpr int AX_PER_THREAD = 4;    // axon records per lane: one 8-byte (compact) or two 16-byte (wide) loads
 constexpr int REDUCE_BLOCK = 256;
+constexpr uint32_t L1_CORES = 16;   // cores one wavefront of level 1 of the step reduction folds (four lanes per core)
 constexpr uint32_t SOMA_LDS_MAX = 128; // soma parameter classes staged in LDS by the neuron kernel (7 KiB)
 constexpr uint32_t COST_LDS_MAX = 64;  // cost classes staged in LDS (4 KiB)
 
@@ -36,7 +37,7 @@ struct WgPart
     long long counted; // uniform chips (DevImage::uni_costing): neurons the default costing covers; level 1 of the step
     long long pad;     // reduction prices them per core (idle = counted - updated, updated-only = updated - fired, fired)
 };
-// Level-1 result of the step reduction: 64 consecutive cores folded by one wavefront.
+// Level-1 result of the step reduction: L1_CORES consecutive cores folded by one wavefront.
 struct GroupPart
 {
     double e_soma, e_dend, e_syn, e_net, gmax, pmax;
@@ -72,7 +73,7 @@ struct DevImage
 {
     uint32_t n_cores, n_slots, ring_slots, n_slices, n_input, slot_offset, n_global_slots, max_core_slots, delay_slots;
     uint32_t n_wgs;          // neuron workgroups
-    uint32_t n_groups;       // ceil(n_cores / 64): level-1 reduction groups
+    uint32_t n_groups;       // ceil(n_cores / L1_CORES): level-1 reduction groups
     uint32_t n_reduce_wgs;   // ceil(n_groups / 4): leading workgroups of a neuron launch that reduce earlier steps
     uint32_t n_soma_classes, n_cost_classes;
     int has_lif;             // some slot runs the LIF soma (its input current `icur` is state)
@@ -236,7 +237,7 @@ constexpr uint32_t ORD_PRE_BITS = 27; // dictionary entries: pre slot in 27 bits
 
 // The reduction of a step is split in two levels that ride in the leading workgroups of LATER neuron launches,
 // so a timestep stays two launches and no launch waits on a serial reduction:
-//   level 1 (step s, inside the neuron launch of step s+1, one wavefront per 64 cores): per core, the neuron
+//   level 1 (step s, inside the neuron launch of step s+1, one wavefront per L1_CORES cores, four lanes per core): per core, the neuron
 //           workgroups' partials and the delivery slices' processing delays are summed in a fixed order, then
 //           folded over the 64 cores -> GroupPart[s & 1][group];
 //   level 2 (step s, inside the neuron launch of step s+2, one wavefront): the groups -> Timestep totals,
@@ -288,7 +289,10 @@ struct DevState
 };
 constexpr uint32_t EV_MAX_SEGMENTS = 8;
 constexpr long long DECISION_LAG = 16;    // step s is pushed / delivered by events when step s - DECISION_LAG caused few events
+constexpr long long DECISION_STRIDE = 4;  // ... rounded down to a multiple of this: only every fourth step publishes its count
+                                          // (a store across PCIe costs the launch it rides in ~1 us on the small configurations)
 constexpr long long HOST_EVENT_RING = 64; // entries of DevState::host_events (the host runs < DECISION_LAG steps ahead)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 // Sum over the 64 lanes, returned in every lane.  DPP moves instead of LDS-crossbar shuffles: Hillis-Steele inside
 // each 16-lane row, row_bcast:15 and row_bcast:31 across rows, total in lane 63.  Lanes without a source read
@@ -908,7 +912,6 @@ extern __shared__ __align__(16) unsigned char deliver_lds[];
 
 // The synapse words are read exactly once per launch: non-temporal loads (global_load_dwordx4 ... nt) keep them from
 // displacing the spike bitmap and the axon records in the caches.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 // Keeps the stream loads in program order: the scheduler would otherwise reorder independent loads, and the wait
 // for "the oldest group" (vmcnt) would again cover all of them.
 __device__ __forceinline__ void keep_load_order() { asm volatile("" ::: "memory"); }
@@ -2340,32 +2343,61 @@ ordered_deliver_kernel(DevImage im, DevState st, long long done /* steps simulat
 // run to run.  sim_calculate_ts_energy, sim_update_ts_counters, schedule_messages_timestep_simple
 // (src/chip.cpp:1028-1051, 1171-1261; src/schedule.cpp:61-102), update_run_data (src/chip.cpp:462-475).
 // ---------------------------------------------------------------------------------------
-// Level 1: one wavefront folds 64 consecutive cores, one core per lane.  Per core: its neuron workgroups'
-// partials in workgroup order, the generation-delay sum of its messages incl. the placeholder
-// (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81) and the processing-delay sum of its
-// delivery slices in slice (= reference delivery) order.
+// Sum over the four lanes of a quad, in every lane: (x0 + x1) + (x2 + x3) -- two DPP quad_perm steps, fixed order.
+__device__ __forceinline__ double quad_sum(double x)
+{
+#define SANAFE_QSTEP(CTRL)                                                                       \
+    {                                                                                             \
+        const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xf, 0xf, false); \
+        const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xf, 0xf, false); \
+        x += __hiloint2double(hi, lo);                                                            \
+    }
+    SANAFE_QSTEP(0xb1) // quad_perm:[1,0,3,2]
+    SANAFE_QSTEP(0x4e) // quad_perm:[2,3,0,1]
+#undef SANAFE_QSTEP
+    return x;
+}
+__device__ __forceinline__ long long quad_sum(long long x)
+{
+#define SANAFE_QSTEP(CTRL)                                                                                                      \
+    {                                                                                                                            \
+        const unsigned lo = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) x, CTRL, 0xf, 0xf, false);               \
+        const unsigned hi = (unsigned) __builtin_amdgcn_update_dpp(0, (int) (unsigned) ((unsigned long long) x >> 32), CTRL, 0xf, 0xf, false); \
+        x += (long long) (((unsigned long long) hi << 32) | lo);                                                                 \
+    }
+    SANAFE_QSTEP(0xb1)
+    SANAFE_QSTEP(0x4e)
+#undef SANAFE_QSTEP
+    return x;
+}
+
+// Level 1: one wavefront folds L1_CORES consecutive cores, FOUR LANES PER CORE.  Per core: its neuron workgroups' partials --
+// lane q of the core's quad takes every fourth one, so a core's (up to 16) partials are four loads in flight per lane instead
+// of one lane walking them one memory latency after the other: that walk sat on the critical path of the neuron launch it
+// rides in (C2: 10.5 instead of 7 us per launch) -- the generation-delay sum of its messages incl. the placeholder
+// (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81) and the processing-delay sum of its delivery slices, all in
+// a fixed order: lane-strided partial sums, then (q0 + q1) + (q2 + q3).
 __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, uint32_t group, int push_buf, int pushed_step)
 {
+    // (The order below keeps few values live at a time -- counters first, each folded and stored before the next; then the
+    //  energies -- because this code shares the register budget of the neuron kernels it rides in: 64 for the uniform
+    //  TrueNorth instantiation.)
     const int lane = threadIdx.x & (WAVE - 1);
-    const uint32_t c = group * WAVE + (uint32_t) lane;
-    double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gen = 0, proc = 0;
-    long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
-    if (c < im.n_cores)
+    const uint32_t q = (uint32_t) lane & 3u;
+    const uint32_t c = group * L1_CORES + ((uint32_t) lane >> 2);
+    const bool have = c < im.n_cores;     // (the same for the four lanes of a quad)
+    const bool owner = have && q == 0u;   // the lane that speaks for the core in the fold over the cores
+    const WgPart *part = st.wg_part + (size_t) parity * im.n_wgs * PARTS_PER_WG;
+    const uint32_t w0 = have ? im.core_wg_beg[c] * PARTS_PER_WG : 0u, w1 = have ? im.core_wg_beg[c + 1] * PARTS_PER_WG : 0u;
+    GroupPart *out = &st.group_part[(size_t) parity * im.n_groups + group];
+    // ---- the counters of the core's wavefront partials: lane q takes every fourth partial ----
+    uint32_t n_upd, n_fired, n_counted, n_packets;
     {
-        const WgPart *part = st.wg_part + (size_t) parity * im.n_wgs * PARTS_PER_WG;
-        const uint32_t w0 = im.core_wg_beg[c] * PARTS_PER_WG, w1 = im.core_wg_beg[c + 1] * PARTS_PER_WG;
-        const uint32_t s0 = im.core_slice_beg[c], s1 = im.core_slice_beg[c + 1];
-        const double out_lat = im.core_axon_out_latency[c];
-        double lat = 0;
-        long long counted = 0;
-        for (uint32_t w = w0; w < w1; w++)
+        long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0, counted = 0;
+#pragma unroll 1
+        for (uint32_t w = w0 + q; w < w1; w += 4u) // (not unrolled: four lanes per core already keep four partials in flight)
         {
-            const WgPart p = part[w];
-            e_soma += p.e_soma;
-            e_dend += p.e_dend;
-            e_syn += p.e_syn;
-            e_net += p.e_net;
-            lat += p.lat;
+            const WgPart &p = part[w];
             upd += p.updated;
             fired += p.fired;
             packets += p.packets;
@@ -2373,73 +2405,113 @@ __device__ void reduce_l1(const DevImage &im, const DevState &st, int parity, ui
             events += p.events;
             counted += p.counted;
         }
-        if (im.uni_costing && counted != 0)
-        {
-            // default costing of the core's neurons (src/pipeline.hpp:574-731), from their counts by soma activity
-            const sanafe_hip_cost_class &cc = im.uni_cost;
-            const double n_all = (double) counted, n_f = (double) fired, n_u = (double) (upd - fired), n_i = (double) (counted - upd);
-            e_soma += (n_i * cc.soma_energy[0] + n_u * cc.soma_energy[1]) + n_f * cc.soma_energy[2];
-            e_dend += n_all * cc.dendrite_energy;
-            lat += n_all * (0.0 + cc.dendrite_latency) + ((n_i * cc.soma_latency[0] + n_u * cc.soma_latency[1]) + n_f * cc.soma_latency[2]);
-        }
-        gen = lat + (double) packets * out_lat;
-        // a core's slices: eight interleaved running sums (eight loads in flight), folded in a fixed order
+        upd = quad_sum(upd);
+        fired = quad_sum(fired);
+        packets = quad_sum(packets);
+        counted = quad_sum(counted);
+        n_upd = (uint32_t) upd; // (per core and step: they fit 32 bits)
+        n_fired = (uint32_t) fired;
+        n_counted = (uint32_t) counted;
+        n_packets = (uint32_t) packets;
+        long long x = wave_sum(owner ? upd : 0LL);
+        if (lane == 0) out->updated = x;
+        x = wave_sum(owner ? fired : 0LL);
+        if (lane == 0) out->fired = x;
+        x = wave_sum(owner ? packets : 0LL);
+        if (lane == 0) out->packets = x;
+        hops = quad_sum(hops); // (every lane executes the quad exchange; then one lane per core counts)
+        events = quad_sum(events);
+        x = wave_sum(q == 0u ? hops : 0LL);
+        if (lane == 0) out->hops = x;
+        x = wave_sum(q == 0u ? events : 0LL);
+        if (lane == 0) out->events = x;
+    }
+    asm volatile("" ::: "memory");
+    // ---- processing delay: the core's delivery slices (lane q takes every fourth one, two running sums each), or the
+    //      counters of the push path / the event kernel ----
+    double proc = 0.0;
+    const bool pushed = pushed_step != 0; // (the host's decision: the same value went to the step's own launches)
+    if (!pushed)
+    {
         const double *sp = st.slice_proc + (size_t) parity * im.n_slices;
-        const bool pushed = pushed_step != 0; // (the host's decision: the same value went to the step's own launches)
+        const uint32_t s0 = have ? im.core_slice_beg[c] : 0u, s1 = have ? im.core_slice_beg[c + 1] : 0u;
+        double a0 = 0.0, a1 = 0.0;
+        uint32_t s = s0 + q;
+#pragma unroll 1
+        for (; s + 4u < s1; s += 8u)
+        {
+            a0 += sp[s];
+            a1 += sp[s + 4u];
+        }
+        if (s < s1) a0 += sp[s];
+        proc = quad_sum(a0 + a1);
+    }
+    if (owner)
+    {
         if (pushed)
         {
-            // the push path counted this core's messages and events: integers times the core's constants
+            // the push path / the event kernel counted this core's messages and events: integers times the core's constants
             uint32_t *cnt = st.push_core_cnt + ((size_t) push_buf * im.n_cores + c) * 2u;
             proc = (double) cnt[1] * im.core_event_lat[c] + (double) cnt[0] * im.core_ain_lat[c];
             cnt[0] = 0u;
             cnt[1] = 0u;
         }
-        else if (s1 - s0 <= 2u)
-        {
-            for (uint32_t s = s0; s < s1; s++) proc += sp[s];
-        }
-        else
-        {
-            double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            uint32_t s = s0;
-            for (; s + 8u <= s1; s += 8u)
-            {
-#pragma unroll
-                for (int j = 0; j < 8; j++) a[j] += sp[s + j];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (s + j < s1) a[j] += sp[s + j];
-            proc = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-        }
         // a core that runs on the host has no delivery slices: its message-processing delay comes from the host's replay
         if (st.host_proc != nullptr) proc += st.host_proc[(size_t) parity * im.n_cores + c];
     }
-    e_soma = wave_sum(e_soma);
-    e_dend = wave_sum(e_dend);
-    e_syn = wave_sum(e_syn);
-    e_net = wave_sum(e_net);
-    upd = wave_sum(upd);
-    fired = wave_sum(fired);
-    packets = wave_sum(packets);
-    hops = wave_sum(hops);
-    events = wave_sum(events);
-    const double gmax = wave_max(gen), pmax = wave_max(proc);
-    if (lane == 0)
+    else proc = 0.0;
     {
-        GroupPart gp;
-        gp.e_soma = e_soma;
-        gp.e_dend = e_dend;
-        gp.e_syn = e_syn;
-        gp.e_net = e_net;
-        gp.gmax = gmax;
-        gp.pmax = pmax;
-        gp.updated = upd;
-        gp.fired = fired;
-        gp.packets = packets;
-        gp.hops = hops;
-        gp.events = events;
-        st.group_part[(size_t) parity * im.n_groups + group] = gp;
+        const double pmax = wave_max(proc);
+        if (lane == 0) out->pmax = pmax;
+    }
+    asm volatile("" ::: "memory");
+    // ---- the energies and the latency sum of the partials ----
+    double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, lat = 0;
+#pragma unroll 1
+    for (uint32_t w = w0 + q; w < w1; w += 4u)
+    {
+        const double *pd = reinterpret_cast<const double *>(part + w);
+        const double2 d01 = *reinterpret_cast<const double2 *>(pd), d23 = *reinterpret_cast<const double2 *>(pd + 2);
+        e_soma += d01.x;
+        e_dend += d01.y;
+        e_syn += d23.x;
+        e_net += d23.y;
+        lat += pd[4];
+    }
+    {
+        e_syn = quad_sum(e_syn);
+        e_net = quad_sum(e_net);
+        double x = wave_sum(q == 0u ? e_syn : 0.0);
+        if (lane == 0) out->e_syn = x;
+        x = wave_sum(q == 0u ? e_net : 0.0);
+        if (lane == 0) out->e_net = x;
+    }
+    e_soma = quad_sum(e_soma);
+    e_dend = quad_sum(e_dend);
+    lat = quad_sum(lat);
+    double gen = 0.0;
+    if (owner)
+    {
+        if (im.uni_costing && n_counted != 0u)
+        {
+            // default costing of the core's neurons (src/pipeline.hpp:574-731), from their counts by soma activity
+            const sanafe_hip_cost_class &cc = im.uni_cost;
+            const double n_all = (double) n_counted, n_f = (double) n_fired, n_u = (double) (n_upd - n_fired), n_i = (double) (n_counted - n_upd);
+            e_soma += (n_i * cc.soma_energy[0] + n_u * cc.soma_energy[1]) + n_f * cc.soma_energy[2];
+            e_dend += n_all * cc.dendrite_energy;
+            lat += n_all * (0.0 + cc.dendrite_latency) + ((n_i * cc.soma_latency[0] + n_u * cc.soma_latency[1]) + n_f * cc.soma_latency[2]);
+        }
+        // generation delay of the core's messages incl. the placeholder (src/chip.cpp:640-652, 727-728, 821-823; src/schedule.cpp:81)
+        gen = lat + (double) n_packets * im.core_axon_out_latency[c];
+    }
+    else e_soma = e_dend = 0.0;
+    {
+        double x = wave_sum(e_soma);
+        if (lane == 0) out->e_soma = x;
+        x = wave_sum(e_dend);
+        if (lane == 0) out->e_dend = x;
+        x = wave_max(gen);
+        if (lane == 0) out->gmax = x;
     }
 }
 
@@ -2451,7 +2523,8 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
     const GroupPart *gp = st.group_part + (size_t) prev.parity * im.n_groups;
     double e_soma = 0, e_dend = 0, e_syn = 0, e_net = 0, gmax = 0, pmax = 0;
     long long upd = 0, fired = 0, packets = 0, hops = 0, events = 0;
-    for (uint32_t g = (uint32_t) lane; g < im.n_groups; g += WAVE)
+#pragma unroll 1
+    for (uint32_t g = (uint32_t) lane; g < im.n_groups; g += WAVE) // (not unrolled: it shares the neuron kernels' register budget)
     {
         const GroupPart p = gp[g];
         e_soma += p.e_soma;
@@ -2517,11 +2590,20 @@ __device__ void reduce_l2(const DevImage &im, const DevState &st, const PendStep
         }
         // the step's synaptic events, for the host's push / pull (event / stream) decision DECISION_LAG steps from now:
         // value first, then the step number it belongs to (the host waits for the number)
-        if (st.host_events != nullptr)
+        // (count and step number in ONE 16-byte store to the pinned ring -- a single write on the bus, so the host never pairs a
+        //  new number with an old count -- written THROUGH to system scope (sc0 sc1) so that the host sees it when this wavefront
+        //  has stored it, not at some later cache write-back, and with no release fence: a system-scope release here writes the
+        //  XCD's L2 back in the middle of the neuron launch, +3 us per step on the small configurations)
+        if (st.host_events != nullptr && ((*st.t + 1) % DECISION_STRIDE) == 0)
         {
-            long long *e = st.host_events + 2 * ((*st.t + 1) % HOST_EVENT_RING);
-            __hip_atomic_store(&e[0], events, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(&e[1], *st.t + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long ev_u = (unsigned long long) events, n_u = (unsigned long long) (*st.t + 1);
+            u32x4_t rec;
+            rec.x = (uint32_t) ev_u;
+            rec.y = (uint32_t) (ev_u >> 32);
+            rec.z = (uint32_t) n_u;
+            rec.w = (uint32_t) (n_u >> 32);
+            long long *dst = st.host_events + 2 * ((*st.t + 1) % HOST_EVENT_RING);
+            asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(rec) : "memory");
         }
         if (st.delay_log != nullptr) st.delay_log[*st.t % st.delay_log_cap] = local_max;
         *st.t = *st.t + 1;

@@ -162,7 +162,10 @@ public:
             const py::array_t<uint8_t> &lp, py::object keep)
     {
         sanafe_chip *out = nullptr;
-        if (carry_state && h)
+        // (the flag is consumed here, whatever happens below: a load that fails must not leave the next one carrying state)
+        const bool carry = carry_state;
+        carry_state = false;
+        if (carry && h)
         {
             // load(net, overwrite=False) after timesteps have run: the programmed neurons' state moves into the new lowering
             const int rc = sanafe_chip_create(reinterpret_cast<const sanafe_desc *>(desc_address), device, n_ranks, rank, &out);
@@ -213,7 +216,9 @@ public:
     {
         if (!py::isinstance<SpikingNetwork>(net)) throw std::invalid_argument("load() takes a sanafecpp_amd.Network");
         py::object to_lower = net;
-        if (h && !overwrite)
+        carry_state = false;
+        const bool add = h && !overwrite;
+        if (add)
         {
             carry_state = sanafe_chip_total_timesteps(h) > 0; // (src/chip.cpp:129-138: every programmed unit keeps its state)
             // the groups of the new network are mapped after the programmed ones (ids, mapping order and per-core
@@ -222,12 +227,7 @@ public:
             SpikingNetwork &m = merged.cast<SpikingNetwork &>();
             for (const py::object &n : nets) m.absorb(n.cast<SpikingNetwork &>());
             m.absorb(net.cast<SpikingNetwork &>());
-            nets.push_back(net);
             to_lower = merged;
-        }
-        else
-        {
-            nets.assign(1, net);
         }
         SpikingNetwork &n = to_lower.cast<SpikingNetwork &>();
         auto built = std::shared_ptr<BuiltDesc>(to_desc(arch.cast<Architecture &>(), n).release());
@@ -242,7 +242,18 @@ public:
         // the description borrows the network's edge arrays: keep both alive with the chip
         py::object keep = py::make_tuple(py::capsule(new std::shared_ptr<BuiltDesc>(built), [](void *p) { delete static_cast<std::shared_ptr<BuiltDesc> *>(p); }),
                 to_lower, arch);
-        adopt(reinterpret_cast<uintptr_t>(&built->desc), groups, ls, lp, keep);
+        try
+        {
+            adopt(reinterpret_cast<uintptr_t>(&built->desc), groups, ls, lp, keep);
+        }
+        catch (...)
+        {
+            carry_state = false; // a refused or failed load leaves the chip as it was: programmed nets unchanged, no pending carry
+            throw;
+        }
+        // only now is the network part of the chip
+        if (add) nets.push_back(net);
+        else nets.assign(1, net);
     }
 
     py::tuple label(int64_t gid) const // NeuronAddress(group_name, neuron_offset)

@@ -49,9 +49,10 @@ def test_event_or_stream_decided_per_step(S, monkeypatch):
     chip, orc, tot = check_batched(S, arch, net, steps=40)
     lay = chip.device_layout()
     assert lay["event_layout"] is not None and not lay["event_layout"]["always"], lay
-    # step t goes by events when step t - 16 caused at most SANAFE_EVENT_MAX_EVENTS events: the first sixteen and the busy ones stream
+    # step t (1-based) goes by events when step (t - 16) rounded down to a multiple of 4 caused at most SANAFE_EVENT_MAX_EVENTS
+    # events: the first nineteen and the busy ones stream
     ev = chip.step_totals(0, 40)["spikes"]
-    expect = sum(1 for t in range(16, 40) if ev[t - 16] <= 7400)
+    expect = sum(1 for t in range(1, 41) if (t - 16) // 4 * 4 >= 1 and ev[(t - 16) // 4 * 4 - 1] <= 7400)
     assert lay["pushed_steps"] == expect and 4 <= expect <= 20, (lay, expect)
     monkeypatch.setenv("SANAFE_EVENT", "0")
     monkeypatch.setenv("SANAFE_PUSH", "0")
@@ -121,7 +122,7 @@ def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind
     for _ in range(6):
         orc.step("simple")
     before, pushed_before = chip.read_totals(), chip.device_layout()["pushed_steps"]
-    assert pushed_before == 0  # (no history yet: the first sixteen steps pull)
+    assert pushed_before == 0  # (no history yet: the first nineteen steps pull)
     ref = {k: 0 for _, k in INT_KEYS}
     ref_d = {k: 0.0 for k in DBL_KEYS}
     for t in range(16):
@@ -141,4 +142,4 @@ def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind
         assert after[ka] - before[ka] == ref[kb], ka
     for k in DBL_KEYS:
         assert after[k] - before[k] == pytest.approx(ref_d[k], rel=1e-9, abs=1e-30), k
-    assert chip.device_layout()["pushed_steps"] == 6  # steps 17 .. 22: the steps sixteen before them caused few events
+    assert chip.device_layout()["pushed_steps"] == 3  # steps 20 .. 22: decided from steps 4 .. 4 (16 back, rounded down to a multiple of 4)

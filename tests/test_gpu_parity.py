@@ -249,10 +249,11 @@ def test_push_delivery_on_steps_with_few_spikes(S, monkeypatch, net_kind):
     chip, orc, tot = check_batched(S, arch, net, steps=40)  # one sim() call: the host decides while the device runs
     lay = chip.device_layout()
     assert lay["push_enabled"] and lay["push_only"] == (net_kind == "truenorth_push_only"), lay
-    # step t is pushed when step t - 16 caused at most SANAFE_PUSH_MAX_EVENTS events: a pure function of the run
+    # step t (1-based) is pushed when step (t - 16) rounded down to a multiple of 4 caused at most SANAFE_PUSH_MAX_EVENTS events:
+    # a pure function of the run
     ev = chip.step_totals(0, 40)["spikes"]
     limit = int(os.environ["SANAFE_PUSH_MAX_EVENTS"])
-    expect = 40 if net_kind == "truenorth_push_only" else sum(1 for t in range(16, 40) if ev[t - 16] <= limit)
+    expect = 40 if net_kind == "truenorth_push_only" else sum(1 for t in range(1, 41) if (t - 16) // 4 * 4 >= 1 and ev[(t - 16) // 4 * 4 - 1] <= limit)
     assert lay["pushed_steps"] == expect and (expect >= 12 or net_kind == "truenorth"), (lay, expect)
     monkeypatch.setenv("SANAFE_PUSH", "0")
     pull = S.SpikingChip(arch)
@@ -786,10 +787,13 @@ def test_uniform_and_table_driven_neuron_kernels_agree(S, monkeypatch, which):
     chip_u2 = S.SpikingChip(arch)
     chip_u2.load(net)
     b = chip_u2.run(15, "simple", record=True)
-    assert a == b  # RunData incl. energies and sim_time: both kernels use the same fixed associations
+    # counters identical; energies and sim_time to the last bits only: the uniform kernel leaves COUNTS per wavefront and level 1
+    # of the step reduction prices them once per core, the table-driven kernel prices per wavefront (different associations)
+    for k in a:
+        assert a[k] == (b[k] if isinstance(a[k], int) else pytest.approx(b[k], rel=1e-12, abs=1e-30)), k
     ra, rb = chip_g.step_totals(0, 15), chip_u2.step_totals(0, 15)
     for k in ra.dtype.names:
-        assert np.array_equal(ra[k], rb[k]), k
+        assert np.array_equal(ra[k], rb[k]) if ra[k].dtype.kind == "i" else np.allclose(ra[k], rb[k], rtol=1e-12, atol=0), k
     assert np.array_equal(chip_g.potentials(), chip_u2.potentials())
     assert np.array_equal(chip_g.potentials(), orc.potentials())
 

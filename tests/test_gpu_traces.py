@@ -259,6 +259,44 @@ def test_load_without_overwrite_after_timesteps_keeps_the_state(S):
     assert np.array_equal(v[:200], alone_a.potentials()) and np.array_equal(v[200:], alone_b.potentials())
 
 
+def test_refused_load_without_overwrite_leaves_the_chip_usable(S):
+    """load(net, overwrite=False) after timesteps on a chip whose state cannot be carried (here: a TrueNorth
+    `random_mask`, i.e. a host-generated value stream) raises -- and must leave no trace: the programmed network stays as it
+    was, and a later load(other, overwrite=True) starts from fresh state instead of running the carry path again."""
+    def build(name, n, core_idx, seed, arch, mask):
+        rng = np.random.default_rng(seed)
+        net = S.Network(name)
+        attrs = {"reset": 0, "leak": 1}
+        if mask:
+            attrs["random_mask"] = 3
+        g = net.create_neuron_group(name, n, attrs, "core_synapses", "core_dendrites", False, True, "core_soma")
+        g.set_attribute_column("threshold", rng.integers(5, 30, size=n).astype(np.float64), integer=True)
+        g.set_attribute_column("bias", np.where(rng.random(n) < 0.4, rng.integers(2, 7, size=n), 0).astype(np.float64), integer=True)
+        src = np.repeat(np.arange(n, dtype=np.int64), 4)
+        net.add_edges(src, rng.integers(0, n, size=4 * n).astype(np.int64), rng.integers(1, 5, size=4 * n).astype(np.float64), "core_synapses")
+        g.map_to_core(arch.cores()[core_idx], 0, n)
+        return net
+
+    arch = S.presets.truenorth(n_tiles=8, width=4, height=2)
+    chip = S.SpikingChip(arch)
+    chip.load(build("a", 120, 0, 1, arch, mask=True))
+    chip.sim(7, timing_model="simple")
+    with pytest.raises((NotImplementedError, RuntimeError)):
+        chip.load(build("b", 90, 3, 2, arch, mask=False))  # overwrite=False after timesteps: value streams cannot be carried
+    assert chip.n_neurons == 120 and chip.total_timesteps == 7  # the programmed chip is untouched ...
+    more = chip.sim(3, timing_model="simple")                   # ... and still simulates
+    assert more["timestep_start"] == 8
+    chip.load(build("b", 90, 3, 2, arch, mask=False), overwrite=True)  # a fresh chip: no state carried, no leftover network
+    assert chip.n_neurons == 90 and chip.total_timesteps == 0
+    alone = S.SpikingChip(arch)
+    alone.load(build("b", 90, 3, 2, arch, mask=False))
+    a, b = chip.sim(11, timing_model="simple"), alone.sim(11, timing_model="simple")
+    assert a["neurons_fired"] == b["neurons_fired"] > 0 and a["spikes"] == b["spikes"]
+    assert np.array_equal(chip.potentials(), alone.potentials())
+    chip.load(build("c", 40, 5, 3, arch, mask=False))  # and adding a network to it works again (state carried by global id)
+    assert chip.n_neurons == 130 and chip.total_timesteps == 11
+
+
 def test_sim_releases_the_gil_and_polls_signals(S):
     """pysim releases the GIL around the simulation and polls PyErr_CheckSignals (src/pymodule.cpp:628-666): other
     Python threads run during sim(), and Ctrl-C interrupts it between chunks."""
