@@ -524,8 +524,6 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     for (uint32_t g = NG; g-- > 0;)
         if (group_slice_beg[g] > group_slice_beg[g + 1]) group_slice_beg[g] = group_slice_beg[g + 1]; // (a group without slices)
     const uint64_t N = h.n_global_slots;
-    const uint64_t row = (uint64_t) NG + 1u;
-    if (N * row >= (1ull << 32)) return 0;
     // pass 1: words and core masks per (source neuron, group)
     std::vector<uint32_t> cnt(N * NG, 0u);
     std::vector<uint16_t> mask(N * NG, 0);
@@ -569,33 +567,37 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     }
     if (const char *env = std::getenv("SANAFE_EVENT_SEGMENTS")) segments = (uint32_t) std::max(1L, std::atol(env));
     segments = std::min(std::min(segments, n_tiles), EV_MAX_SEGMENTS); // (one row of partials per segment, DevState::ev_part)
-    // pass 2: offsets.  meta[n][g] = first unit of the block (relative to the neuron's base) | mask << 16; meta[n][NG] = end
-    std::vector<uint32_t> meta(N * row, 0u);
-    std::vector<uint32_t> base(N + 1, 0u);
+    // pass 2: offsets, NEURON-major: the blocks of a neuron lie group after group, neuron after neuron (the ~70 workgroups that
+    // need a fired neuron's blocks read one contiguous 5 KB region at about the same time: each 128-byte line comes out of
+    // HBM once and is served to the other XCDs by the Infinity Cache; with the blocks of a GROUP together -- tried -- every
+    // line is private to one workgroup and the launch is HBM-bound on half-used lines: 97 instead of 71 us at 10 % activity).
+    // meta[n][g] = first 16-byte unit of block (n, g) | core mask << 32; meta[n][NG] = the end of the neuron's blocks
+    const uint64_t mrow = (uint64_t) NG + 1u;
+    std::vector<uint64_t> meta(N * mrow, 0ull);
+    std::vector<uint64_t> neuron_units(N + 1, 0ull);
     parallel_for(N, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++)
         {
-            uint32_t off = 0;
-            for (uint32_t g = 0; g < NG; g++)
-            {
-                meta[n * row + g] = off | ((uint32_t) mask[n * NG + g] << 16);
-                off += (cnt[n * NG + g] + 7u) / 8u;
-                if (off > 0xffffu) bad = true;
-            }
-            meta[n * row + NG] = off;
-            base[n + 1] = off;
+            uint64_t units = 0;
+            for (uint32_t g = 0; g < NG; g++) units += (cnt[n * NG + g] + 7u) / 8u;
+            neuron_units[n + 1] = units;
         }
     });
-    if (bad.load()) return 0;
-    uint64_t total_units = 0;
-    for (uint64_t n = 0; n < N; n++)
-    {
-        const uint32_t units = base[n + 1];
-        base[n] = (uint32_t) total_units;
-        total_units += units;
-        if (total_units >= (1ull << 32)) return 0;
-    }
-    base[N] = (uint32_t) total_units;
+    for (uint64_t n = 0; n < N; n++) neuron_units[n + 1] += neuron_units[n];
+    const uint64_t total_units = neuron_units[N];
+    if (total_units >= (1ull << 32)) return 0;
+    parallel_for(N, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t n = lo; n < hi; n++)
+        {
+            uint64_t off = neuron_units[n];
+            for (uint32_t g = 0; g < NG; g++)
+            {
+                meta[n * mrow + g] = off | ((uint64_t) mask[n * NG + g] << 32);
+                off += (cnt[n * NG + g] + 7u) / 8u;
+            }
+            meta[n * mrow + NG] = off;
+        }
+    });
     // pass 3: the words, group by group (a block is written by one thread); cnt becomes the write cursor.  Per (segment,
     // accumulator): events and |weight| sums, for the bounds of the integer accumulators.
     std::vector<uint16_t> words((total_units + 64u) * 8u, 0);
@@ -619,7 +621,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
                     const uint64_t n = h.ax_pre[a];
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const size_t sg = (size_t) std::min<uint32_t>((uint32_t) (n / EV_TILE) / seg_tiles, segments - 1u) * acc_max;
-                    uint64_t at = ((uint64_t) base[n] + (meta[n * row + g] & 0xffffu)) * 8u + cnt[n * NG + g];
+                    uint64_t at = (meta[n * mrow + g] & 0xffffffffull) * 8u + cnt[n * NG + g];
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t idx = acc0 + (h.syn_meta[src + k] & 0xffffu);
@@ -631,6 +633,12 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
                 }
             }
             for (size_t q = 0; q < count.size(); q++) mc = std::max<uint64_t>(mc, count[q]), ma = std::max(ma, abs_sum[q]);
+            // padding words of every block: code 0 into the trash entries behind the group's accumulators
+            for (uint64_t n = 0; n < N; n++)
+            {
+                const uint64_t b0 = (meta[n * mrow + g] & 0xffffffffull) * 8u, b1 = (meta[n * mrow + g + 1] & 0xffffffffull) * 8u;
+                for (uint64_t p = b0 + cnt[n * NG + g]; p < b1; p++) words[p] = (uint16_t) ((groups[g].n_acc + (uint32_t) (p & (EV_TRASH - 1u))) << code_bits);
+            }
         }
         uint64_t seen = max_count.load();
         while (seen < mc && !max_count.compare_exchange_weak(seen, mc)) {}
@@ -640,23 +648,12 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     int shift = 1;
     while ((1ull << (shift - 1)) <= max_abs.load() && shift < 32) shift++;
     if (shift > 15 || ((max_count.load() + 1ull) << shift) > (1ull << 32)) return 0; // (weight + 2^shift: 16 bits in the kernel's table)
-    // padding words of every block: code 0 into the trash entries behind the group's accumulators
-    parallel_for(N, [&](uint64_t lo, uint64_t hi) {
-        for (uint64_t n = lo; n < hi; n++)
-            for (uint32_t g = 0; g < NG; g++)
-            {
-                const uint64_t b0 = ((uint64_t) base[n] + (meta[n * row + g] & 0xffffu)) * 8u;
-                const uint64_t b1 = ((uint64_t) base[n] + (meta[n * row + g + 1] & 0xffffu)) * 8u;
-                for (uint64_t p = b0 + cnt[n * NG + g]; p < b1; p++) words[p] = (uint16_t) ((groups[g].n_acc + (uint32_t) (p & (EV_TRASH - 1u))) << code_bits);
-            }
-    });
     std::vector<uint32_t> chunk_core(h.n_slots / 64, 0u);
     for (uint32_t k = 0; k < h.n_cores; k++)
         for (uint32_t q = 0; q < (h.core_ncount[k] + 63u) / 64u; q++) chunk_core[h.core_nbase[k] / 64u + q] = k;
     lut.resize(32, 0.0);
     TRY(upload(c, groups.data(), groups.size(), &im.ev_group));
-    TRY(upload(c, base.data(), base.size(), &im.ev_base));
-    TRY(upload(c, meta.data(), meta.size(), &im.ev_meta));
+    TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta.data()), meta.size(), &im.ev_meta));
     TRY(upload(c, words.data(), words.size(), &im.ev_words));
     TRY(upload(c, chunk_core.data(), chunk_core.size(), &im.ev_chunk_core));
     TRY(upload(c, lut.data(), lut.size(), &im.ev_lut));
@@ -672,17 +669,17 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // the per-step decision rides on the push machinery (reduce_l2 decides, reduce_l1 prices the per-core counters)
     im.push_cap = h.n_slots / WAVE;
     im.push_always = im.ev_always;
-    // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~12 us + 0.87 us per million events,
+    // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~11 us + 0.75 us per million events,
     // the streaming kernel 245 us whatever the activity (and up to 0.8 ms when so few axons spike that its windows fall back
-    // to the gather path): they cross at ~39 % of the neurons firing, 0.39 events per synapse and step
-    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.37));
+    // to the gather path): they cross at ~46 % of the neurons firing, 0.46 events per synapse and step
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.42));
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
     c->ev_waves = 16;
     if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 8 ? 8 : std::atoi(env) == 4 ? 4 : 16;
     c->layout_bytes[9] = total_units * 16ull;
-    c->layout_bytes[10] = meta.size() * 4ull + base.size() * 4ull;
+    c->layout_bytes[10] = meta.size() * 8ull;
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
     c->ev_lpb = c->ev_avg_block > 32.0 ? 8 : 4; // lanes (16-byte units) per block and batch
     if (const char *env = std::getenv("SANAFE_EVENT_LPB")) c->ev_lpb = std::atoi(env) == 8 ? 8 : 4;

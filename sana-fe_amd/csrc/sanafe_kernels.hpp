@@ -187,11 +187,13 @@ struct DevImage
     const double *ord_w;                // the entries' weights (no dictionary), same indexing
     int ord_dict;                       // weights are 5-bit codes into weight_lut
     // Event-driven delivery (event_deliver_kernel): the reference touches only the synapses behind the messages that arrived
-    // (src/chip.cpp:738-764).  A second copy of the format-7 words, regrouped SOURCE-NEURON-major: the destination cores are
-    // cut into groups whose accumulators fit one workgroup's LDS (EvGroup), and the words a neuron sends into a group lie in
-    // one contiguous, 16-byte aligned BLOCK, the blocks of a neuron group after group.  A step with few spikes then reads the
-    // spike bitmap, per (fired neuron, group) one 8-byte table entry, and that neuron's blocks -- work and bytes in proportion
-    // to the step's synaptic events instead of to the chip's synapses.  Which kernel delivers a step is decided on the device
+    // (src/chip.cpp:738-764).  A second copy of the format-7 words, regrouped by SOURCE neuron: the destination cores are cut
+    // into groups whose accumulators fit one workgroup's LDS (EvGroup), and the words a neuron sends into a group lie in one
+    // contiguous, 16-byte aligned BLOCK; the blocks of a NEURON lie group after group (one ~5 KB region per neuron that all
+    // the groups' workgroups read at about the same time: a 128-byte line comes out of HBM once, the Infinity Cache serves
+    // the other XCDs).  A step with few spikes then reads the spike bitmap, per (fired neuron, group) two adjacent 8-byte
+    // table entries, and that neuron's blocks -- work and bytes in proportion to the step's synaptic events instead of to
+    // the chip's synapses.  Which kernel delivers a step is decided on the device
     // by the host like push delivery (push_max_events); both are exact for any activity.  ev_groups == 0: not built.
     uint32_t ev_groups;           // core groups
     uint32_t ev_segments;         // the source space is cut into this many segments of ev_seg_tiles tiles: grid = groups x segments
@@ -200,10 +202,9 @@ struct DevImage
     uint32_t ev_always;           // 1: every step is delivered by events, the streaming kernel is never launched (tests)
     int ev_shift;                 // every event adds weight + 2^ev_shift; bounds proven per (segment, accumulator)
     const struct EvGroup *ev_group;   // [ev_groups]
-    const uint32_t *ev_base;      // [n_global_slots + 1] first 16-byte unit of each source neuron's blocks
-    const uint32_t *ev_meta;      // [n_global_slots][ev_groups + 1]: bits 0-15 first unit of the neuron's block for the group,
-                                  // relative to ev_base; bits 16-31 which cores of the group it reaches (one message each).
-                                  // Entry [ev_groups]: the end.  A block's length is the next entry's offset minus its own.
+    const unsigned long long *ev_meta; // [n_global_slots][ev_groups + 1]: bits 0-31 first 16-byte unit of block (neuron, group);
+                                  // bits 32-47 which cores of the group the neuron reaches (one message each).  Entry
+                                  // [ev_groups]: the end.  A block's length is the next entry's offset minus its own.
     const uint16_t *ev_words;     // weight code (ev_code_bits) | accumulator index << ev_code_bits; padding words add into the
                                   // trash entries behind the group's accumulators
     const uint32_t *ev_chunk_core; // [n_slots / 64] local core of each 64-slot chunk
@@ -1908,6 +1909,15 @@ constexpr uint32_t EV_TILE = 1024;      // source slots per tile: 16 per lane
 constexpr uint32_t EV_LIST_CAP = 1536;  // per wavefront (16-bit entries): a tile adds at most 1,024, the list is drained from 512 on
 constexpr uint32_t EV_DRAIN_AT = 512;
 constexpr uint32_t EV_TRASH = 64;       // accumulators behind a group's own that padding words add into
+// (plain loads: consecutive fired neurons' blocks share 128-byte lines, which the caches should keep for the neighbour)
+__device__ __forceinline__ uint4 ev_load16(const uint4 *p)
+{
+#ifdef SANAFE_EVENT_NT_LOADS
+    return load_stream16(p);
+#else
+    return *p;
+#endif
+}
 template <int LPB, int CODE_BITS, int WAVES>
 __global__ void __launch_bounds__(WAVES * WAVE)
 event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
@@ -1933,7 +1943,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     if (threadIdx.x < 16) s_msgs[threadIdx.x] = s_events[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
-    const uint32_t row = im.ev_groups + 1u; // entries of a neuron in ev_meta
+    const size_t mrow = (size_t) im.ev_groups + 1u; // entries of a neuron in ev_meta
     uint16_t *list = s_list[wave];
     const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
     uint32_t msg_cnt[(16 + LPB - 1) / LPB];        // messages to core q, q + LPB, ... of the group, over this lane's neurons
@@ -1958,7 +1968,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     };
     struct Meta
     {
-        uint32_t m0, m1, base;
+        unsigned long long m0, m1;
         bool have;
     };
     struct Words
@@ -1974,19 +1984,18 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         auto fetch_meta = [&](uint32_t b, Meta &m) {
             m.have = b + j < len;
             const uint32_t f = list_slot0 + (uint32_t) list[m.have ? b + j : b];
-            const uint32_t *mrow = im.ev_meta + (size_t) f * row + g;
-            m.m0 = mrow[0];
-            m.m1 = mrow[1];
-            m.base = im.ev_base[f];
+            const unsigned long long *me = im.ev_meta + (size_t) f * mrow + g;
+            m.m0 = me[0];
+            m.m1 = me[1];
         };
         auto fetch_words = [&](const Meta &m, Words &w) {
-            w.units = m.have ? (m.m1 - m.m0) & 0xffffu : 0u;
-            w.unit0 = m.base + (m.m0 & 0xffffu);
+            w.units = m.have ? (uint32_t) m.m1 - (uint32_t) m.m0 : 0u;
+            w.unit0 = (uint32_t) m.m0;
             // (lanes without a unit read the block's first unit -- or, for an empty block, whatever follows: the array is padded)
-            w.w = load_stream16(words + (size_t) w.unit0 + (q < w.units ? q : 0u));
+            w.w = ev_load16(words + (size_t) w.unit0 + (q < w.units ? q : 0u));
             if (m.have)
             {
-                const uint32_t mask = m.m0 >> 16;
+                const uint32_t mask = (uint32_t) (m.m0 >> 32);
 #pragma unroll
                 for (uint32_t mm = 0; mm < (16 + LPB - 1) / LPB; mm++) msg_cnt[mm] += (mask >> (q + mm * LPB)) & 1u;
             }
@@ -2004,7 +2013,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
             if (q < wc.units) add8(wc.w);
             // blocks of more than LPB units: the rest, LPB units at a time
             for (uint32_t u = q + LPB; __ballot(u < wc.units) != 0ull; u += LPB)
-                if (u < wc.units) add8(load_stream16(words + (size_t) wc.unit0 + u));
+                if (u < wc.units) add8(ev_load16(words + (size_t) wc.unit0 + u));
         }
         wave_lds_fence(); // the list is rewritten
     };
