@@ -391,11 +391,6 @@ def collect_traffic_inline(args, n_launch_tail):
             d["hbm_bytes_per_launch"] = d["fetch_bytes_corrected"] + d["write_bytes"]
     if not any("hbm_bytes_per_launch" in d for d in res.values()):
         return None, "no neuron_kernel / deliver_kernel counter rows in the rocprofv3 output"
-    if "event_deliver_kernel" in res and "deliver_kernel" in res and "hbm_bytes_per_launch" in res["event_deliver_kernel"]:
-        # chips with the event layout launch both delivery kernels every step, one of them returns at once: a step's
-        # delivery traffic is the sum
-        res["event_deliver_kernel"]["hbm_bytes_per_launch"] += res["deliver_kernel"].get("hbm_bytes_per_launch", 0.0)
-        res["deliver_kernel"]["hbm_bytes_per_launch"] = res["event_deliver_kernel"]["hbm_bytes_per_launch"]
     return res, None
 
 
@@ -558,19 +553,20 @@ def main():
         by_events = (layout_now["pushed_steps"] - pushed_before) / float(args.timed_steps) if evl else 0.0
         if evl:
             # Steps delivered by events (event_deliver_kernel) read: every workgroup its segment of the spike bitmap
-            # (groups x bitmap), per fired neuron and core group 8 + 4 bytes of the block tables, the fired neurons' blocks
-            # of 2-byte words (padded to 16 bytes per block: layout bytes / synapses per word on average), and write back
-            # 17 bytes per (segment, neuron) that received an event (atomics: the segments of a group share its neurons).
-            n_acc = float(evl["segments"]) * float(info["n_neurons"])
-            touched = n_acc * (1.0 - np.exp(-ev / n_acc)) if n_acc > 0 else 0.0
-            ev_parts = {"spike_bitmap_scans": evl["groups"] * lay[4], "block_tables": 12.0 * fired * evl["groups"],
+            # (groups x bitmap), per fired neuron and core group two 8-byte entries of the block table, the fired neurons'
+            # blocks of 2-byte words (padded to 16 bytes per block: layout bytes / synapses per word on average), and write
+            # one 4-byte partial per (segment, neuron slot) -- every accumulator, touched or not -- which the next neuron
+            # launch reads back (counted there)
+            ev_parts = {"spike_bitmap_scans": evl["groups"] * lay[4], "block_tables": 16.0 * fired * evl["groups"],
                         "synapse_words_of_fired_neurons": ev * lay[9] / max(1.0, float(info["n_synapses"])),
-                        "write_back": 17.0 * touched}
+                        "partial_rows_written": 4.0 * evl["segments"] * float(info["n_slots"])}
             design_event = float(sum(ev_parts.values()))
             design_deliver = by_events * design_event + (1.0 - by_events) * design_stream
             if by_events >= 0.5:
                 deliver_name, deliver_parts = "event_deliver_kernel", ev_parts
         design_neuron = float(lay[5] + lay[6]) + lay[7] * fired
+        if evl:  # after a step delivered by events the neuron launch reads all eight partial rows instead of the buffer row
+            design_neuron += by_events * 4.0 * 8.0 * float(info["n_slots"])
         # (2) SURVEY 8(d)'s byte model (48 B per neuron update, 28 B per synaptic event, 96 B per message): it prices
         #     12-byte synapses, HBM accumulators and materialised 40-byte messages, none of which this design moves, so
         #     on dense workloads it exceeds 1 -- kept as a secondary figure only (frac_contract_model).

@@ -128,6 +128,8 @@ struct sanafe_hip_chip
     int cur_pushed{0};               // mode of the step whose neuron launch went out last
     long long pushed_steps{0};       // steps delivered by the push path / the event kernel since create
     long long ev_pending{-1};        // t_host after the step whose input still lies in DevState::ev_part (-1: none)
+    long long dbg_waits{0}, dbg_fallbacks{0}; // decide_pushed: decisions that had to wait for the device / gave up (SANAFE_DEBUG_DECIDE)
+    double dbg_wait_ms{0.0};
     double ev_avg_block{0.0};        // words per (source neuron, core group) block
     uint32_t ev_grid{0};
     uint32_t deliver_block{0};
@@ -386,7 +388,7 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     if (std::getenv("SANAFE_PUSH") != nullptr && std::atoi(std::getenv("SANAFE_PUSH")) == 0) return 0; // tests / A-B runs
     // (the integer formats whose kernels have a PUSH instantiation: 7, and 0 / 3 on integer accumulators)
     const bool integer_weights = c->syn_format == 7 || ((c->syn_format == 0 || c->syn_format == 3) && c->acc_shift > 0);
-    if (!integer_weights || h.n_global_slots != h.n_slots || c->has_delay || im.has_last || h.n_taps != 0 || h.n_ext != 0 ||
+    if (!integer_weights || c->has_delay || im.has_last || h.n_taps != 0 || h.n_ext != 0 ||
             h.n_synapses == 0 || h.n_synapses > (64ull << 20) || h.ax_lat_class == nullptr || h.ring_slots < 2)
         return 0; // (two rows of the time-step buffer: the neuron launch adds to the next step's row while it reads this step's)
     for (uint32_t g = 0; g < h.n_slots; g++)
@@ -406,9 +408,11 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
         }
     for (uint32_t k = 0; k < h.n_cores; k++)
         if (cls[k] >= 0) ev_lat[k] = h.lat_class_per_event ? h.lat_class_per_event[cls[k]] : 0.0;
-    std::vector<uint32_t> ptr(h.n_slots + 1, 0);
+    // by GLOBAL source slot: on a tile-sharded chip the lists of the other ranks' neurons (their synapses into THIS chip) are
+    // walked by remote_push_kernel after the all-gather of the spike bitmap
+    std::vector<uint32_t> ptr((size_t) h.n_global_slots + 1, 0);
     for (uint64_t a = 0; a < h.n_axons; a++) ptr[h.ax_pre[a] + 1] += h.ax_nsyn[a];
-    for (uint32_t g = 0; g < h.n_slots; g++) ptr[g + 1] += ptr[g];
+    for (uint32_t g = 0; g < h.n_global_slots; g++) ptr[g + 1] += ptr[g];
     std::vector<PushEntry> syn(h.n_synapses);
     std::vector<uint32_t> cur(ptr.begin(), ptr.end() - 1);
     for (uint32_t sl = 0; sl < h.n_slices; sl++)
@@ -437,7 +441,8 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
     {
         double degree = 1.0;
         if (const char *env = std::getenv("SANAFE_PUSH_ONLY_DEGREE")) degree = std::atof(env);
-        im.push_always = (double) h.n_synapses <= degree * (double) h.n_slots ? 1u : 0u;
+        // (a rank of a tile-sharded chip holds the synapses INTO its neurons: about one per neuron, not exactly: 10 % slack)
+        im.push_always = (double) h.n_synapses <= degree * (double) h.n_slots * (h.n_global_slots != h.n_slots ? 1.1 : 1.0) ? 1u : 0u;
         if (const char *env = std::getenv("SANAFE_PUSH_ONLY")) im.push_always = std::atoi(env) != 0 ? 1u : 0u;
     }
     // a pushed event costs three atomics inside the neuron launch; the pull path one probe per inbound axon of the chip, whatever the activity
@@ -1670,6 +1675,9 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
                  (void *) c->d_host_b, (void *) c->d_host_costs, (void *) c->d_ext, (void *) c->d_soma_classes,
                  (void *) c->d_in_beg, (void *) c->d_in_len, (void *) c->d_in_bits, (void *) c->d_in_period})
         if (p) (void) hipFree(p);
+    if (c->h_events && std::getenv("SANAFE_DEBUG_DECIDE"))
+        std::fprintf(stderr, "[sanafe_hip] decide: %lld steps, %lld pushed, %lld waited for the device (%.2f ms in all), %lld gave up\n",
+                c->t_host, c->pushed_steps, c->dbg_waits, c->dbg_wait_ms, c->dbg_fallbacks);
     if (c->h_events) (void) hipHostFree(c->h_events);
     if (c->stream && c->own_stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -1778,7 +1786,15 @@ static int decide_pushed(sanafe_hip_chip *c, long long t)
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned long long spins = 0;; spins++)
     {
-        if (__atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) return __atomic_load_n(&e[0], __ATOMIC_RELAXED) <= (long long) c->im.push_max_events ? 1 : 0;
+        if (__atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n)
+        {
+            if (spins > 0)
+            {
+                c->dbg_waits++;
+                c->dbg_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            return __atomic_load_n(&e[0], __ATOMIC_RELAXED) <= (long long) c->im.push_max_events ? 1 : 0;
+        }
         if ((spins & 0x3fffu) == 0x3fffu)
         {
             // Waited long (the device normally publishes within a few steps' time): is the stream idle and the entry not there
@@ -1789,7 +1805,15 @@ static int decide_pushed(sanafe_hip_chip *c, long long t)
             if (waited < std::chrono::milliseconds(50)) continue;
             const bool idle = hipStreamQuery(c->stream) == hipSuccess;
             if (idle && __atomic_load_n(&e[1], __ATOMIC_ACQUIRE) == n) continue;
-            if (idle || waited > std::chrono::seconds(20)) return 0;
+            if (idle || waited > std::chrono::seconds(20))
+            {
+                c->dbg_fallbacks++;
+                c->dbg_wait_ms += std::chrono::duration<double, std::milli>(waited).count();
+                if (std::getenv("SANAFE_DEBUG_DECIDE"))
+                    std::fprintf(stderr, "[sanafe_hip] decide: step %lld wants the events of step %lld, ring holds step %lld (idle %d)\n", t, n,
+                            (long long) e[1], (int) idle);
+                return 0;
+            }
         }
     }
 }
@@ -1850,7 +1874,19 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
         }
         return 0;
     }
-    if (c->cur_pushed) return 0; // the neuron launch delivered the step's spikes itself
+    if (c->cur_pushed)
+    {
+        // the neuron launch delivered this chip's own spikes itself; on a tile-sharded chip the other ranks' spikes are in the
+        // gathered bitmap by now (this call follows the exchange) and are pushed here, through the same tables
+        if (c->im.n_global_slots != c->im.n_slots && first + count == c->im.n_slices)
+        {
+            const size_t nslot = (size_t) ((c->t_host + 2) % c->im.ring_slots); // the NEXT step's row, as in launch_neurons
+            hipLaunchKernelGGL(remote_push_kernel, dim3((c->im.n_global_slots / 32u + WAVE - 1) / WAVE), dim3(WAVE), 0, c->stream, c->im, c->st,
+                    c->st.ring + nslot * c->im.n_slots, c->st.ring_valid + nslot * c->im.n_slots, (int) (c->t_host % 3));
+            HIPCHK(hipGetLastError());
+        }
+        return 0;
+    }
     if (c->syn_format == 8)
     {
         // ordered delivery: one launch for the whole chip -- every wavefront folds an accumulator group, then walks

@@ -164,14 +164,15 @@ struct DevImage
     // neuron launch (StepArgs::pushed) and to level 1 of the step's reduction (PendStep::pushed).
     // Only built for chips where the result cannot depend on the order of the additions and the per-core message costs are
     // integers times a constant: integer weights, no synaptic delays / last-event cores / taps / host units, one latency
-    // class per core, one GPU, ring_slots >= 2.  push_cap == 0: not built.
+    // class per core, ring_slots >= 2.  On a tile-sharded chip the neuron launch pushes the rank's own spikes and
+    // remote_push_kernel, after the all-gather, those of the other ranks.  push_cap == 0: not built.
     uint32_t push_cap;            // 0: not built; else the number of 64-slot neuron chunks
     uint32_t push_always;         // 1: every step is pushed and the chip has NO delivery launch (chips with so few synapses per
                                   // neuron that even a step in which every neuron fires costs about what one probe of all
                                   // inbound axons costs: C4 has one synapse per neuron)
     uint32_t push_max_events;     // a step is pushed when the step DECISION_LAG before it caused at most this many synaptic
                                   // events (the prediction only picks the faster path: both paths are exact for any activity)
-    const uint32_t *push_ptr;     // [n_slots + 1] out-synapses of each neuron
+    const uint32_t *push_ptr;     // [n_global_slots + 1] out-synapses INTO THIS CHIP of each neuron, by global slot
     const struct PushEntry *push_syn; // post slot, destination core | first-synapse-of-its-axon flag, weight
     const double *core_ain_lat;   // [n_cores] axon-in latency per message
     const double *core_event_lat; // [n_cores] latency per synaptic event (one latency class per core)
@@ -388,6 +389,78 @@ struct UniformSoma
     uint32_t bias_uniform; // every live slot carries the bias `bias`: the per-slot array is not read (C4: no biases at all)
     double bias;
 };
+
+// Push delivery of the spikes of up to 64 source neurons (one per lane: fired_mask; lanes of fired neurons hold the bounds
+// of their out-synapse lists in push_b / push_e): neuron by neuron, the lanes over its out-synapses (integer-valued weights:
+// exact in any order), into the NEXT step's row of the time-step buffer.  The per-core message / event counters are bumped
+// once per RUN of lanes with the same destination core (a neuron's synapses lie core by core), not once per synapse:
+// thousands of same-address atomics would serialise at ~2.5 ns each.  Used by the neuron launch for its own chunk and, on
+// tile-sharded chips, by remote_push_kernel for the neurons of the other ranks.
+__device__ __forceinline__ void push_walk(const DevImage &im, uint32_t *cnt, double *ring_next, uint8_t *rvalid_next, unsigned long long fired_mask,
+        uint32_t push_b, uint32_t push_e, uint32_t lane)
+{
+    for (unsigned long long m = fired_mask; m != 0ull; m &= m - 1ull)
+    {
+        const int j = __ffsll((long long) m) - 1;
+        const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) push_b, j), ei = (uint32_t) __builtin_amdgcn_readlane((int) push_e, j);
+        for (uint32_t k0 = bi; k0 < ei; k0 += WAVE) // (wave-uniform bounds)
+        {
+            const uint32_t k = k0 + lane;
+            const bool act = k < ei; // lanes 0 .. n - 1
+            uint32_t pc = 0xffffffffu;
+            bool first = false;
+            if (act)
+            {
+                const PushEntry pe = im.push_syn[k];
+                atomicAdd(&ring_next[pe.post], pe.w);
+                rvalid_next[pe.post] = 1;
+                pc = pe.core & 0x7fffffffu;
+                first = (pe.core >> 31) != 0u;
+            }
+            const uint32_t before = (uint32_t) __shfl_up((int) pc, 1, WAVE);
+            const bool head = act && (lane == 0u || before != pc);
+            const unsigned long long heads = __ballot(head), firsts = __ballot(first);
+            if (head)
+            {
+                const unsigned long long later = heads & ~((2ull << lane) - 1ull); // (lane 63: the shift wraps to 0 - 1: no later head)
+                const uint32_t n_act = min(ei - k0, (uint32_t) WAVE);
+                const uint32_t end = (lane < 63u && later != 0ull) ? (uint32_t) __ffsll((long long) later) - 1u : n_act;
+                const unsigned long long run = (end >= 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+                atomicAdd(&cnt[pc * 2u + 1u], end - lane);
+                const uint32_t n_msgs = (uint32_t) __popcll(firsts & run);
+                if (n_msgs != 0u) atomicAdd(&cnt[pc * 2u], n_msgs);
+            }
+        }
+    }
+}
+
+// Tile-sharded chips with push tables: the spikes of the OTHER ranks' neurons, pushed by the receiving rank after the
+// all-gather of the spike bitmap (the neuron launch has pushed this rank's own).  grid = ceil(n_global_slots / 2048), block =
+// 64: a wavefront scans 64 words of the global bitmap (2,048 source slots; the local window reads as silent) and walks the
+// out-synapse lists -- into THIS rank's neurons -- of the neurons that fired.  Nothing else touches the bitmap: a step with
+// few spikes costs the scan (n_global_slots / 8 bytes) however many ranks the chip is cut into.
+__global__ void __launch_bounds__(WAVE) remote_push_kernel(DevImage im, DevState st, double *ring_next, uint8_t *rvalid_next, int push_buf)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t wi = blockIdx.x * WAVE + lane; // word of the global bitmap
+    const uint32_t local0 = im.slot_offset / 32u, local1 = (im.slot_offset + im.n_slots) / 32u;
+    uint32_t w = 0;
+    if (wi < im.n_global_slots / 32u && !(wi >= local0 && wi < local1)) w = st.bits_global[wi];
+    uint32_t *cnt = st.push_core_cnt + (size_t) push_buf * im.n_cores * 2u;
+    for (unsigned long long words = __ballot(w != 0u); words != 0ull; words &= words - 1ull) // (wave-uniform)
+    {
+        const int l = __ffsll((long long) words) - 1;
+        const uint32_t ww = (uint32_t) __builtin_amdgcn_readlane((int) w, l);
+        const uint32_t slot = (blockIdx.x * WAVE + (uint32_t) l) * 32u + lane; // lanes 0 .. 31: the word's source slots
+        uint32_t pb = 0, pe = 0;
+        if (lane < 32u && ((ww >> lane) & 1u))
+        {
+            pb = im.push_ptr[slot];
+            pe = im.push_ptr[slot + 1u];
+        }
+        push_walk(im, cnt, ring_next, rvalid_next, (unsigned long long) ww, pb, pe, lane);
+    }
+}
 
 // ---------------------------------------------------------------------------------------
 // K1: neuron update.  grid = n_reduce_wgs + n_wgs, block = 256.
@@ -717,8 +790,8 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         const bool pushing = push_now && fired_mask != 0ull; // wave-uniform
         if (pushing && status == 3)
         {
-            push_b = im.push_ptr[c0 + lane];
-            push_e = im.push_ptr[c0 + lane + 1];
+            push_b = im.push_ptr[im.slot_offset + c0 + lane]; // (indexed by GLOBAL source slot: tile-sharded chips push too)
+            push_e = im.push_ptr[im.slot_offset + c0 + lane + 1];
         }
         if (lane == 0)
         {
@@ -790,46 +863,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
             }
         }
-        if (pushing)
-        {
-            // neuron by neuron, the lanes over its out-synapses (integer-valued weights: exact in any order).  The per-core
-            // message / event counters are bumped once per RUN of lanes with the same destination core (a neuron's synapses
-            // lie core by core), not once per synapse: thousands of same-address atomics would serialise at ~2.5 ns each.
-            uint32_t *cnt = st.push_core_cnt + (size_t) sa.push_buf * im.n_cores * 2u;
-            for (unsigned long long m = fired_mask; m != 0ull; m &= m - 1ull)
-            {
-                const int j = __ffsll((long long) m) - 1;
-                const uint32_t bi = (uint32_t) __builtin_amdgcn_readlane((int) push_b, j), ei = (uint32_t) __builtin_amdgcn_readlane((int) push_e, j);
-                for (uint32_t k0 = bi; k0 < ei; k0 += WAVE) // (wave-uniform bounds)
-                {
-                    const uint32_t k = k0 + lane;
-                    const bool act = k < ei; // lanes 0 .. n - 1
-                    uint32_t pc = 0xffffffffu;
-                    bool first = false;
-                    if (act)
-                    {
-                        const PushEntry pe = im.push_syn[k];
-                        atomicAdd(&sa.ring_next[pe.post], pe.w);
-                        sa.rvalid_next[pe.post] = 1;
-                        pc = pe.core & 0x7fffffffu;
-                        first = (pe.core >> 31) != 0u;
-                    }
-                    const uint32_t before = (uint32_t) __shfl_up((int) pc, 1, WAVE);
-                    const bool head = act && (lane == 0u || before != pc);
-                    const unsigned long long heads = __ballot(head), firsts = __ballot(first);
-                    if (head)
-                    {
-                        const unsigned long long later = heads & ~((2ull << lane) - 1ull); // (lane 63: the shift wraps to 0 - 1: no later head)
-                        const uint32_t n_act = min(ei - k0, (uint32_t) WAVE);
-                        const uint32_t end = (lane < 63u && later != 0ull) ? (uint32_t) __ffsll((long long) later) - 1u : n_act;
-                        const unsigned long long run = (end >= 64u ? ~0ull : ((1ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
-                        atomicAdd(&cnt[pc * 2u + 1u], end - lane);
-                        const uint32_t n_msgs = (uint32_t) __popcll(firsts & run);
-                        if (n_msgs != 0u) atomicAdd(&cnt[pc * 2u], n_msgs);
-                    }
-                }
-            }
-        }
+        if (pushing) push_walk(im, st.push_core_cnt + (size_t) sa.push_buf * im.n_cores * 2u, sa.ring_next, sa.rvalid_next, fired_mask, push_b, push_e, lane);
     }
     if (lane == 0)
     {

@@ -91,18 +91,30 @@ def test_sharded_chip_needs_an_exchange(S):
         chip.run(3, "simple", state=True)  # potential traces stay single-rank
 
 
-@pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_unequal"])
-def test_two_ranks_match_one(S, which):
+@pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_unequal", "loihi_sparse_push"])
+def test_two_ranks_match_one(S, monkeypatch, which):
     if which == "truenorth":
         arch, net = nets.truenorth_net(S, n_tiles=16)
+    elif which == "loihi_sparse_push":
+        # few spikes: push delivery decided per step on each rank's host; the rank's own spikes are pushed by its neuron
+        # launch, the other rank's by remote_push_kernel after the gather
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.01, seed=43)
+        monkeypatch.setenv("SANAFE_PUSH_MAX_EVENTS", "5000")
     elif which == "loihi_delays":
         arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=96, out_degree=48, delays=True, seed=5)
     else:  # the ranks' slot windows differ in size: 5 tiles -> 3 + 2
         arch, net = nets.random_loihi(S, n_tiles=5, neurons_per_core=70, out_degree=40, seed=6)
-    steps = 25
+    steps = 40 if which == "loihi_sparse_push" else 25
     ref, v_ref, _ = _one_rank(S, arch, net, steps)
     chips, results = _sharded(S, arch, net, steps)
     assert ref["spikes"] > 0 and ref["neurons_fired"] > 0
+    if which in ("truenorth", "loihi_sparse_push"):
+        # sharded chips push as well: TrueNorth's one edge per neuron -> push-only (no delivery launch at all, one small
+        # launch per step for the other ranks' spikes); the sparse Loihi network decides per step
+        for c in chips:
+            lay = c.device_layout()
+            assert lay["push_enabled"] and lay["push_only"] == (which == "truenorth"), lay
+            assert lay["pushed_steps"] == steps if which == "truenorth" else lay["pushed_steps"] >= 12, lay
     for r in range(2):
         _assert_same(results[r][0], ref)  # every rank reports the totals of the whole chip
     # potentials: each rank holds its own neurons (others read 0)
