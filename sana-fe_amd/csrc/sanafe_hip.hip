@@ -395,6 +395,8 @@ int build_push(sanafe_hip_chip *c, const sanafe_hip_image &h)
         if ((h.slot_cls[g] & 7u) == SANAFE_SOMA_HOST) return 0; // their spikes are set after the neuron launch
     for (uint64_t k = 0; k < h.n_synapses; k++)
         if ((h.syn_meta[k] >> 19) & 1u) return 0; // lost charge still counts as an event: keep such chips on the pull path
+    for (uint64_t a = 0; a < h.n_axons; a++)
+        if (h.ax_nsyn[a] == 0u) return 0; // an axon without synapses is still a message (axon-in latency): it would have no entry here
     // one latency class per core
     std::vector<double> ev_lat(h.n_cores, 0.0);
     std::vector<int> cls(h.n_cores, -1);
@@ -2569,6 +2571,9 @@ extern "C" int sanafe_hip_write_host_core_costs(sanafe_hip_chip *c, uint32_t cou
     HIPCHK(hipSetDevice(c->device));
     for (uint32_t i = 0; i < count; i++)
         if (costs[i].core >= c->im.n_cores) return fail(SANAFE_HIP_ERR_INVALID, "bad host core entry %u", i);
+    if (c->timing)
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "per-kernel timing (sanafe_hip_set_timing) closes every step's reduction at once: switch it off on "
+                                                "chips with cores that run on the host");
     if (c->pend1.valid == 0) return fail(SANAFE_HIP_ERR_INVALID, "the step's reduction has already run: write the host cores' costs right after its delivery");
     if (c->st.host_proc == nullptr) TRY(dalloc(c, 2 * (size_t) c->im.n_cores, &c->st.host_proc));
     if (count > c->host_cost_cap)
@@ -2658,6 +2663,10 @@ extern "C" int sanafe_hip_reset(sanafe_hip_chip *c)
 extern "C" int sanafe_hip_set_timing(sanafe_hip_chip *c, int enabled)
 {
     if (!c) return fail(SANAFE_HIP_ERR_INVALID, "null chip");
+    // timed steps close every step's reduction at once; cores that run on the host write their costs after the delivery
+    // launch (sanafe_hip_write_host_core_costs) and would find it closed
+    if (enabled && c->st.host_proc != nullptr)
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "per-kernel timing is not available on chips with cores that run on the host");
     c->timing = enabled != 0;
     c->t_neuron = c->t_deliver = c->t_reduce = 0.0;
     c->t_launches = 0;

@@ -1028,7 +1028,21 @@ extern "C" int sanafe_chip_carry_state(sanafe_chip *to, sanafe_chip *from)
         brf[s1] = arf[s0];
         bst[s1] = ast[s0];
         barr[s1] = aarr[s0];
-        blast[s1] = alast[s0]; // (positions among the core's synapses: only valid while the core's inbound synapses keep their order)
+        if (alast[s0] != 0u)
+        {
+            // a pending last-event entry is 1 + the event's position among the core's inbound synapses: only meaningful while
+            // that list is what it was.  A network that adds inbound synapses to such a core shifts the positions.
+            const uint32_t ca = a.core_of_slot[s0], cb = b.core_of_slot[s1];
+            auto core_synapses = [](const MappedChip &m, uint32_t core) {
+                const uint32_t k = core - m.first_core;
+                const uint64_t end = (k + 1 < m.core_syn_base.size()) ? m.core_syn_base[k + 1] : m.syn_meta.size();
+                return end - m.core_syn_base[k];
+            };
+            if (core_synapses(a, ca) != core_synapses(b, cb))
+                return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: load(net, overwrite=False) adds inbound synapses to a core whose time-step "
+                                                        "buffer (before the dendrite unit) still holds an event: its position cannot be carried");
+        }
+        blast[s1] = alast[s0];
         // what the time-step buffer / delay line holds for the steps to come: step t + 1 + k sits in row (t + 1 + k) % R
         for (uint32_t k = 0; k < ra; k++)
         {
