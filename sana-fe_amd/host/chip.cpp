@@ -341,6 +341,11 @@ struct sanafe_chip
     std::vector<std::vector<double>> rec_optional; // per recorded step: the optional perf-trace columns (mc.log)
     // state log (potential / neuron traces): neurons whose potential / input current every recorded step keeps
     std::vector<int64_t> log_v_gids, log_u_gids;
+    // tile-sharded chips: every rank logs the neurons it holds; per requested neuron (v list, then u list) the rank that
+    // holds it and its column in that rank's rows -- the ranks' rows of a chunk are gathered and laid out in request order
+    std::vector<int32_t> log_owner;
+    std::vector<uint32_t> log_column;
+    std::vector<uint32_t> log_rank_columns; // [n_ranks] columns (v + u) each rank logs
     std::vector<double> rec_state; // [recorded steps][log_v_gids + log_u_gids]
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
@@ -1224,7 +1229,7 @@ struct ShardedRun
 
 // sim() of one rank of a tile-sharded chip under the simple timing model: whole chunks stay on the device.  Counters
 // and energies of the ranks are added in rank order.
-static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &run, int record)
+static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &run, int record, bool want_state)
 {
     ShardedRun sr(chip);
     if (int rc = sr.begin(timesteps)) return rc;
@@ -1250,8 +1255,31 @@ static int sim_sharded(sanafe_chip *chip, int64_t timesteps, sanafe_hip_totals &
     {
         m = std::min(std::min(cap, rec_cap), timesteps - done);
         if (n_ext != 0) m = std::min<int64_t>(m, std::max<int64_t>(1, (int64_t{16} << 20) / static_cast<int64_t>(n_ext)));
-        if (int rc = sr.chunk(m, 1, record ? 1 : 0)) return rc;
+        if (int rc = sr.chunk(m, 1, (record ? 1 : 0) | ((want_state && chip->log_rank_columns[chip->rank] > 0) ? 8 : 0))) return rc; // (bit 3: only ranks that hold a logged neuron)
         for (int64_t s = 0; s < m; s++) sim_time += maxima[s] + mc.sync_delay;
+        if (want_state)
+        {
+            // potential / neuron traces (src/chip.cpp:1766-1831): every rank sampled the neurons it holds on the device, one row
+            // per step; the ranks' rows of this chunk are gathered once and laid out in the order the neurons were given
+            const size_t mine = chip->log_rank_columns[chip->rank];
+            size_t widest_row = 0;
+            for (uint32_t w : chip->log_rank_columns) widest_row = std::max<size_t>(widest_row, w);
+            std::vector<double> local(static_cast<size_t>(m) * std::max<size_t>(mine, 1), 0.0);
+            if (mine > 0) DEV(sanafe_hip_read_step_state(chip->dev, 0, m, local.data()));
+            std::vector<double> send(static_cast<size_t>(m) * widest_row, 0.0);
+            for (int64_t s = 0; s < m; s++)
+                std::copy(local.begin() + static_cast<size_t>(s) * mine, local.begin() + static_cast<size_t>(s + 1) * mine, send.begin() + static_cast<size_t>(s) * widest_row);
+            std::vector<unsigned char> recv;
+            if (xc.gather_bytes(send.data(), send.size() * sizeof(double), recv)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
+            const size_t row = chip->log_owner.size();
+            const size_t base = chip->rec_state.size();
+            chip->rec_state.resize(base + static_cast<size_t>(m) * row);
+            const double *all = reinterpret_cast<const double *>(recv.data());
+            for (int64_t s = 0; s < m; s++)
+                for (size_t j = 0; j < row; j++)
+                    chip->rec_state[base + static_cast<size_t>(s) * row + j] =
+                            all[static_cast<size_t>(chip->log_owner[j]) * send.size() + static_cast<size_t>(s) * widest_row + chip->log_column[j]];
+        }
         if (record)
         {
             rec_local.resize(m);
@@ -1360,8 +1388,6 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
     const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
-    if (want_state && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
-        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces are not available on a tile-sharded chip");
     if (want_state && chip->log_v_gids.empty() && chip->log_u_gids.empty())
         return fail(SANAFE_HIP_ERR_INVALID, "SANAFE_RECORD_STATE needs the neurons to log (sanafe_chip_set_state_log)");
     record = (record & (SANAFE_RECORD_STEPS | SANAFE_RECORD_MESSAGES | SANAFE_RECORD_STATE)) ? 1 : 0;
@@ -1370,9 +1396,12 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
     if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
     {
-        if (want_state || host_units || (record && chip->mc.log.any))
-            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces, optional perf columns and plugin units "
-                                                    "are not available on a tile-sharded chip");
+        if (host_units || (record && chip->mc.log.any))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: optional perf columns and plugin units are not available on a "
+                                                    "tile-sharded chip");
+        if (want_state && (timing_model != SANAFE_TIMING_SIMPLE || want_messages))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces of a tile-sharded chip need the simple timing "
+                                                    "model without a message trace");
         if ((timing_model != SANAFE_TIMING_SIMPLE || want_messages) && chip->whole == nullptr)
             return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces on a tile-sharded chip need the whole "
                                                     "chip's tables on the host: call sanafe_chip_attach_whole with the complete description first");
@@ -1380,7 +1409,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     const bool sharded = chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None;
     if (sharded && timing_model == SANAFE_TIMING_SIMPLE && !want_messages)
     {
-        if (int rc = sim_sharded(chip, timesteps, run, record)) return rc;
+        if (int rc = sim_sharded(chip, timesteps, run, record, want_state)) return rc;
     }
     else if (!sharded && timing_model == SANAFE_TIMING_SIMPLE && !host_units && !want_messages && !(record && chip->mc.log.any))
     {
@@ -1916,18 +1945,37 @@ extern "C" int sanafe_chip_set_state_log(sanafe_chip *chip, int64_t n_v, const i
     if (!chip->dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "the chip has no device (mapped only)");
     const MappedChip &mc = chip->mc;
     std::vector<uint32_t> sv, su;
-    auto to_slots = [&](const int64_t *g, int64_t n, std::vector<uint32_t> &out) {
+    // a tile-sharded chip logs the neurons THIS rank holds (all ranks are given the same lists); sim() gathers the rows
+    const int n_ranks = std::max(1, chip->n_ranks);
+    std::vector<uint32_t> n_v_rank(n_ranks, 0), n_u_rank(n_ranks, 0);
+    std::vector<int32_t> owner;
+    std::vector<uint32_t> column;
+    auto owner_of = [&](uint32_t slot) {
+        int r = 0;
+        while (r + 1 < n_ranks && !mc.rank_slot_begin.empty() && slot >= mc.rank_slot_begin[r + 1]) r++;
+        return r;
+    };
+    auto to_slots = [&](const int64_t *g, int64_t n, std::vector<uint32_t> &out, std::vector<uint32_t> &per_rank) {
         for (int64_t i = 0; i < n; i++)
         {
             if (g[i] < 0 || g[i] >= chip->n_neurons) return false;
             const uint32_t s = mc.slot_of_gid[g[i]];
-            if (s < mc.slot_offset || s >= mc.slot_offset + mc.n_slots) return false; // another rank's neuron
-            out.push_back(s - mc.slot_offset);
+            const int r = n_ranks > 1 ? owner_of(s) : 0;
+            owner.push_back(r);
+            column.push_back(per_rank[r]++);
+            if (s >= mc.slot_offset && s < mc.slot_offset + mc.n_slots) out.push_back(s - mc.slot_offset);
+            else if (n_ranks == 1) return false;
         }
         return true;
     };
-    if (!to_slots(neurons_v, n_v, sv) || !to_slots(neurons_u, n_u, su))
-        return fail(SANAFE_HIP_ERR_INVALID, "logged neuron id out of range (or held by another rank)");
+    if (!to_slots(neurons_v, n_v, sv, n_v_rank) || !to_slots(neurons_u, n_u, su, n_u_rank))
+        return fail(SANAFE_HIP_ERR_INVALID, "logged neuron id out of range");
+    // a rank's row: its potentials, then its currents -- the u columns follow the rank's v columns
+    for (int64_t i = 0; i < n_u; i++) column[static_cast<size_t>(n_v + i)] += n_v_rank[owner[static_cast<size_t>(n_v + i)]];
+    chip->log_owner = owner;
+    chip->log_column = column;
+    chip->log_rank_columns.assign(n_ranks, 0);
+    for (int r = 0; r < n_ranks; r++) chip->log_rank_columns[r] = n_v_rank[r] + n_u_rank[r];
     DEV(sanafe_hip_set_state_log(chip->dev, static_cast<uint32_t>(sv.size()), sv.data(), static_cast<uint32_t>(su.size()), su.data()));
     chip->log_v_gids.assign(neurons_v, neurons_v + n_v);
     chip->log_u_gids.assign(neurons_u, neurons_u + n_u);

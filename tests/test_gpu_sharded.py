@@ -86,9 +86,6 @@ def test_sharded_chip_needs_an_exchange(S):
     chip.load(net)
     with pytest.raises(RuntimeError, match="exchange"):
         chip.run(3, "simple")
-    chip.comm_init_callback(lambda send: np.stack([send, send]))
-    with pytest.raises(NotImplementedError):
-        chip.run(3, "simple", state=True)  # potential traces stay single-rank
 
 
 @pytest.mark.parametrize("which", ["truenorth", "loihi_delays", "loihi_unequal", "loihi_sparse_push"])
@@ -147,7 +144,29 @@ def _sharded_calls(S, arch, net, call, n_ranks=2):
     for t in threads:
         t.join()
     assert not errors, errors
+    chips[0]._test_gather = tg
     return chips, results
+
+
+def _sharded_rerun(chips, call, tg=None):
+    """Runs `call(chip)` concurrently on chips that already have their exchange."""
+    results, errors = [None] * len(chips), []
+
+    def work(r):
+        try:
+            results[r] = call(chips[r])
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+            if tg is not None:
+                tg.barrier.abort()  # the other rank must not wait for this one for ever
+
+    threads = [threading.Thread(target=work, args=(r,)) for r in range(len(chips))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    return results
 
 
 def test_sharded_recorded_run_gathers_spike_and_perf_traces(S):
@@ -285,3 +304,47 @@ def test_c4_full_size_properties(S):
     assert np.array_equal(v, v2)
     for k in recs.dtype.names:
         assert np.array_equal(recs[k], recs2[k]), k
+
+
+@pytest.mark.timeout(180)
+def test_sharded_potential_traces(S):
+    """Potential / neuron traces on a tile-sharded chip (src/pymodule.cpp:549-706 has no such limit):
+    every rank samples the logged neurons IT holds on the device, the ranks' rows of a chunk of steps are gathered like the
+    spike rows, and every rank ends up with the rows of all logged neurons in the order they were given -- equal to the
+    one-rank run's.  Neurons of both ranks in one list, potentials and LIF input currents, unequal windows (3 + 2 tiles)."""
+    arch, net = nets.random_loihi(S, n_tiles=5, neurons_per_core=70, out_degree=40, seed=6)
+    steps = 20
+    n = 5 * 4 * 70
+    rng = np.random.default_rng(3)
+    pv = rng.choice(n, size=37, replace=False)  # unsorted: the order given is the order of the columns
+    pu = rng.choice(n, size=11, replace=False)
+    one = S.SpikingChip(arch)
+    one.load(net)
+    one.set_state_log(pv, pu)
+    ref_tot = one.run(steps, "simple", state=True)
+    ref = one.step_state(0, steps)
+    assert ref.shape == (steps, 48) and np.abs(ref).sum() > 0
+
+    def call(chip):
+        chip.set_state_log(pv, pu)
+        tot = chip.run(steps, "simple", state=True)
+        return tot, chip.step_state(0, steps), np.stack([chip.step_fired(t) for t in range(steps)])
+
+    chips, results = _sharded_calls(S, arch, net, call)
+    for tot, rows, fired in results:
+        assert np.array_equal(rows, ref)  # every rank holds the rows of all logged neurons
+        _assert_same(tot, ref_tot)
+    assert np.array_equal(results[0][2], np.stack([one.step_fired(t) for t in range(steps)]))
+    # a second call on the same chips continues, and a list that lies on ONE rank only works too (the other logs nothing)
+    only0 = np.arange(5, 25)
+
+    def call2(chip):
+        chip.set_state_log(only0)
+        chip.run(7, "simple", state=True)
+        return chip.step_state(0, 7)
+
+    one.set_state_log(only0)
+    one.run(7, "simple", state=True)
+    ref2 = one.step_state(0, 7)
+    for chip, r in zip(chips, _sharded_rerun(chips, call2, chips[0]._test_gather)):
+        assert np.array_equal(r, ref2)
