@@ -10,7 +10,7 @@ import shutil
 import sys
 
 out = sys.argv[1]
-KERNELS = ("deliver_kernel", "neuron_kernel", "reduce_kernel")
+KERNELS = ("event_deliver_kernel", "deliver_kernel", "neuron_kernel", "reduce_kernel", "remote_push_kernel")  # (first match wins)
 
 
 def short(name):
