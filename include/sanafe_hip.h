@@ -57,7 +57,12 @@ typedef enum sanafe_hip_status
 
 /* soma models (src/models.cpp:933-967) */
 enum { SANAFE_SOMA_NONE = 0, SANAFE_SOMA_LIF = 1, SANAFE_SOMA_TRUENORTH = 2,
-       SANAFE_SOMA_INPUT = 3, SANAFE_SOMA_HOST = 4 };
+       SANAFE_SOMA_INPUT = 3, SANAFE_SOMA_HOST = 4,
+       SANAFE_SOMA_PERSIST = 5 /* a neuron of a core whose time-step buffer sits before axon_out (`buffer_position:
+                                  axon_out`): its neuron pipeline holds NO unit (src/mapped.cpp:168-188) -- nothing is updated or
+                                  costed in the neuron loop, the status the message pipeline's soma calls left persists and is
+                                  what axon_out acts on (a `fired` neuron sends its spike messages); the soma parameters of its
+                                  class are TrueNorth's, used by the per-event updates (msg_* below) */ };
 /* how a neuron's synaptic input reaches its soma */
 enum {
     SANAFE_IN_BUFFERED = 0,   /* accumulator + kernel time-step buffer, or delay line: read slot t % ring_slots */
@@ -74,6 +79,9 @@ enum {
                                  every step (the line shifts, the matured charge reaches the soma) and integrates only the LAST
                                  synaptic event's current, without a synapse address -- so with the delay of the unit's synapse
                                  address 0 (src/models.cpp:96-131, src/pipeline.hpp:460-508); slot_aux = that delay */
+    SANAFE_IN_NONE = 6,       /* the soma is called from the neuron loop WITHOUT an input (`buffer_position: soma`, inside the
+                                 unit: the neuron pipeline is the soma alone, src/mapped.cpp:168-188); its synaptic input
+                                 reaches it per event in the message pipeline (msg_* below) */
     SANAFE_IN_LAST = 2        /* buffer before the dendrite unit (`buffer_position: dendrite`, outside): the kernel's
                                  time-step buffer keeps only the LAST synaptic event's current (src/chip.cpp:759), which the
                                  accumulator then integrates alone; always "has input" (the lazy clear leaves 0.0) */
@@ -184,7 +192,35 @@ typedef struct sanafe_hip_image
     /* ---- per synapse [n_synapses] ---- */
     const uint32_t *syn_meta;     /* post-neuron offset in core (16b) | delay (3b) << 16 | drop (1b) << 19 */
     const double *syn_weight;
+
+    /* ---- cores whose SOMA is part of the message pipeline (buffer inside the soma unit or before axon_out:
+     *      src/pipeline.cpp:268-310, src/mapped.cpp:27-58) with built-in units -- `current_based` synapse, `accumulator`
+     *      dendrite, `truenorth` soma: every synaptic event runs synapse -> dendrite (running sum of the step's currents,
+     *      src/models.cpp:71-94) -> soma update, in delivery order (src/chip.cpp:738-789).  Their inbound axons are NOT in
+     *      the arrays above (their places in syn_meta are holes with the drop bit); they are listed here per core, in
+     *      delivery order, and the device walks them per post-synaptic neuron after the step's delivery.  n_msg_cores = 0:
+     *      none.  Cores of this kind with plugin units, other models or `taps` run on the host instead (sanafe_host.h). ---- */
+    uint32_t n_msg_cores;
+    const uint32_t *msg_core;      /* [n_msg_cores] local core */
+    const uint32_t *msg_ax_beg;    /* [n_msg_cores + 1] the core's axons in msg_ax_* */
+    const uint32_t *msg_ax_pre;    /* GLOBAL slot of the axon's source neuron */
+    const uint32_t *msg_ax_nsyn;   /* synapses of the axon; they follow each other in msg_syn_* in axon order */
+    const uint32_t *msg_syn_beg;   /* [n_msg_cores + 1] the core's synapses in msg_syn_* */
+    const uint32_t *msg_syn_post;  /* post-synaptic neuron, offset within the core */
+    const double *msg_syn_weight;
+    const struct sanafe_hip_msg_core_costs *msg_costs; /* [n_msg_cores] */
 } sanafe_hip_image;
+
+/* Default costs of the units a message passes on such a core (src/pipeline.hpp:511-731): per message the axon-in latency,
+ * per synaptic event the synapse's and the dendrite's costs and the soma's by the status its update returned
+ * (access + update always -- an update with an input current is never idle --, spike_out when it fired). */
+typedef struct sanafe_hip_msg_core_costs
+{
+    double axon_in_latency;
+    double synapse_energy, synapse_latency;   /* energy_process_spike, latency_process_spike */
+    double dendrite_energy, dendrite_latency; /* energy_update, latency_update */
+    double soma_energy[3], soma_latency[3];   /* access_neuron, update_neuron, spike_out */
+} sanafe_hip_msg_core_costs;
 
 /* Totals of one timestep / of a run: `Timestep` (src/timestep.hpp:21-46),
  * `RunData` (src/chip.hpp:215-233). */
@@ -263,6 +299,8 @@ int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t 
  *   [6] accumulator shift   [7] 1: every step goes by events (SANAFE_EVENT=2)   [8] event threshold of the decision
  * SANAFE_EVENT=0 off / 1 build whatever the block length / 2 build and always use; SANAFE_EVENT_SEGMENTS,
  * SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_LPB (4 | 8), SANAFE_EVENT_MAX_EVENTS. */
+/* Cores whose soma is part of the message pipeline and that run on the device (sanafe_hip_image::msg_*): their number. */
+int sanafe_hip_get_msg_cores(sanafe_hip_chip *chip);
 #define SANAFE_HIP_EVENT_INFO_FIELDS 9
 int sanafe_hip_get_event_info(sanafe_hip_chip *chip, uint64_t *info, int n);
 

@@ -413,10 +413,14 @@ class SpikingChip(_Base):
                  "lanes_per_block": int(ev[4]), "code_bits": int(ev[5]), "shift": int(ev[6]), "always": bool(ev[7]),
                  "max_events": int(ev[8])} if ev[0] else None
         return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle())),
-                "event_layout": event,
+                "event_layout": event, "msg_cores_on_device": int(self._msg_cores(H)),
                 "push_enabled": bool(en.value), "push_only": en.value == 2, "pushed_steps": int(pushed.value),
                 "n_bitmap_slices": int(H.sanafe_hip_get_bitmap_slices(self.device_handle())),
                 "sub_accumulators": bool(H.sanafe_hip_get_sub_accumulators(self.device_handle()))}
+
+    def _msg_cores(self, H):
+        H.sanafe_hip_get_msg_cores.argtypes = [C.c_void_p]
+        return H.sanafe_hip_get_msg_cores(self.device_handle())
 
     def step_neurons(self):
         self._check(self._L.sanafe_chip_step_neurons(self._h))
@@ -485,6 +489,9 @@ class HipImage(C.Structure):
         ("ax_pre", _p(C.c_uint32)), ("ax_syn_beg", _p(C.c_uint32)), ("ax_nsyn", _p(C.c_uint32)),
         ("ax_proc_delay", _p(C.c_double)), ("ax_lat_class", _p(C.c_uint8)), ("lat_class_per_event", _p(C.c_double)),
         ("syn_meta", _p(C.c_uint32)), ("syn_weight", _p(C.c_double)),
+        ("n_msg_cores", C.c_uint32), ("msg_core", _p(C.c_uint32)), ("msg_ax_beg", _p(C.c_uint32)), ("msg_ax_pre", _p(C.c_uint32)),
+        ("msg_ax_nsyn", _p(C.c_uint32)), ("msg_syn_beg", _p(C.c_uint32)), ("msg_syn_post", _p(C.c_uint32)),
+        ("msg_syn_weight", _p(C.c_double)), ("msg_costs", C.c_void_p),
     ]
 
 
@@ -520,6 +527,11 @@ def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
             counts[n] = im.n_slots
         counts["slot_ext"] = im.n_slots if im.n_ext else 0
         counts.update(tap_slot=im.n_taps, tap_count=im.n_taps, tap_tc=im.n_taps * 8, tap_sc=im.n_taps * 8)
+        n_msg_ax = int(im.msg_ax_beg[im.n_msg_cores]) if im.n_msg_cores else 0
+        n_msg_syn = int(im.msg_syn_beg[im.n_msg_cores]) if im.n_msg_cores else 0
+        counts.update(msg_core=im.n_msg_cores, msg_ax_beg=im.n_msg_cores + 1 if im.n_msg_cores else 0, msg_ax_pre=n_msg_ax,
+                      msg_ax_nsyn=n_msg_ax, msg_syn_beg=im.n_msg_cores + 1 if im.n_msg_cores else 0, msg_syn_post=n_msg_syn,
+                      msg_syn_weight=n_msg_syn)
         out = {}
         for n, _t in HipImage._fields_:
             v = getattr(im, n)

@@ -121,6 +121,7 @@ struct sanafe_hip_chip
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     const void *event_fn{nullptr};   // event_deliver_kernel instantiation (chips with the event layout, DevImage::ev_*)
     int ev_lpb{4};                   // its lanes per block
+    int ev_upl{1};                   // its 16-byte units per lane and batch
     int ev_waves{16};                // its wavefronts per workgroup
     // push / event decisions (DevImage::push_*): made here, on the host, from the events the device publishes
     long long *h_events{nullptr};    // pinned ring DevState::host_events points at
@@ -128,6 +129,7 @@ struct sanafe_hip_chip
     int cur_pushed{0};               // mode of the step whose neuron launch went out last
     long long pushed_steps{0};       // steps delivered by the push path / the event kernel since create
     long long ev_pending{-1};        // t_host after the step whose input still lies in DevState::ev_part (-1: none)
+    uint32_t *cur_slog{nullptr};     // spike-record row of the step whose neuron launch went out last (msgsoma_kernel patches it)
     long long dbg_waits{0}, dbg_fallbacks{0}; // decide_pushed: decisions that had to wait for the device / gave up (SANAFE_DEBUG_DECIDE)
     double dbg_wait_ms{0.0};
     double ev_avg_block{0.0};        // words per (source neuron, core group) block
@@ -688,8 +690,12 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     c->layout_bytes[9] = total_units * 16ull;
     c->layout_bytes[10] = meta.size() * 8ull;
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
-    c->ev_lpb = c->ev_avg_block > 32.0 ? 8 : 4; // lanes (16-byte units) per block and batch
+    // 8 unit slots per block and batch from ~32 words per block on (4 lanes x 2 units: 16 neurons per batch), else 4
+    c->ev_lpb = 4;
+    c->ev_upl = c->ev_avg_block > 32.0 ? 2 : 1;
     if (const char *env = std::getenv("SANAFE_EVENT_LPB")) c->ev_lpb = std::atoi(env) == 8 ? 8 : 4;
+    if (const char *env = std::getenv("SANAFE_EVENT_UPL")) c->ev_upl = std::atoi(env) == 2 ? 2 : 1;
+    if (c->ev_lpb == 8) c->ev_upl = 1;
     return 0;
 }
 
@@ -780,14 +786,15 @@ int validate(const sanafe_hip_image *im)
     for (uint32_t g = 0; g < im->n_slots; g++)
     {
         const uint32_t cls = im->slot_cls[g], model = cls & 7u;
-        if (model > SANAFE_SOMA_HOST) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma model", g);
+        if (model > SANAFE_SOMA_PERSIST) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma model", g);
         if (model == SANAFE_SOMA_NONE) continue;
         if (((cls >> 6) & 1023u) >= im->n_cost_classes) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad cost class", g);
         if ((model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH) && (cls >> 16) >= im->n_soma_classes)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (model == SANAFE_SOMA_INPUT && im->slot_aux[g] >= im->n_input)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input index", g);
-        if (((cls >> 3) & 7u) > SANAFE_IN_LAST_DELAY) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (((cls >> 3) & 7u) > SANAFE_IN_NONE) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad input kind", g);
+        if (model == SANAFE_SOMA_PERSIST && (cls >> 16) >= im->n_soma_classes) return fail(SANAFE_HIP_ERR_INVALID, "slot %u: bad soma class", g);
         if (((cls >> 3) & 7u) == SANAFE_IN_LAST_DELAY && im->slot_aux[g] + 2u > im->ring_slots)
             return fail(SANAFE_HIP_ERR_INVALID, "slot %u: delay %u needs %u ring slots", g, im->slot_aux[g], im->slot_aux[g] + 2u);
         if (((cls >> 3) & 7u) == SANAFE_IN_TAPS && (im->slot_aux[g] >= im->n_taps || im->tap_count[im->slot_aux[g]] < 1 || im->tap_count[im->slot_aux[g]] > 8))
@@ -805,6 +812,31 @@ int validate(const sanafe_hip_image *im)
     for (uint32_t i = 0; i < im->n_input; i++)
         if ((uint64_t) im->in_train_beg[i] + im->in_train_len[i] > im->n_train_words * 32ull)
             return fail(SANAFE_HIP_ERR_INVALID, "input %u: spike train outside in_train_bits", i);
+    // cores whose soma is part of the message pipeline (msg_*)
+    for (uint32_t k = 0; k < im->n_msg_cores; k++)
+    {
+        if (!im->msg_core || !im->msg_ax_beg || !im->msg_syn_beg || !im->msg_costs) return fail(SANAFE_HIP_ERR_INVALID, "msg_* arrays are NULL");
+        const uint32_t core = im->msg_core[k];
+        if (core >= im->n_cores || (k > 0 && core <= im->msg_core[k - 1])) return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: bad or unsorted core", k);
+        if (im->msg_ax_beg[k] > im->msg_ax_beg[k + 1] || im->msg_syn_beg[k] > im->msg_syn_beg[k + 1])
+            return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: bad table ranges", k);
+        uint64_t syn = im->msg_syn_beg[k];
+        for (uint32_t a = im->msg_ax_beg[k]; a < im->msg_ax_beg[k + 1]; a++)
+        {
+            if (im->msg_ax_pre[a] >= im->n_global_slots) return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: bad pre slot", k);
+            syn += im->msg_ax_nsyn[a];
+        }
+        if (syn != im->msg_syn_beg[k + 1]) return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: the axons' synapse counts do not add up", k);
+        for (uint32_t q = im->msg_syn_beg[k]; q < im->msg_syn_beg[k + 1]; q++)
+            if (im->msg_syn_post[q] >= im->core_ncount[core]) return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: post neuron outside its core", k);
+        for (uint32_t n = 0; n < im->core_ncount[core]; n++)
+        {
+            const uint32_t cl = im->slot_cls[im->core_nbase[core] + n], m = cl & 7u;
+            if (m == SANAFE_SOMA_NONE) continue;
+            if (!((m == SANAFE_SOMA_TRUENORTH && ((cl >> 3) & 7u) == SANAFE_IN_NONE) || m == SANAFE_SOMA_PERSIST))
+                return fail(SANAFE_HIP_ERR_INVALID, "msg core %u: its neurons must be TrueNorth somas with SANAFE_IN_NONE, or SANAFE_SOMA_PERSIST", k);
+        }
+    }
     return 0;
 }
 } // namespace
@@ -985,6 +1017,55 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     im.n_ext = h.n_ext;
     im.slot_ext = nullptr;
     if (h.n_ext > 0) TRYC(upload(c, h.slot_ext, h.n_slots, &im.slot_ext));
+    // ---- cores whose soma is part of the message pipeline: per post-synaptic neuron, its inbound synapses in delivery order ----
+    im.n_msg_cores = h.n_msg_cores;
+    im.n_msg_chunks = 0;
+    c->st.msg_cnt = nullptr;
+    if (h.n_msg_cores > 0)
+    {
+        std::vector<MsgCoreDev> cores(h.n_msg_cores);
+        std::vector<uint32_t> chunk_core, chunk_slot0, ptr((size_t) h.n_slots + 1, 0u);
+        for (uint32_t k = 0; k < h.n_msg_cores; k++)
+        {
+            const uint32_t core = h.msg_core[k];
+            cores[k].core = core;
+            cores[k].first_chunk = (uint32_t) chunk_core.size();
+            cores[k].ax_beg = h.msg_ax_beg[k];
+            cores[k].ax_end = h.msg_ax_beg[k + 1];
+            cores[k].costs = h.msg_costs[k];
+            for (uint32_t q = 0; q < (h.core_ncount[core] + 63u) / 64u; q++)
+            {
+                chunk_core.push_back(k);
+                chunk_slot0.push_back(h.core_nbase[core] + 64u * q);
+            }
+            for (uint32_t q = h.msg_syn_beg[k]; q < h.msg_syn_beg[k + 1]; q++) ptr[h.core_nbase[core] + h.msg_syn_post[q] + 1u]++;
+        }
+        for (uint32_t g = 0; g < h.n_slots; g++) ptr[g + 1] += ptr[g];
+        const uint32_t n_syn = ptr[h.n_slots];
+        std::vector<uint32_t> pre(std::max<uint32_t>(n_syn, 1u), 0u), cur(ptr.begin(), ptr.end() - 1);
+        std::vector<double> w(std::max<uint32_t>(n_syn, 1u), 0.0);
+        for (uint32_t k = 0; k < h.n_msg_cores; k++)
+        {
+            const uint32_t core = h.msg_core[k];
+            uint32_t q = h.msg_syn_beg[k];
+            for (uint32_t a = h.msg_ax_beg[k]; a < h.msg_ax_beg[k + 1]; a++) // axon by axon = delivery order, per neuron as well
+                for (uint32_t j = 0; j < h.msg_ax_nsyn[a]; j++, q++)
+                {
+                    const uint32_t at = cur[h.core_nbase[core] + h.msg_syn_post[q]]++;
+                    pre[at] = h.msg_ax_pre[a];
+                    w[at] = h.msg_syn_weight[q];
+                }
+        }
+        im.n_msg_chunks = (uint32_t) chunk_core.size();
+        TRYC(upload(c, cores.data(), cores.size(), &im.msg_core_dev));
+        TRYC(upload(c, chunk_core.data(), chunk_core.size(), &im.msg_chunk_core));
+        TRYC(upload(c, chunk_slot0.data(), chunk_slot0.size(), &im.msg_chunk_slot0));
+        TRYC(upload(c, ptr.data(), ptr.size(), &im.msg_ptr));
+        TRYC(upload(c, pre.data(), pre.size(), &im.msg_pre));
+        TRYC(upload(c, w.data(), w.size(), &im.msg_w));
+        TRYC(upload(c, h.msg_ax_pre, h.msg_ax_beg[h.n_msg_cores], &im.msg_ax_pre));
+        TRYC(dalloc(c, (size_t) h.n_msg_cores * 4, &c->st.msg_cnt));
+    }
     // ---- synapse format: the narrowest that holds every weight exactly and every accumulator index (see DevImage) ----
     //   streamable: 0 int8 weights, 3 12-bit integer weights, 4 fp64 weights; gather-only fall-backs: 1 (12-bit), 2 (fp64)
     {
@@ -1535,6 +1616,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     st.delay_log = nullptr;
     st.delay_log_cap = 0;
     st.host_proc = nullptr;
+    if (im.n_msg_cores > 0) TRYC(dalloc(c, 2 * (size_t) h.n_cores, &st.host_proc)); // their processing delays (msgsoma_finish_kernel)
     TRYC(dalloc(c, 1, &st.t));
     TRYC(dalloc(c, 1, &st.rec));
     TRYC(dalloc(c, 1, &st.run));
@@ -1650,9 +1732,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->deliver_block = (uint32_t) v->block;
         if (im.ev_groups != 0u)
         {
-#define SANAFE_EV(L, B, W) if (c->ev_lpb == L && im.ev_code_bits == B && c->ev_waves == W) c->event_fn = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W>)
-            SANAFE_EV(4, 4, 4); SANAFE_EV(4, 4, 8); SANAFE_EV(4, 4, 16); SANAFE_EV(8, 4, 4); SANAFE_EV(8, 4, 8); SANAFE_EV(8, 4, 16);
-            SANAFE_EV(4, 5, 4); SANAFE_EV(4, 5, 8); SANAFE_EV(4, 5, 16); SANAFE_EV(8, 5, 4); SANAFE_EV(8, 5, 8); SANAFE_EV(8, 5, 16);
+#define SANAFE_EV(L, B, W, U) if (c->ev_lpb == L && im.ev_code_bits == B && c->ev_waves == W && c->ev_upl == U) c->event_fn = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W, U>)
+#define SANAFE_EVW(L, B, U) SANAFE_EV(L, B, 4, U); SANAFE_EV(L, B, 8, U); SANAFE_EV(L, B, 16, U)
+            SANAFE_EVW(4, 4, 1); SANAFE_EVW(8, 4, 1); SANAFE_EVW(4, 4, 2); SANAFE_EVW(4, 5, 1); SANAFE_EVW(8, 5, 1); SANAFE_EVW(4, 5, 2);
+#undef SANAFE_EVW
 #undef SANAFE_EV
         }
     }
@@ -1844,6 +1927,7 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     sa.rvalid_next = c->st.ring_valid + nslot * c->im.n_slots;
     sa.ev_part = (c->im.ev_groups != 0u && c->ev_pending == c->t_host) ? c->st.ev_part : nullptr; // the previous step went by events
     if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
+    c->cur_slog = sa.slog;
     if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
     const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
 #define SANAFE_LAUNCH_NEURON(M, U) \
@@ -1859,8 +1943,21 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     c->pend1.valid = 0;
     return 0;
 }
-// Delivers the slices [first, first + count) of the launch order.
+static int launch_deliver_slices(sanafe_hip_chip *c, uint32_t first, uint32_t count);
+// Delivers the slices [first, first + count) of the launch order; with the last of them, the cores whose soma is part of the
+// message pipeline (msgsoma_kernel: one soma update per synaptic event, after everything else of the step).
 static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
+{
+    TRY(launch_deliver_slices(c, first, count));
+    if (c->im.n_msg_cores != 0u && first + count == c->im.n_slices)
+    {
+        hipLaunchKernelGGL(msgsoma_kernel, dim3(c->im.n_msg_chunks), dim3(WAVE), 0, c->stream, c->im, c->st, c->cur_slog);
+        hipLaunchKernelGGL(msgsoma_finish_kernel, dim3((c->im.n_msg_cores + 63u) / 64u), dim3(64), 0, c->stream, c->im, c->st, (int) (c->t_host & 1));
+        HIPCHK(hipGetLastError());
+    }
+    return 0;
+}
+static int launch_deliver_slices(sanafe_hip_chip *c, uint32_t first, uint32_t count)
 {
     if (c->im.ev_groups != 0u && c->cur_pushed)
     {
@@ -2059,6 +2156,7 @@ extern "C" int sanafe_hip_get_push_info(sanafe_hip_chip *c, uint32_t *enabled, u
     }
     return 0;
 }
+extern "C" int sanafe_hip_get_msg_cores(sanafe_hip_chip *c) { return c ? (int) c->im.n_msg_cores : 0; }
 extern "C" int sanafe_hip_get_event_info(sanafe_hip_chip *c, uint64_t *info, int n)
 {
     if (!c || !info || n < SANAFE_HIP_EVENT_INFO_FIELDS) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");

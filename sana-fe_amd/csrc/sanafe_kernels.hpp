@@ -211,6 +211,21 @@ struct DevImage
     const uint32_t *ev_chunk_core; // [n_slots / 64] local core of each 64-slot chunk
     const double *ev_lut;         // [32] the chip's distinct weight values, densely coded
     uint32_t ev_code_bits;        // 4 (<= 16 distinct weights: 4,096 accumulators per group) or 5 (2,048)
+    // Cores whose soma is part of the MESSAGE pipeline (sanafe_hip_image::msg_*): msgsoma_kernel walks, per post-synaptic
+    // neuron, its inbound synapses in delivery order and updates the soma once per synaptic event.
+    uint32_t n_msg_cores, n_msg_chunks;
+    const struct MsgCoreDev *msg_core_dev;  // [n_msg_cores]
+    const uint32_t *msg_chunk_core;         // [n_msg_chunks] 64-slot chunk -> msg core
+    const uint32_t *msg_chunk_slot0;        // [n_msg_chunks] first local slot of the chunk
+    const uint32_t *msg_ptr;                // [n_slots + 1] a neuron's inbound synapses in msg_pre / msg_w, delivery order
+    const uint32_t *msg_pre;                // GLOBAL slot of the synapse's source neuron
+    const double *msg_w;
+    const uint32_t *msg_ax_pre;             // the cores' inbound axons (message counting), core after core
+};
+struct MsgCoreDev
+{
+    uint32_t core, first_chunk, ax_beg, ax_end;
+    sanafe_hip_msg_core_costs costs;
 };
 // One group of destination cores of the event layout: consecutive cores whose slots (each core padded to 64) span at most
 // 2^(16 - code bits) - 64 accumulators; accumulator i of the group is local slot slot0 + i.
@@ -286,6 +301,7 @@ struct DevState
     double *delay_log;            // [delay_log_cap] largest per-core delay of each step (multi-GPU simple timing), or NULL
     long long delay_log_cap;
     // event-driven delivery (DevImage::ev_*): what a step delivered by events leaves for the NEXT step's neuron launch
+    uint32_t *msg_cnt;            // [n_msg_cores][4]: synaptic events, soma updates that fired, messages of the step (msgsoma_kernel)
     uint32_t *ev_part;            // [EV_MAX_SEGMENTS][n_slots]: per segment of the source space and neuron, count * 2^ev_shift + sum
                                   // of the weights that arrived (0: nothing); every workgroup stores all of its accumulators
 };
@@ -577,7 +593,10 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
     {
         const uint32_t model = cls & 7u; // padding slots carry SANAFE_SOMA_NONE
         int status = 0;
-        if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST)
+        // buffer before axon_out: the neuron pipeline holds no unit; the status the message pipeline's soma calls left persists
+        // and axon_out acts on it (src/mapped.cpp:168-188, src/chip.cpp:710-736)
+        if (!UNI && model == SANAFE_SOMA_PERSIST) status = st.status[c0 + lane];
+        if (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST && (UNI || model != SANAFE_SOMA_PERSIST))
         {
             const uint32_t inkind = (cls >> 3) & 7u;
             // ---- synaptic input from the time-step buffer / delay ring (read, then clear) ----
@@ -586,6 +605,13 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
             if (inkind == SANAFE_IN_ZERO)
             {
                 has_in = true;
+                cur = 0.0;
+            }
+            else if (inkind == SANAFE_IN_NONE)
+            {
+                // buffer inside the soma unit: the neuron loop calls the soma without an input; its synaptic input reaches
+                // it per event in the message pipeline (msgsoma_kernel)
+                has_in = false;
                 cur = 0.0;
             }
             else if (inkind == SANAFE_IN_GATED)
@@ -781,7 +807,7 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         // SANAFE_SOMA_HOST slots (plugin units) are evaluated by the host between
         // step_neurons and step_deliver; host_status_kernel sets their status and spike bits.
         const bool live = model != SANAFE_SOMA_NONE;
-        if (live && model != SANAFE_SOMA_HOST) st.status[c0 + lane] = (uint8_t) status;
+        if (live && model != SANAFE_SOMA_HOST && (UNI || model != SANAFE_SOMA_PERSIST)) st.status[c0 + lane] = (uint8_t) status;
         if (sa.stlog != nullptr && live) sa.stlog[c0 + lane] = (uint8_t) status;
         const unsigned long long fired_mask = __ballot(status == 3);
         // push delivery (see DevImage::push_*): this step was decided to be one of few spikes -- the wavefront delivers its
@@ -807,13 +833,15 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
         // ---- default costing, src/pipeline.hpp:574-731.  Counters and class costs are taken per wavefront from
         //      ballots; only what depends on the individual neuron -- the static totals of a spike, or costs when
         //      the 64 neurons do not share one cost class -- is summed per lane and reduced once. ----
-        const bool counted = (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST);
+        const bool sender = (model != SANAFE_SOMA_NONE && model != SANAFE_SOMA_HOST); // (host slots: host_status_kernel)
+        const bool counted = sender && (UNI || model != SANAFE_SOMA_PERSIST);         // a soma call of the neuron loop
         const unsigned long long m_cnt = __ballot(counted);
+        const unsigned long long fired_cnt = fired_mask & m_cnt;
         if (m_cnt != 0ull) // wave-uniform
         {
-            const unsigned long long m_upd = __ballot(status >= 2);
+            const unsigned long long m_upd = __ballot(counted && status >= 2);
             n_upd = __popcll(m_upd);
-            n_fire = __popcll(fired_mask);
+            n_fire = __popcll(fired_cnt);
             const uint32_t ccid = (cls >> 6) & 1023u;
             const uint32_t cc0 = UNI ? 0u : (uint32_t) __builtin_amdgcn_readlane((int) ccid, __ffsll((long long) m_cnt) - 1);
             if (UNI)
@@ -825,8 +853,8 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 sanafe_hip_cost_class c0c;
                 if (cost_lds) c0c = s_cost[cc0];
                 else c0c = im.cost_classes[cc0];
-                const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_mask),
-                             n_u = (double) __popcll(m_upd & ~fired_mask), n_i = (double) __popcll(m_cnt & ~m_upd);
+                const double n_all = (double) __popcll(m_cnt), n_f = (double) __popcll(fired_cnt),
+                             n_u = (double) __popcll(m_upd & ~fired_cnt), n_i = (double) __popcll(m_cnt & ~m_upd);
                 e_soma = (n_i * c0c.soma_energy[0] + n_u * c0c.soma_energy[1]) + n_f * c0c.soma_energy[2];
                 e_dend = n_all * c0c.dendrite_energy;
                 lat = n_all * (0.0 + c0c.dendrite_latency) + ((n_i * c0c.soma_latency[0] + n_u * c0c.soma_latency[1]) + n_f * c0c.soma_latency[2]);
@@ -847,21 +875,21 @@ neuron_kernel(DevImage im, DevState st, StepArgs sa, UniformSoma us, PendStep l1
                 e_dend = wave_sum(le_dend);
                 lat = wave_sum(l_lat);
             }
-            if (fired_mask != 0ull)
-            {
-                // everything this spike causes downstream is static per neuron
-                // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
-                SpikeStatic ss{};
-                if (status == 3 && counted) ss = im.slot_spike[c0 + lane];
-                // messages and hops of a chunk fit 24 + 40 bits: one integer reduction for both
-                const long long ph = wave_sum((long long) (((unsigned long long) ss.packets << 40) | (unsigned long long) ss.hops));
-                n_pack = (long long) ((unsigned long long) ph >> 40);
-                n_hops = (long long) ((unsigned long long) ph & ((1ull << 40) - 1ull));
-                n_ev = wave_sum((long long) ss.events);
-                if (im.spike_energy & 1) e_syn = wave_sum(ss.e_syn);
-                if (im.spike_energy & 2) e_net = wave_sum(ss.e_net);
-                if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
-            }
+        }
+        if ((fired_mask & __ballot(sender)) != 0ull) // wave-uniform
+        {
+            // everything this spike causes downstream is static per neuron
+            // (pipeline_process_axon_out, receive_message: src/chip.cpp:694-708, 802-834)
+            SpikeStatic ss{};
+            if (status == 3 && sender) ss = im.slot_spike[c0 + lane];
+            // messages and hops of a chunk fit 24 + 40 bits: one integer reduction for both
+            const long long ph = wave_sum((long long) (((unsigned long long) ss.packets << 40) | (unsigned long long) ss.hops));
+            n_pack = (long long) ((unsigned long long) ph >> 40);
+            n_hops = (long long) ((unsigned long long) ph & ((1ull << 40) - 1ull));
+            n_ev = wave_sum((long long) ss.events);
+            if (im.spike_energy & 1) e_syn = wave_sum(ss.e_syn);
+            if (im.spike_energy & 2) e_net = wave_sum(ss.e_net);
+            if (im.spike_energy & 4) e_dend += wave_sum(ss.e_dend);
         }
         if (pushing) push_walk(im, st.push_core_cnt + (size_t) sa.push_buf * im.n_cores * 2u, sa.ring_next, sa.rvalid_next, fired_mask, push_b, push_e, lane);
     }
@@ -1938,6 +1966,9 @@ deliver_kernel(DevImage im, DevState st, long long done /* steps simulated befor
 //   atomics into the time-step buffer the write-back alone was ~13 us of a 38 us launch at 2 % activity.
 //   Messages and events per destination core go to the push counters that level 1 of the step reduction prices.
 //   WAVES wavefronts per workgroup share the accumulators: more loads in flight per CU without more rows to write back.
+//   UPL units per lane and batch: with LPB = 4 and UPL = 2 a batch covers 16 neurons instead of 8 with the same 8 unit
+//   slots per block -- twice the table entries and words in flight per wavefront (the launch is bound by the bytes in
+//   flight per CU, not by LDS or vector issue).
 // ---------------------------------------------------------------------------------------
 constexpr uint32_t EV_TILE = 1024;      // source slots per tile: 16 per lane
 constexpr uint32_t EV_LIST_CAP = 1536;  // per wavefront (16-bit entries): a tile adds at most 1,024, the list is drained from 512 on
@@ -1952,7 +1983,7 @@ __device__ __forceinline__ uint4 ev_load16(const uint4 *p)
     return *p;
 #endif
 }
-template <int LPB, int CODE_BITS, int WAVES>
+template <int LPB, int CODE_BITS, int WAVES, int UPL = 1>
 __global__ void __launch_bounds__(WAVES * WAVE)
 event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
@@ -2007,7 +2038,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     };
     struct Words
     {
-        uint4 w;
+        uint4 w[UPL]; // UPL units per lane and batch: lane q of a block holds units q, q + LPB, ...
         uint32_t unit0, units;
     };
     const uint4 *words = reinterpret_cast<const uint4 *>(im.ev_words);
@@ -2026,7 +2057,9 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
             w.units = m.have ? (uint32_t) m.m1 - (uint32_t) m.m0 : 0u;
             w.unit0 = (uint32_t) m.m0;
             // (lanes without a unit read the block's first unit -- or, for an empty block, whatever follows: the array is padded)
-            w.w = ev_load16(words + (size_t) w.unit0 + (q < w.units ? q : 0u));
+#pragma unroll
+            for (uint32_t u = 0; u < (uint32_t) UPL; u++)
+                w.w[u] = ev_load16(words + (size_t) w.unit0 + (q + u * LPB < w.units ? q + u * LPB : 0u));
             if (m.have)
             {
                 const uint32_t mask = (uint32_t) (m.m0 >> 32);
@@ -2044,9 +2077,11 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
             const Words wc = wb;
             if (b + NB < len) fetch_words(ma, wb);
             if (b + 2u * NB < len) fetch_meta(b + 2u * NB, ma);
-            if (q < wc.units) add8(wc.w);
-            // blocks of more than LPB units: the rest, LPB units at a time
-            for (uint32_t u = q + LPB; __ballot(u < wc.units) != 0ull; u += LPB)
+#pragma unroll
+            for (uint32_t u = 0; u < (uint32_t) UPL; u++)
+                if (q + u * LPB < wc.units) add8(wc.w[u]);
+            // blocks of more than LPB x UPL units: the rest, LPB units at a time
+            for (uint32_t u = q + UPL * LPB; __ballot(u < wc.units) != 0ull; u += LPB)
                 if (u < wc.units) add8(ev_load16(words + (size_t) wc.unit0 + u));
         }
         wave_lds_fence(); // the list is rewritten
@@ -2141,6 +2176,126 @@ __global__ void event_fold_kernel(DevImage im, DevState st, long long t_done)
     const size_t gi = (size_t) ((t_done + 1) % im.ring_slots) * im.n_slots + g;
     st.ring[gi] = (double) tot;
     st.ring_valid[gi] = 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// K2m: cores whose SOMA is part of the message pipeline (buffer inside the soma unit or before axon_out; DevImage::msg_*).
+//
+// The reference runs, for every synaptic event of such a core and in delivery order, synapse -> dendrite -> soma
+// (process_message / execute_pipeline, src/chip.cpp:738-789; build_message_processing_pipeline, src/mapped.cpp:27-58): the
+// `accumulator` dendrite returns the running sum of the step's currents (src/models.cpp:71-94) and the TrueNorth soma is
+// updated with it -- leak, bias, input, threshold and reset, once PER EVENT (src/models.cpp:724-830).  A neuron's events
+// are its inbound synapses whose source fired, in delivery order, and nothing couples two neurons of the core: one lane
+// per post-synaptic neuron walks its own list against the step's spike bitmap.  grid = 64-slot chunks of these cores,
+// block = 64, launched after the step's delivery:
+//   * potential and status as the LAST update left them (what get_status reports at the end of a step; with the buffer
+//     before axon_out it is also what the NEXT neuron launch sends spikes for: SANAFE_SOMA_PERSIST);
+//   * the step's spike RECORD row of the chunk = neurons whose final status is `fired` (the reference's traces read the
+//     status at the end of the step, src/pymodule.cpp:549-706); the bitmap that was delivered is left alone;
+//   * per core: synaptic events, updates that fired, messages (the first chunk of a core walks its axon list) -- integers;
+//     msgsoma_finish_kernel prices them once per core into the step's partials and the core's processing delay.
+// ---------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(WAVE) msgsoma_kernel(DevImage im, DevState st, uint32_t *slog /* spike-record row of the step, or NULL */)
+{
+    const uint32_t lane = threadIdx.x;
+    const uint32_t k = im.msg_chunk_core[blockIdx.x];
+    const uint32_t slot0 = im.msg_chunk_slot0[blockIdx.x], slot = slot0 + lane;
+    const MsgCoreDev mcd = im.msg_core_dev[k];
+    const uint32_t cls = im.slot_cls[slot];
+    const bool live = (cls & 7u) != SANAFE_SOMA_NONE;
+    const uint32_t b = live ? im.msg_ptr[slot] : 0u, e = live ? im.msg_ptr[slot + 1u] : 0u;
+    sanafe_hip_soma_class p{};
+    if (live) p = im.soma_classes[cls >> 16];
+    const double bias = live ? im.slot_bias[slot] : 0.0;
+    double v = live ? st.v[slot] : 0.0, acc = 0.0;
+    uint32_t n_events = 0, n_fired = 0;
+    int status = 0;
+    for (uint32_t i = b; i < e; i++)
+    {
+        const uint32_t pre = im.msg_pre[i];
+        if (!((st.bits_global[pre >> 5] >> (pre & 31u)) & 1u)) continue;
+        acc = acc + im.msg_w[i]; // AccumulatorModel::update: cleared at the step's first call, then the running sum
+        // TrueNorthModel::update with an input current: never idle
+        status = 2;
+        if (p.leak_towards_zero)
+        {
+            if (v > 0.0) v -= p.leak_decay;
+            else if (v < 0.0) v += p.leak_decay;
+        }
+        else v += p.leak_decay;
+        v += bias;
+        v += acc;
+        if (v >= p.threshold)
+        {
+            if (p.reset_mode == SANAFE_RESET_HARD) v = p.reset;
+            else if (p.reset_mode == SANAFE_RESET_SOFT) v -= p.threshold;
+            else if (p.reset_mode == SANAFE_RESET_SATURATE) v = p.threshold;
+            status = 3;
+        }
+        else if (v <= p.reverse_threshold)
+        {
+            if (p.reverse_reset_mode == SANAFE_RESET_HARD) v = p.reverse_reset;
+            else if (p.reverse_reset_mode == SANAFE_RESET_SOFT) v += p.reverse_threshold;
+            else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
+        }
+        n_events++;
+        n_fired += status == 3 ? 1u : 0u;
+    }
+    int final_status = 0;
+    if (live)
+    {
+        if (n_events != 0u)
+        {
+            st.v[slot] = v;
+            st.status[slot] = (uint8_t) status;
+            final_status = status;
+        }
+        else final_status = st.status[slot]; // what the neuron loop left (or, before axon_out, an earlier step's events)
+    }
+    const unsigned long long fired_now = __ballot(final_status == 3);
+    if (slog != nullptr && lane == 0)
+    {
+        slog[slot0 >> 5] = (uint32_t) fired_now;
+        slog[(slot0 >> 5) + 1u] = (uint32_t) (fired_now >> 32);
+    }
+    const long long ev = wave_sum((long long) n_events), fi = wave_sum((long long) n_fired);
+    if (lane == 0)
+    {
+        if (ev != 0) atomicAdd(&st.msg_cnt[k * 4u + 0u], (uint32_t) ev);
+        if (fi != 0) atomicAdd(&st.msg_cnt[k * 4u + 1u], (uint32_t) fi);
+    }
+    if (blockIdx.x == mcd.first_chunk) // the core's messages: its inbound axons whose source fired
+    {
+        uint32_t cnt = 0;
+        for (uint32_t a = mcd.ax_beg + lane; a < mcd.ax_end; a += WAVE)
+        {
+            const uint32_t pre = im.msg_ax_pre[a];
+            cnt += (st.bits_global[pre >> 5] >> (pre & 31u)) & 1u;
+        }
+        const long long msgs = wave_sum((long long) cnt);
+        if (lane == 0) st.msg_cnt[k * 4u + 2u] = (uint32_t) msgs;
+    }
+}
+
+// One thread per such core, after msgsoma_kernel: the step's counts priced with the core's default costs
+// (src/pipeline.hpp:511-731) into the partial of the core's first neuron workgroup -- unit energies by role, soma-activity
+// counters -- and the core's message-processing delay (axon-in latency per message + the units' latencies per event).
+__global__ void msgsoma_finish_kernel(DevImage im, DevState st, int parity)
+{
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= im.n_msg_cores) return;
+    const MsgCoreDev mcd = im.msg_core_dev[k];
+    const sanafe_hip_msg_core_costs &c = mcd.costs;
+    const double ev = (double) st.msg_cnt[k * 4u + 0u], fi = (double) st.msg_cnt[k * 4u + 1u], msgs = (double) st.msg_cnt[k * 4u + 2u];
+    WgPart *cp = st.wg_part + ((size_t) parity * im.n_wgs + im.core_wg_beg[mcd.core]) * PARTS_PER_WG;
+    cp->e_syn += ev * c.synapse_energy;
+    cp->e_dend += ev * c.dendrite_energy;
+    cp->e_soma += ev * (c.soma_energy[0] + c.soma_energy[1]) + fi * c.soma_energy[2];
+    cp->updated += (long long) st.msg_cnt[k * 4u + 0u];
+    cp->fired += (long long) st.msg_cnt[k * 4u + 1u];
+    st.host_proc[(size_t) parity * im.n_cores + mcd.core] = msgs * c.axon_in_latency +
+            ev * ((c.synapse_latency + c.dendrite_latency) + (c.soma_latency[0] + c.soma_latency[1])) + fi * c.soma_latency[2];
+    st.msg_cnt[k * 4u + 0u] = st.msg_cnt[k * 4u + 1u] = st.msg_cnt[k * 4u + 2u] = 0u;
 }
 
 // ---------------------------------------------------------------------------------------

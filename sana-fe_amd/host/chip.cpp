@@ -953,7 +953,7 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
             for (int k = 0; k < 3; k++) chip->slot_lat[k][s] = (0.0 + cc.dendrite_latency) + cc.soma_latency[k];
         }
     }
-    if (!chip->mc.host_cores.empty())
+    if (!chip->mc.host_cores.empty() && !chip->mc.msg_on_device) // (msg_on_device: these cores run on the device, msgsoma_kernel)
     {
         try
         {
@@ -1387,6 +1387,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
+    if (chip->mc.msg_on_device && (timing_model != SANAFE_TIMING_SIMPLE || want_messages || ((record & SANAFE_RECORD_STEPS) && chip->mc.log.any)))
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: cores whose soma is part of the message pipeline (buffer inside the soma unit / "
+                                                "before axon_out) are simulated under the simple timing model, without message traces or "
+                                                "optional perf columns: their message costs depend on the statuses the soma returns at run time");
     const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
     if (want_state && chip->log_v_gids.empty() && chip->log_u_gids.empty())
         return fail(SANAFE_HIP_ERR_INVALID, "SANAFE_RECORD_STATE needs the neurons to log (sanafe_chip_set_state_log)");
@@ -2071,7 +2075,7 @@ extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, cons
     const uint32_t model = mc.slot_model[ls];
     try
     {
-        if (model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH)
+        if (model == SANAFE_SOMA_LIF || model == SANAFE_SOMA_TRUENORTH || model == SANAFE_SOMA_PERSIST)
         {
             sanafe_amd::SomaAttr a;
             a.key = key;
@@ -2082,7 +2086,7 @@ extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, cons
             const uint32_t cls = mc.slot_cls[ls];
             sanafe_hip_soma_class p = mc.soma_classes[cls >> 16];
             sanafe_amd::SomaAttrEffect fx;
-            sanafe_amd::apply_soma_attribute(model, a, p, fx);
+            sanafe_amd::apply_soma_attribute(model == SANAFE_SOMA_PERSIST ? static_cast<uint32_t>(SANAFE_SOMA_TRUENORTH) : model, a, p, fx);
             if (fx.random_mask_set)
             {
                 uint32_t old_mask = 0;

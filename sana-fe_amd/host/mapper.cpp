@@ -434,6 +434,15 @@ sanafe_hip_image MappedChip::image() const
     im.lat_class_per_event = lat_class_per_event.data();
     im.syn_meta = syn_meta.data();
     im.syn_weight = syn_weight.data();
+    im.n_msg_cores = static_cast<uint32_t>(msg_core.size());
+    im.msg_core = msg_core.data();
+    im.msg_ax_beg = msg_ax_beg.data();
+    im.msg_ax_pre = msg_ax_pre.data();
+    im.msg_ax_nsyn = msg_ax_nsyn.data();
+    im.msg_syn_beg = msg_syn_beg.data();
+    im.msg_syn_post = msg_syn_post.data();
+    im.msg_syn_weight = msg_syn_weight.data();
+    im.msg_costs = msg_costs.data();
     return im;
 }
 
@@ -813,6 +822,28 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         mc.host_cores.push_back(std::move(hc));
     }
     const bool any_host_core = !mc.host_cores.empty();
+    {
+        // Can these cores run on the device?  Buffer inside the soma unit / before axon_out (not a plugin or `taps` case), one
+        // synapse unit `current_based`, one dendrite unit `accumulator`, one soma unit `truenorth`, each with its default
+        // costs: then the message pipeline is synapse -> running sum -> TrueNorth update per event, which msgsoma_kernel
+        // runs per post-synaptic neuron in delivery order.  All of the chip's host cores or none.
+        bool ok = any_host_core && !(std::getenv("SANAFE_HOST_CORES") != nullptr && std::atoi(std::getenv("SANAFE_HOST_CORES")) != 0);
+        for (const MappedChip::HostCore &hc : mc.host_cores)
+        {
+            ok = ok && (hc.bp == SANAFE_BUF_INSIDE_SOMA || hc.bp == SANAFE_BUF_BEFORE_AXON_OUT) && !taps_need_host[hc.core];
+            int n_syn = 0, n_dend = 0, n_soma = 0;
+            for (const UnitInfo &u : tmpl_of(static_cast<int>(hc.core)).units)
+            {
+                n_syn += u.syn, n_dend += u.dend, n_soma += u.soma;
+                if (u.syn) ok = ok && u.model == M_CURRENT_BASED && !u.dend && !u.soma && u.e_spike && u.l_spike;
+                if (u.dend) ok = ok && u.model == M_ACCUMULATOR && !u.syn && !u.soma && u.e_update && u.l_update;
+                if (u.soma) ok = ok && u.model == M_TRUENORTH && !u.syn && !u.dend && u.has_soma_e && u.has_soma_l;
+                ok = ok && !u.log && !u.log_energy && !u.log_latency;
+            }
+            ok = ok && n_syn == 1 && n_dend == 1 && n_soma == 1;
+        }
+        mc.msg_on_device = ok;
+    }
     if (any_host_core)
     {
         // per-unit neuron addresses in arrival (mapping) order: Core::map_neuron, src/core.cpp:116-168
@@ -900,7 +931,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         const UnitInfo &du = t.units[dend_unit[gid]];
         const UnitInfo &su = t.units[soma_unit[gid]];
         const int bp = d.core_buffer_pos[c];
-        if (host_core_index[c] >= 0)
+        const bool msg_core = host_core_index[c] >= 0 && mc.msg_on_device; // soma in the message pipeline, on the device
+        if (host_core_index[c] >= 0 && !msg_core)
         {
             // evaluated by the host library every step (host/host_cores.cpp); the device only keeps its status and spike bit
             const uint32_t hs = mc.slot_of_gid[gid];
@@ -914,14 +946,18 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             mc.slot_log_potential[hs - SO] = d.neuron_log_potential[gid];
             continue;
         }
-        if (bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE && bp != SANAFE_BUF_BEFORE_DENDRITE)
+        if (msg_core && su.model == M_TRUENORTH && random_mask_key >= 0)
+            for (int64_t i = d.neuron_attr_ptr[gid]; i < d.neuron_attr_ptr[gid + 1]; i++)
+                if (d.neuron_attrs.key[i] == random_mask_key && d.neuron_attrs.num[i] != 0.0)
+                    throw UnsupportedError("TrueNorth random_mask on a core whose soma is part of the message pipeline");
+        if (!msg_core && bp != SANAFE_BUF_BEFORE_SOMA && bp != SANAFE_BUF_INSIDE_DENDRITE && bp != SANAFE_BUF_BEFORE_DENDRITE)
             throw UnsupportedError("buffer position " + std::to_string(bp) +
                     " is not implemented on the MI355X backend (supported: soma/outside, dendrite/inside, dendrite/outside)");
         if (du.model == M_PLUGIN)
             throw UnsupportedError("dendrite model of unit '" + du.name + "' is not implemented on the MI355X backend");
         if (du.model == M_TAPS && bp != SANAFE_BUF_BEFORE_SOMA)
             throw UnsupportedError("`taps` dendrites are implemented for `buffer_position: soma` (outside the unit) only");
-        uint8_t kind = SANAFE_IN_BUFFERED;
+        uint8_t kind = msg_core ? SANAFE_IN_NONE : SANAFE_IN_BUFFERED; // (msg cores: the soma's input arrives per event, msgsoma_kernel)
         if (bp == SANAFE_BUF_INSIDE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_ZERO, neuron_dend_kind[gid] = 1;
         if (bp == SANAFE_BUF_BEFORE_DENDRITE && du.model == M_ACCUMULATOR) kind = SANAFE_IN_LAST;
         if (du.model == M_TAPS) kind = SANAFE_IN_TAPS, neuron_dend_kind[gid] = 3, any_taps = true;
@@ -976,6 +1012,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             cc.dendrite_energy = *du.e_update;
             cc.dendrite_latency = *du.l_update;
         }
+        // buffer before axon_out: the neuron pipeline holds no unit at all -- nothing is costed in the neuron loop
+        if (msg_core && bp == SANAFE_BUF_BEFORE_AXON_OUT) cc = sanafe_hip_cost_class{};
         CostKey ck;
         std::memcpy(ck.b, &cc, sizeof(cc));
         auto cit = cost_ids.find(ck);
@@ -996,6 +1034,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         else if (su.model == M_TRUENORTH) model = SANAFE_SOMA_TRUENORTH, p.leak_decay = 0.0;
         else if (su.model == M_INPUT) model = SANAFE_SOMA_INPUT;
         else model = SANAFE_SOMA_HOST;
+        const bool persist = msg_core && bp == SANAFE_BUF_BEFORE_AXON_OUT; // (the class word gets SANAFE_SOMA_PERSIST below)
         // (an `input` soma never asks its dendrite for anything: such a neuron merely sits on the unit)
         if (du.model == M_TAPS && model == SANAFE_SOMA_INPUT) kind = SANAFE_IN_BUFFERED;
         if (du.model == M_TAPS && model != SANAFE_SOMA_INPUT)
@@ -1154,6 +1193,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
             pcls = it->second;
         }
+        if (persist) model = SANAFE_SOMA_PERSIST; // (its soma class is the TrueNorth parameter set: the per-event updates use it)
         mc.slot_cls[ls] = model | (static_cast<uint32_t>(kind) << 3) | (cit->second << 6) | (pcls << 16);
         if (du.model == M_TAPS && model != SANAFE_SOMA_INPUT) mc.slot_aux[ls] = static_cast<uint32_t>(taps_index[gid]);
         mc.slot_model[ls] = static_cast<uint8_t>(model);
@@ -1535,6 +1575,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     hs.addr = static_cast<uint32_t>(syn_addr[e]);
                     hs.post = offset_in_core[d.edge_dst[e]];
                     hs.edge = static_cast<int64_t>(e);
+                    hs.weight = d.edge_weight[e];
                     hs.pre_checks_synapses = !receives_forced_synapse.empty() && receives_forced_synapse[d.edge_src[e]] != 0;
                     hc.synapses.push_back(hs);
                 }
@@ -1573,6 +1614,38 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     }
     if (syn0 != static_cast<uint64_t>(local_end - local_beg)) throw std::logic_error("mapper: synapse numbering out of step");
     lap("axon numbering + aggregates");
+    if (mc.msg_on_device)
+    {
+        // the tables of the cores whose soma is part of the message pipeline, as the image carries them (sanafe_hip_image::msg_*)
+        mc.msg_ax_beg.push_back(0);
+        mc.msg_syn_beg.push_back(0);
+        for (const MappedChip::HostCore &hc : mc.host_cores) // (ascending core id)
+        {
+            mc.msg_core.push_back(hc.core - mc.first_core);
+            for (const MappedChip::HostCore::Axon &ax : hc.axons)
+            {
+                mc.msg_ax_pre.push_back(ax.pre);
+                mc.msg_ax_nsyn.push_back(ax.n_syn);
+            }
+            for (const MappedChip::HostCore::Synapse &hs : hc.synapses)
+            {
+                mc.msg_syn_post.push_back(hs.post);
+                mc.msg_syn_weight.push_back(hs.weight);
+            }
+            mc.msg_ax_beg.push_back(static_cast<uint32_t>(mc.msg_ax_pre.size()));
+            mc.msg_syn_beg.push_back(static_cast<uint32_t>(mc.msg_syn_post.size()));
+            sanafe_hip_msg_core_costs k{};
+            k.axon_in_latency = hc.ain_latency;
+            for (const UnitInfo &u : tmpl_of(static_cast<int>(hc.core)).units)
+            {
+                if (u.syn) k.synapse_energy = *u.e_spike, k.synapse_latency = *u.l_spike;
+                if (u.dend) k.dendrite_energy = *u.e_update, k.dendrite_latency = *u.l_update;
+                if (u.soma)
+                    for (int q = 0; q < 3; q++) k.soma_energy[q] = u.se[q], k.soma_latency[q] = u.sl[q];
+            }
+            mc.msg_costs.push_back(k);
+        }
+    }
     mc.lat_class_per_event.resize(255, 0.0);
     for (uint32_t k = 0; k < LC; k++) core_axon_beg[k + 1] += core_axon_beg[k];
     // cores without inbound axons still need a valid synapse base

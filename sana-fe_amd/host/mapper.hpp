@@ -185,6 +185,7 @@ struct MappedChip
             uint32_t addr{0};          // address on that unit: arrival order in map_connections order
             uint32_t post{0};          // post neuron, offset within the core
             int64_t edge{0};           // index into sanafe_desc::edge_*
+            double weight{0.0};        // the edge's weight (cores that run on the device: sanafe_hip_image::msg_syn_weight)
             bool pre_checks_synapses{false}; // the SOURCE neuron itself receives through a synapse unit flagged
                                              // update_every_timestep: forced_updates walks its connections (src/chip.cpp:989-1005)
         };
@@ -202,6 +203,14 @@ struct MappedChip
         std::vector<Axon> axons;       // delivery order (source core, source neuron): src/chip.cpp:661-690
     };
     std::vector<HostCore> host_cores;
+    // Buffer inside the soma unit / before axon_out with built-in units only (`current_based`, `accumulator`, `truenorth`, one
+    // unit of each role): these cores run on the DEVICE (sanafe_hip_image::msg_*, msgsoma_kernel); host_cores then only carries
+    // their tables to the image and no host replay object is created.  All such cores of a chip or none (SANAFE_HOST_CORES=1
+    // keeps them on the host).
+    bool msg_on_device{false};
+    std::vector<uint32_t> msg_core, msg_ax_beg, msg_ax_pre, msg_ax_nsyn, msg_syn_beg, msg_syn_post;
+    std::vector<double> msg_syn_weight;
+    std::vector<sanafe_hip_msg_core_costs> msg_costs;
 
     // ---- optional perf-trace columns: tiles / cores with log_energy, units with log_energy / log_latency
     //      (sim_trace_get_optional_traces, src/chip.cpp:1541-1579).  Filled only when some flag is set. ----

@@ -39,13 +39,20 @@ def _compare(chip, orc, steps):
     return fired
 
 
+@pytest.mark.parametrize("where", ["device", "host"])
 @pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
-def test_soma_inside_the_message_pipeline(S, position):
+def test_soma_inside_the_message_pipeline(S, monkeypatch, position, where):
     """Buffer positions 3 and 4 with TrueNorth somas: the soma updates once per synaptic event (and, inside the unit,
-    once more in the neuron loop); behind the buffer before axon_out a neuron's status persists until the next event."""
+    once more in the neuron loop); behind the buffer before axon_out a neuron's status persists until the next event.
+    With built-in units (`current_based`, `accumulator`, `truenorth`) such cores run ON THE DEVICE since round 4
+    (msgsoma_kernel: one lane per post-synaptic neuron walks its inbound synapses in delivery order; VERDICT r3 item 6);
+    SANAFE_HOST_CORES=1 keeps the host replay of round 3, which plugin units and other models still use."""
+    if where == "host":
+        monkeypatch.setenv("SANAFE_HOST_CORES", "1")
     arch, net = nets.host_cores(S, position=position)
     chip = S.SpikingChip(arch)
     chip.load(net)
+    assert chip.device_layout()["msg_cores_on_device"] == (2 if where == "device" else 0)
     orc = OracleChip(S.to_desc(arch, net))
     fired = _compare(chip, orc, 40)
     host = chip.status().reshape(6, -1)[[2, 4]]
@@ -114,3 +121,31 @@ def test_host_cores_need_simple_timing_and_one_rank(S):
     sharded = S.SpikingChip(arch, device=0, n_ranks=2, rank=0)
     with pytest.raises(NotImplementedError, match="single-rank"):
         sharded.load(net)
+
+
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_message_pipeline_somas_in_one_batched_run(S, position):
+    """The same cores through ONE sim() call with records (no host round trip between steps: the chip has no host replay
+    object any more): per-step totals and the spike record rows -- which hold the status at the END of each step, as the
+    reference's traces do -- against the oracle."""
+    arch, net = nets.host_cores(S, position=position, seed=11)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    assert chip.device_layout()["msg_cores_on_device"] == 2
+    orc = OracleChip(S.to_desc(arch, net))
+    steps = 60
+    tot = chip.run(steps, "simple", record=True)
+    recs = chip.step_totals(0, steps)
+    acc = {}
+    for t in range(steps):
+        b = orc.step("simple")
+        for ka, kb in INT_KEYS:
+            assert recs[ka][t] == b[kb], (t, ka)
+        for k in DBL_KEYS:
+            assert recs[k][t] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k)
+        assert np.array_equal(chip.step_fired(t), (orc.status() == 3).astype(np.uint8)), t
+        for k, v in b.items():
+            acc[k] = acc.get(k, 0) + v
+    for ka, kb in INT_KEYS:
+        assert tot[ka] == acc[kb]
+    assert np.array_equal(chip.potentials(), orc.potentials()) and np.array_equal(chip.status(), orc.status())

@@ -76,9 +76,9 @@ def test_hot_kernels_keep_their_occupancy_and_do_not_spill(isa):
     assert len(hot) == 2
     for name, (vgprs, scratch) in hot.items():
         assert vgprs <= 80 and scratch == 0, (name, vgprs, scratch)
-    # event-driven delivery: 4 / 8 lanes per block x 4 / 5 code bits x 4 / 8 / 16 wavefronts, 64 registers (8 wavefronts per
+    # event-driven delivery: (4, 8 lanes x 1 unit, 4 lanes x 2 units) per block x 4 / 5 code bits x 4 / 8 / 16 wavefronts, 64 registers (8 wavefronts per
     # SIMD: two 16-wavefront workgroups per CU), no scratch
     event = {k: v for k, v in meta.items() if "event_deliver_kernel" in k}
-    assert len(event) == 12
+    assert len(event) == 18
     for name, (vgprs, scratch) in event.items():
         assert vgprs <= 64 and scratch == 0, (name, vgprs, scratch)
