@@ -553,11 +553,11 @@ def main():
         by_events = (layout_now["pushed_steps"] - pushed_before) / float(args.timed_steps) if evl else 0.0
         if evl:
             # Steps delivered by events (event_deliver_kernel) read: every workgroup its segment of the spike bitmap
-            # (groups x bitmap), per fired neuron and core group two 8-byte entries of the block table, the fired neurons'
+            # (groups x bitmap), per fired neuron and core group one 8-byte entry of the block table, the fired neurons'
             # blocks of 2-byte words (padded to 16 bytes per block: layout bytes / synapses per word on average), and write
             # one 4-byte partial per (segment, neuron slot) -- every accumulator, touched or not -- which the next neuron
             # launch reads back (counted there)
-            ev_parts = {"spike_bitmap_scans": evl["groups"] * lay[4], "block_tables": 16.0 * fired * evl["groups"],
+            ev_parts = {"spike_bitmap_scans": evl["groups"] * lay[4], "block_tables": 8.0 * fired * evl["groups"],
                         "synapse_words_of_fired_neurons": ev * lay[9] / max(1.0, float(info["n_synapses"])),
                         "partial_rows_written": 4.0 * evl["segments"] * float(info["n_slots"])}
             design_event = float(sum(ev_parts.values()))

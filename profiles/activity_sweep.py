@@ -90,7 +90,7 @@ def main():
                    "stream_layout_bytes": float(sum(lay[0:5])) + 17.0 * n,
                    "survey_8d_model_bytes": 28.0 * ev + 96.0 * msgs,
                    "event_path_bytes": None if not evl else
-                   evl["groups"] * lay[4] + 16.0 * fired * evl["groups"] + ev * lay[9] / max(1.0, float(info["n_synapses"])) +
+                   evl["groups"] * lay[4] + 8.0 * fired * evl["groups"] + ev * lay[9] / max(1.0, float(info["n_synapses"])) +
                    4.0 * evl["segments"] * float(info["n_slots"]),
                    "event_layout": evl, "load_s": load_s}
             rows.append(row)

@@ -580,9 +580,10 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // need a fired neuron's blocks read one contiguous 5 KB region at about the same time: each 128-byte line comes out of
     // HBM once and is served to the other XCDs by the Infinity Cache; with the blocks of a GROUP together -- tried -- every
     // line is private to one workgroup and the launch is HBM-bound on half-used lines: 97 instead of 71 us at 10 % activity).
-    // meta[n][g] = first 16-byte unit of block (n, g) | core mask << 32; meta[n][NG] = the end of the neuron's blocks
-    const uint64_t mrow = (uint64_t) NG + 1u;
-    std::vector<uint64_t> meta(N * mrow, 0ull);
+    // The TABLE is group-major -- meta[g][n] = first 16-byte unit of block (n, g) | units << 32 | core mask << 48, one
+    // self-contained 8-byte entry per lookup -- so that a workgroup, which walks the fired neurons of its segment in ascending
+    // order, reads its group's entries front to back: at the headline's activity a 128-byte line serves ~5 lookups.
+    std::vector<uint64_t> meta((uint64_t) NG * N + 1u, 0ull);
     std::vector<uint64_t> neuron_units(N + 1, 0ull);
     parallel_for(N, [&](uint64_t lo, uint64_t hi) {
         for (uint64_t n = lo; n < hi; n++)
@@ -601,12 +602,14 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
             uint64_t off = neuron_units[n];
             for (uint32_t g = 0; g < NG; g++)
             {
-                meta[n * mrow + g] = off | ((uint64_t) mask[n * NG + g] << 32);
-                off += (cnt[n * NG + g] + 7u) / 8u;
+                const uint64_t units = (cnt[n * NG + g] + 7u) / 8u;
+                if (units > 0xffffu) bad = true;
+                meta[(uint64_t) g * N + n] = off | (units << 32) | ((uint64_t) mask[n * NG + g] << 48);
+                off += units;
             }
-            meta[n * mrow + NG] = off;
         }
     });
+    if (bad.load()) return 0;
     // pass 3: the words, group by group (a block is written by one thread); cnt becomes the write cursor.  Per (segment,
     // accumulator): events and |weight| sums, for the bounds of the integer accumulators.
     std::vector<uint16_t> words((total_units + 64u) * 8u, 0);
@@ -630,7 +633,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
                     const uint64_t n = h.ax_pre[a];
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const size_t sg = (size_t) std::min<uint32_t>((uint32_t) (n / EV_TILE) / seg_tiles, segments - 1u) * acc_max;
-                    uint64_t at = (meta[n * mrow + g] & 0xffffffffull) * 8u + cnt[n * NG + g];
+                    uint64_t at = (meta[g * N + n] & 0xffffffffull) * 8u + cnt[n * NG + g];
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t idx = acc0 + (h.syn_meta[src + k] & 0xffffu);
@@ -645,7 +648,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
             // padding words of every block: code 0 into the trash entries behind the group's accumulators
             for (uint64_t n = 0; n < N; n++)
             {
-                const uint64_t b0 = (meta[n * mrow + g] & 0xffffffffull) * 8u, b1 = (meta[n * mrow + g + 1] & 0xffffffffull) * 8u;
+                const uint64_t b0 = (meta[g * N + n] & 0xffffffffull) * 8u, b1 = b0 + ((meta[g * N + n] >> 32) & 0xffffull) * 8u;
                 for (uint64_t p = b0 + cnt[n * NG + g]; p < b1; p++) words[p] = (uint16_t) ((groups[g].n_acc + (uint32_t) (p & (EV_TRASH - 1u))) << code_bits);
             }
         }

@@ -203,9 +203,9 @@ struct DevImage
     uint32_t ev_always;           // 1: every step is delivered by events, the streaming kernel is never launched (tests)
     int ev_shift;                 // every event adds weight + 2^ev_shift; bounds proven per (segment, accumulator)
     const struct EvGroup *ev_group;   // [ev_groups]
-    const unsigned long long *ev_meta; // [n_global_slots][ev_groups + 1]: bits 0-31 first 16-byte unit of block (neuron, group);
-                                  // bits 32-47 which cores of the group the neuron reaches (one message each).  Entry
-                                  // [ev_groups]: the end.  A block's length is the next entry's offset minus its own.
+    const unsigned long long *ev_meta; // [ev_groups][n_global_slots]: bits 0-31 first 16-byte unit of block (neuron, group),
+                                  // bits 32-47 its length in units, bits 48-63 which cores of the group the neuron reaches
+                                  // (one message each).  Group-major: a workgroup reads its group's entries front to back.
     const uint16_t *ev_words;     // weight code (ev_code_bits) | accumulator index << ev_code_bits; padding words add into the
                                   // trash entries behind the group's accumulators
     const uint32_t *ev_chunk_core; // [n_slots / 64] local core of each 64-slot chunk
@@ -2008,7 +2008,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     if (threadIdx.x < 16) s_msgs[threadIdx.x] = s_events[threadIdx.x] = 0u;
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
-    const size_t mrow = (size_t) im.ev_groups + 1u; // entries of a neuron in ev_meta
+    const unsigned long long *mgroup = im.ev_meta + (size_t) g * im.n_global_slots; // this group's table entries
     uint16_t *list = s_list[wave];
     const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
     uint32_t msg_cnt[(16 + LPB - 1) / LPB];        // messages to core q, q + LPB, ... of the group, over this lane's neurons
@@ -2033,7 +2033,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     };
     struct Meta
     {
-        unsigned long long m0, m1;
+        unsigned long long m0;
         bool have;
     };
     struct Words
@@ -2049,12 +2049,10 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         auto fetch_meta = [&](uint32_t b, Meta &m) {
             m.have = b + j < len;
             const uint32_t f = list_slot0 + (uint32_t) list[m.have ? b + j : b];
-            const unsigned long long *me = im.ev_meta + (size_t) f * mrow + g;
-            m.m0 = me[0];
-            m.m1 = me[1];
+            m.m0 = mgroup[f];
         };
         auto fetch_words = [&](const Meta &m, Words &w) {
-            w.units = m.have ? (uint32_t) m.m1 - (uint32_t) m.m0 : 0u;
+            w.units = m.have ? (uint32_t) (m.m0 >> 32) & 0xffffu : 0u;
             w.unit0 = (uint32_t) m.m0;
             // (lanes without a unit read the block's first unit -- or, for an empty block, whatever follows: the array is padded)
 #pragma unroll
@@ -2062,7 +2060,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
                 w.w[u] = ev_load16(words + (size_t) w.unit0 + (q + u * LPB < w.units ? q + u * LPB : 0u));
             if (m.have)
             {
-                const uint32_t mask = (uint32_t) (m.m0 >> 32);
+                const uint32_t mask = (uint32_t) (m.m0 >> 48);
 #pragma unroll
                 for (uint32_t mm = 0; mm < (16 + LPB - 1) / LPB; mm++) msg_cnt[mm] += (mask >> (q + mm * LPB)) & 1u;
             }
