@@ -681,10 +681,10 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // the per-step decision rides on the push machinery (reduce_l2 decides, reduce_l1 prices the per-core counters)
     im.push_cap = h.n_slots / WAVE;
     im.push_always = im.ev_always;
-    // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~11 us + 0.75 us per million events,
+    // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~11 us + 0.6 us per million events,
     // the streaming kernel 245 us whatever the activity (and up to 0.8 ms when so few axons spike that its windows fall back
-    // to the gather path): they cross at ~46 % of the neurons firing, 0.46 events per synapse and step
-    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.42));
+    // to the gather path): they cross at ~55 % of the neurons firing, 0.55 events per synapse and step
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.5));
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
@@ -696,6 +696,8 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // 8 unit slots per block and batch from ~32 words per block on (4 lanes x 2 units: 16 neurons per batch), else 4
     c->ev_lpb = 4;
     c->ev_upl = c->ev_avg_block > 32.0 ? 2 : 1;
+    // (2 lanes x 4 units -- 32 neurons per batch -- needs 77 registers: one workgroup per CU instead of two, 175 instead of
+    //  142 us at the headline's activity)
     if (const char *env = std::getenv("SANAFE_EVENT_LPB")) c->ev_lpb = std::atoi(env) == 8 ? 8 : 4;
     if (const char *env = std::getenv("SANAFE_EVENT_UPL")) c->ev_upl = std::atoi(env) == 2 ? 2 : 1;
     if (c->ev_lpb == 8) c->ev_upl = 1;
