@@ -37,3 +37,6 @@ for n in ("c3", "c3_act002", "c4", "c2"):
     except Exception as e:
         print(n, "ERR", e)
 PY
+# SQ counters of the event kernel at the headline's activity (two --pmc passes; profiles/pmc_sq.sh)
+bash "$ROOT/profiles/pmc_sq.sh" r04_event --steps 100 --warmup 20 > "$OUT/r04_sq_event.txt" 2>&1
+cp "$OUT/sq_r04_event/sq_summary.json" "$OUT/r04_sq_event.json" 2>/dev/null

@@ -683,8 +683,8 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     im.push_always = im.ev_always;
     // Measured on C3 1,024 x 256 (profiles/r04_c3_activity.json): the event kernel takes ~11 us + 0.6 us per million events,
     // the streaming kernel 245 us whatever the activity (and up to 0.8 ms when so few axons spike that its windows fall back
-    // to the gather path): they cross at ~55 % of the neurons firing, 0.55 events per synapse and step
-    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.5));
+    // to the gather path): they cross at ~59 % of the neurons firing, 0.59 events per synapse and step
+    im.push_max_events = (uint32_t) std::min<uint64_t>(0xffffffffu, (uint64_t) ((double) h.n_synapses * 0.58));
     if (const char *env = std::getenv("SANAFE_EVENT_MAX_EVENTS")) im.push_max_events = (uint32_t) std::max(0LL, std::atoll(env));
     TRY(dalloc(c, 3 * (size_t) h.n_cores * 2, &c->st.push_core_cnt));
     TRY(dalloc(c, (size_t) EV_MAX_SEGMENTS * h.n_slots, &c->st.ev_part)); // (rows of unused segments stay zero)
