@@ -143,3 +143,50 @@ def test_split_steps_with_flushing_calls_between_the_halves(S, monkeypatch, kind
     for k in DBL_KEYS:
         assert after[k] - before[k] == pytest.approx(ref_d[k], rel=1e-9, abs=1e-30), k
     assert chip.device_layout()["pushed_steps"] == 3  # steps 20 .. 22: decided from steps 4 .. 4 (16 back, rounded down to a multiple of 4)
+
+
+def test_reset_and_state_carry_on_an_event_chip(S, monkeypatch):
+    """A step delivered by events leaves the next step's input in the partial rows, not in the time-step buffer: `reset()`
+    must drop it like the buffer rows, and `load(net, overwrite=False)` after timesteps -- which exports the chip's state
+    (sanafe_hip_export_state) -- must fold it into the buffer first (event_fold_kernel).  Every step by events."""
+    monkeypatch.setenv("SANAFE_EVENT", "2")
+
+    def build(name, n, core_idx, seed, arch):
+        rng = np.random.default_rng(seed)
+        net = S.Network(name)
+        g = net.create_neuron_group(name, n, {"reset": 0, "leak": 1}, "core_synapses", "core_dendrites", False, True, "core_soma")
+        g.set_attribute_column("threshold", rng.integers(5, 30, size=n).astype(np.float64), integer=True)
+        g.set_attribute_column("bias", np.where(rng.random(n) < 0.4, rng.integers(2, 7, size=n), 0).astype(np.float64), integer=True)
+        src = np.repeat(np.arange(n, dtype=np.int64), 24)
+        dst = rng.integers(0, n, size=24 * n).astype(np.int64)
+        net.add_edges(src, dst, rng.integers(1, 5, size=24 * n).astype(np.float64), "core_synapses")
+        cores = arch.cores()
+        half = n // 2
+        g.map_to_core(cores[core_idx], 0, half)
+        g.map_to_core(cores[core_idx + 1], half, n)
+        return net
+
+    arch = S.presets.truenorth(n_tiles=8, width=4, height=2)
+    chip = S.SpikingChip(arch)
+    chip.load(build("a", 400, 0, 1, arch))
+    assert chip.device_layout()["event_layout"] is not None and chip.device_layout()["event_layout"]["always"]
+    first = chip.sim(12, timing_model="simple")
+    # reset: a fresh run of the same chip equals the first one (pending input of step 12 is gone, potentials are zero)
+    chip.reset()
+    again = chip.sim(12, timing_model="simple")
+    assert again["neurons_fired"] == first["neurons_fired"] > 0 and again["spikes"] == first["spikes"]
+    # carry: add a second network after 12 more steps; A must continue exactly as it does alone
+    chip.load(build("b", 300, 3, 2, arch))  # overwrite=False
+    assert chip.n_neurons == 700 and chip.device_layout()["event_layout"] is not None
+    second = chip.sim(13, timing_model="simple")
+    alone_a, alone_b = S.SpikingChip(arch), S.SpikingChip(arch)
+    alone_a.load(build("a", 400, 0, 1, arch))
+    alone_b.load(build("b", 300, 3, 2, arch))
+    alone_a.sim(12, timing_model="simple")
+    alone_a.reset()
+    alone_a.sim(12, timing_model="simple")
+    a2, b2 = alone_a.sim(13, timing_model="simple"), alone_b.sim(13, timing_model="simple")
+    assert second["neurons_fired"] == a2["neurons_fired"] + b2["neurons_fired"] and b2["neurons_fired"] > 0
+    assert second["spikes"] == a2["spikes"] + b2["spikes"]
+    v = chip.potentials()
+    assert np.array_equal(v[:400], alone_a.potentials()) and np.array_equal(v[400:], alone_b.potentials())

@@ -348,3 +348,25 @@ def test_sharded_potential_traces(S):
     ref2 = one.step_state(0, 7)
     for chip, r in zip(chips, _sharded_rerun(chips, call2, chips[0]._test_gather)):
         assert np.array_equal(r, ref2)
+
+
+@pytest.mark.parametrize("mode", ["2", "1"])
+def test_two_ranks_with_event_delivery(S, monkeypatch, mode):
+    """Event-driven delivery on a tile-sharded chip -- what the multi-GPU C3 bench runs: every rank builds the event layout
+    over the GLOBAL source space (its own neurons and the other ranks'), its event kernel scans the gathered bitmap after the
+    exchange and leaves the next step's input in its own partial rows; each rank's host decides event / stream from its own
+    event counts (mode 1; mode 2: every step by events).  Two ranks on one device against the one-rank run."""
+    monkeypatch.setenv("SANAFE_EVENT", mode)
+    if mode == "1":
+        monkeypatch.setenv("SANAFE_EVENT_MAX_EVENTS", "3800")  # per rank: about half of the steps
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.05, seed=52)
+    steps = 40
+    ref, v_ref, one = _one_rank(S, arch, net, steps)
+    assert one.device_layout()["event_layout"] is not None
+    chips, results = _sharded(S, arch, net, steps)
+    for r in range(2):
+        _assert_same(results[r][0], ref)
+        lay = chips[r].device_layout()
+        assert lay["event_layout"] is not None and lay["event_layout"]["always"] == (mode == "2"), lay
+        assert lay["pushed_steps"] == steps if mode == "2" else 3 <= lay["pushed_steps"] <= 21, lay
+    assert np.array_equal(chips[0].potentials() + chips[1].potentials(), v_ref)
