@@ -68,8 +68,8 @@ def test_event_or_stream_decided_per_step(S, monkeypatch):
 
 
 @pytest.mark.slow
-@pytest.mark.parametrize("p_fire", [0.01, 0.3])
-def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire):
+@pytest.mark.parametrize("p_fire,one_segment", [(0.01, False), (0.3, False), (0.01, True)])
+def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire, one_segment):
     """SURVEY 8(d)'s shape of C3 -- 262,144 source neurons on 1,024 cores of 256, 16 destination cores that hear from
     (nearly) every neuron -- delivered by events at p_fire 0.01 and at the headline's 0.3: ten steps
     against the oracle.  (The 16 destination cores lie in 16 different core groups: blocks of ~2.6 words, far below what the
@@ -78,12 +78,17 @@ def test_c3_delivery_shape_by_events(S, monkeypatch, p_fire):
     orc = OracleChip(S.to_desc(arch, net))
     monkeypatch.setenv("SANAFE_MIN_SLICE_AXONS", "16384")
     monkeypatch.setenv("SANAFE_EVENT", "2")
+    if one_segment:
+        # one segment of 256 tiles on 4 wavefronts: a wavefront's tiles span more than the 64 its 16-bit list entries can
+        # address from the list's first tile -- the list is drained on the way (what a rank of an 8-GPU chip, 2,048 tiles, does)
+        monkeypatch.setenv("SANAFE_EVENT_SEGMENTS", "1")
+        monkeypatch.setenv("SANAFE_EVENT_WAVES", "4")
     chip = S.SpikingChip(arch)
     chip.load(net)
     lay, info = chip.device_layout(), chip.info()
     ev = lay["event_layout"]
     assert lay["syn_format"] == 7 and lay["n_bitmap_slices"] == info["n_slices"] and ev is not None and ev["always"], lay
-    assert ev["groups"] == 69 and ev["segments"] == 7 and ev["code_bits"] == 4, ev  # 15 cores of 256 per group (7 segments: 483 workgroups on 512 slots), 16 weight values
+    assert ev["groups"] == 69 and ev["segments"] == (1 if one_segment else 7) and ev["code_bits"] == 4, ev  # 15 cores of 256 per group (7 segments: 483 workgroups on 512 slots), 16 weight values
     fired = 0
     for t in range(10):
         a, b = chip.run(1, "simple", record=True), orc.step("simple")
