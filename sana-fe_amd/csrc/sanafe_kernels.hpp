@@ -1995,6 +1995,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     __shared__ uint16_t s_lut16[32];
     __shared__ uint16_t s_list[WAVES][EV_LIST_CAP];
     __shared__ uint32_t s_msgs[16], s_events[16];
+    __shared__ uint8_t s_chunk_core[ACC_MAX / WAVE]; // core (within the group) of every 64-accumulator chunk
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t wave = (uint32_t) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> 6));
     // workgroup -> (group, segment): blocks b and b + 8 share an XCD
@@ -2006,6 +2007,9 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     for (uint32_t i = threadIdx.x; i < ACC_MAX; i += BLOCK) s_acc[i] = 0u;
     if (threadIdx.x < 32) s_lut16[threadIdx.x] = (uint16_t) ((int) im.ev_lut[threadIdx.x] + (1 << im.ev_shift));
     if (threadIdx.x < 16) s_msgs[threadIdx.x] = s_events[threadIdx.x] = 0u;
+    // (staged here, under the barrier: a dependent global load per 64 accumulators in the write-back loop cost the launch
+    //  a memory latency per iteration)
+    if (threadIdx.x < eg.n_acc / WAVE) s_chunk_core[threadIdx.x] = (uint8_t) (im.ev_chunk_core[(eg.slot0 >> 6) + threadIdx.x] - eg.core0);
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
     const unsigned long long *mgroup = im.ev_meta + (size_t) g * im.n_global_slots; // this group's table entries
@@ -2144,7 +2148,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         // count * 2^shift + sum of weights, |sum| < 2^(shift-1) (proven by the host per segment and accumulator)
         const uint32_t events = (v + (1u << (im.ev_shift - 1))) >> im.ev_shift;
         const long long ev = wave_sum((long long) events);
-        if (lane == 0 && ev != 0) atomicAdd(&s_events[im.ev_chunk_core[(eg.slot0 + i0) >> 6] - eg.core0], (uint32_t) ev);
+        if (lane == 0 && ev != 0) atomicAdd(&s_events[s_chunk_core[i0 >> 6]], (uint32_t) ev);
     }
     __syncthreads();
     if (threadIdx.x < eg.n_cores)

@@ -195,3 +195,27 @@ def test_reset_and_state_carry_on_an_event_chip(S, monkeypatch):
     assert second["spikes"] == a2["spikes"] + b2["spikes"]
     v = chip.potentials()
     assert np.array_equal(v[:400], alone_a.potentials()) and np.array_equal(v[400:], alone_b.potentials())
+
+
+def test_event_chip_under_detailed_timing_with_message_trace(S, monkeypatch):
+    """`detailed` timing on a chip whose steps are delivered by events: the host rebuilds the messages from the per-step
+    status log and schedules them (src/schedule.cpp:208-620) -- nothing of that depends on which kernel delivered the step.
+    Totals, statuses and the message records against the oracle."""
+    monkeypatch.setenv("SANAFE_EVENT", "2")
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.03, seed=53)
+    chip, orc, tot = check_batched(S, arch, net, steps=12, timing="detailed")
+    assert chip.device_layout()["event_layout"] is not None and chip.device_layout()["pushed_steps"] == 12
+    chip2 = S.SpikingChip(arch)
+    chip2.load(net)
+    orc2 = OracleChip(S.to_desc(arch, net))
+    n_msgs = 0
+    for t in range(6):
+        a = chip2.run(1, "detailed", record=True, messages=True)
+        b = orc2.step("detailed")
+        assert a["sim_time"] == b["sim_time"], t  # same serial algorithm on identical inputs: bit-exact
+        ma, mb = chip2.step_messages(0), orc2.messages()
+        assert len(ma) == len(mb), t
+        for name in ma.dtype.names:
+            assert np.array_equal(ma[name], mb[name]), (t, name)
+        n_msgs += len(ma)
+    assert n_msgs > 0
