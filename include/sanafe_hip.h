@@ -301,6 +301,11 @@ int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t 
  * SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_LPB (4 | 8), SANAFE_EVENT_MAX_EVENTS. */
 /* Cores whose soma is part of the message pipeline and that run on the device (sanafe_hip_image::msg_*): their number. */
 int sanafe_hip_get_msg_cores(sanafe_hip_chip *chip);
+/* ... and, for recorded steps with the status log (record bit 1), per message INTO such a core (= inbound axon, in the order
+ * of msg_ax_*) how many of its synaptic events made the soma fire: what the message's processing delay depends on
+ * (process_message, src/chip.cpp:738-789: the soma's latency is by the status its update returned) -- the host's NoC
+ * schedule and message trace need it per step.  out: [count][msg_ax_beg[n_msg_cores]]. */
+int sanafe_hip_read_step_msg_fired(sanafe_hip_chip *chip, int64_t first, int64_t count, uint16_t *out);
 #define SANAFE_HIP_EVENT_INFO_FIELDS 9
 int sanafe_hip_get_event_info(sanafe_hip_chip *chip, uint64_t *info, int n);
 

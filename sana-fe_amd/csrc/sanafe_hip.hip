@@ -130,6 +130,7 @@ struct sanafe_hip_chip
     long long pushed_steps{0};       // steps delivered by the push path / the event kernel since create
     long long ev_pending{-1};        // t_host after the step whose input still lies in DevState::ev_part (-1: none)
     uint32_t *cur_slog{nullptr};     // spike-record row of the step whose neuron launch went out last (msgsoma_kernel patches it)
+    uint16_t *cur_msg_log{nullptr};  // its row of DevState::msg_fired_log (recorded status: detailed timing), or NULL
     long long dbg_waits{0}, dbg_fallbacks{0}; // decide_pushed: decisions that had to wait for the device / gave up (SANAFE_DEBUG_DECIDE)
     double dbg_wait_ms{0.0};
     double ev_avg_block{0.0};        // words per (source neuron, core group) block
@@ -1026,6 +1027,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
     im.n_msg_cores = h.n_msg_cores;
     im.n_msg_chunks = 0;
     c->st.msg_cnt = nullptr;
+    c->st.msg_ax_fired = nullptr;
+    c->st.msg_fired_log = nullptr;
+    im.n_msg_axons = 0;
     if (h.n_msg_cores > 0)
     {
         std::vector<MsgCoreDev> cores(h.n_msg_cores);
@@ -1047,7 +1051,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         }
         for (uint32_t g = 0; g < h.n_slots; g++) ptr[g + 1] += ptr[g];
         const uint32_t n_syn = ptr[h.n_slots];
-        std::vector<uint32_t> pre(std::max<uint32_t>(n_syn, 1u), 0u), cur(ptr.begin(), ptr.end() - 1);
+        std::vector<uint32_t> pre(std::max<uint32_t>(n_syn, 1u), 0u), axn(std::max<uint32_t>(n_syn, 1u), 0u), cur(ptr.begin(), ptr.end() - 1);
         std::vector<double> w(std::max<uint32_t>(n_syn, 1u), 0.0);
         for (uint32_t k = 0; k < h.n_msg_cores; k++)
         {
@@ -1058,6 +1062,7 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
                 {
                     const uint32_t at = cur[h.core_nbase[core] + h.msg_syn_post[q]]++;
                     pre[at] = h.msg_ax_pre[a];
+                    axn[at] = a;
                     w[at] = h.msg_syn_weight[q];
                 }
         }
@@ -1067,6 +1072,9 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         TRYC(upload(c, chunk_slot0.data(), chunk_slot0.size(), &im.msg_chunk_slot0));
         TRYC(upload(c, ptr.data(), ptr.size(), &im.msg_ptr));
         TRYC(upload(c, pre.data(), pre.size(), &im.msg_pre));
+        TRYC(upload(c, axn.data(), axn.size(), &im.msg_ax));
+        im.n_msg_axons = h.msg_ax_beg[h.n_msg_cores];
+        TRYC(dalloc(c, std::max<uint32_t>(im.n_msg_axons, 1u), &c->st.msg_ax_fired));
         TRYC(upload(c, w.data(), w.size(), &im.msg_w));
         TRYC(upload(c, h.msg_ax_pre, h.msg_ax_beg[h.n_msg_cores], &im.msg_ax_pre));
         TRYC(dalloc(c, (size_t) h.n_msg_cores * 4, &c->st.msg_cnt));
@@ -1758,6 +1766,7 @@ extern "C" void sanafe_hip_chip_destroy(sanafe_hip_chip *c)
     if (c->st.step_log) (void) hipFree(c->st.step_log);
     if (c->st.spike_log) (void) hipFree(c->st.spike_log);
     if (c->st.status_log) (void) hipFree(c->st.status_log);
+    if (c->st.msg_fired_log) (void) hipFree(c->st.msg_fired_log);
     if (c->st.delay_log) (void) hipFree(c->st.delay_log);
     for (void *p : {(void *) c->d_log_slots_v, (void *) c->d_log_slots_u, (void *) c->d_state_log})
         if (p) (void) hipFree(p);
@@ -1790,6 +1799,9 @@ static int ensure_log(sanafe_hip_chip *c, long long steps, bool with_status)
     {
         HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.status_log), (size_t) steps * c->im.n_slots));
         HIPCHK(hipMemset(c->st.status_log, 0, (size_t) steps * c->im.n_slots)); // padding slots stay 0
+        if (c->st.msg_fired_log) HIPCHK(hipFree(c->st.msg_fired_log));
+        c->st.msg_fired_log = nullptr;
+        if (c->im.n_msg_axons > 0) HIPCHK(hipMalloc(reinterpret_cast<void **>(&c->st.msg_fired_log), (size_t) steps * c->im.n_msg_axons * sizeof(uint16_t)));
     }
     c->st.log_cap = steps;
     return 0;
@@ -1933,6 +1945,7 @@ static int launch_neurons(sanafe_hip_chip *c, int record, long long rec_index)
     sa.ev_part = (c->im.ev_groups != 0u && c->ev_pending == c->t_host) ? c->st.ev_part : nullptr; // the previous step went by events
     if (record) sa.slog = c->st.spike_log + (size_t) (rec_index % c->st.log_cap) * (c->im.n_slots / 32);
     c->cur_slog = sa.slog;
+    c->cur_msg_log = ((record & 2) && c->st.msg_fired_log) ? c->st.msg_fired_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_msg_axons : nullptr;
     if (record & 2) sa.stlog = c->st.status_log + (size_t) (rec_index % c->st.log_cap) * c->im.n_slots;
     const dim3 grid(c->neuron_grid), block(NEURON_BLOCK);
 #define SANAFE_LAUNCH_NEURON(M, U) \
@@ -1957,7 +1970,9 @@ static int launch_deliver(sanafe_hip_chip *c, uint32_t first, uint32_t count)
     if (c->im.n_msg_cores != 0u && first + count == c->im.n_slices)
     {
         hipLaunchKernelGGL(msgsoma_kernel, dim3(c->im.n_msg_chunks), dim3(WAVE), 0, c->stream, c->im, c->st, c->cur_slog);
-        hipLaunchKernelGGL(msgsoma_finish_kernel, dim3((c->im.n_msg_cores + 63u) / 64u), dim3(64), 0, c->stream, c->im, c->st, (int) (c->t_host & 1));
+        hipLaunchKernelGGL(msgsoma_finish_kernel, dim3(std::max((c->im.n_msg_cores + 255u) / 256u, std::min(64u, (c->im.n_msg_axons + 255u) / 256u))), dim3(256), 0, c->stream, c->im,
+                c->st,
+                (int) (c->t_host & 1), c->cur_msg_log);
         HIPCHK(hipGetLastError());
     }
     return 0;
@@ -2422,6 +2437,13 @@ extern "C" int sanafe_hip_read_step_status(sanafe_hip_chip *c, int64_t first, in
     if (!c || !out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.status_log)
         return fail(SANAFE_HIP_ERR_INVALID, "status records [%lld, %lld) not available", (long long) first, (long long) (first + count));
     return d2h(c, out, c->st.status_log + (size_t) first * c->im.n_slots, (size_t) count * c->im.n_slots);
+}
+
+extern "C" int sanafe_hip_read_step_msg_fired(sanafe_hip_chip *c, int64_t first, int64_t count, uint16_t *out)
+{
+    if (!c || !out || first < 0 || count < 0 || first + count > c->st.log_cap || !c->st.msg_fired_log)
+        return fail(SANAFE_HIP_ERR_INVALID, "per-message fired counts of steps [%lld, %lld) not available", (long long) first, (long long) (first + count));
+    return d2h(c, out, c->st.msg_fired_log + (size_t) first * c->im.n_msg_axons, (size_t) count * c->im.n_msg_axons);
 }
 
 extern "C" int sanafe_hip_read_status(sanafe_hip_chip *c, uint8_t *out)

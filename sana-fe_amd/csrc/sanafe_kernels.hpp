@@ -219,7 +219,9 @@ struct DevImage
     const uint32_t *msg_chunk_slot0;        // [n_msg_chunks] first local slot of the chunk
     const uint32_t *msg_ptr;                // [n_slots + 1] a neuron's inbound synapses in msg_pre / msg_w, delivery order
     const uint32_t *msg_pre;                // GLOBAL slot of the synapse's source neuron
+    const uint32_t *msg_ax;                 // the synapse's axon, numbered over all such cores (sanafe_hip_image::msg_ax_*)
     const double *msg_w;
+    uint32_t n_msg_axons;
     const uint32_t *msg_ax_pre;             // the cores' inbound axons (message counting), core after core
 };
 struct MsgCoreDev
@@ -302,6 +304,9 @@ struct DevState
     long long delay_log_cap;
     // event-driven delivery (DevImage::ev_*): what a step delivered by events leaves for the NEXT step's neuron launch
     uint32_t *msg_cnt;            // [n_msg_cores][4]: synaptic events, soma updates that fired, messages of the step (msgsoma_kernel)
+    uint32_t *msg_ax_fired;       // [n_msg_axons] soma updates that fired, per message (= inbound axon) of the step; cleared by
+                                  // msgsoma_finish_kernel
+    uint16_t *msg_fired_log;      // [log_cap][n_msg_axons] the same per recorded step (record bit 1: status log), or NULL
     uint32_t *ev_part;            // [EV_MAX_SEGMENTS][n_slots]: per segment of the source space and neuron, count * 2^ev_shift + sum
                                   // of the weights that arrived (0: nothing); every workgroup stores all of its accumulators
 };
@@ -2241,7 +2246,11 @@ __global__ void __launch_bounds__(WAVE) msgsoma_kernel(DevImage im, DevState st,
             else if (p.reverse_reset_mode == SANAFE_RESET_SATURATE) v = p.reverse_threshold;
         }
         n_events++;
-        n_fired += status == 3 ? 1u : 0u;
+        if (status == 3)
+        {
+            n_fired++;
+            atomicAdd(&st.msg_ax_fired[im.msg_ax[i]], 1u); // (what the message's processing delay depends on: detailed timing)
+        }
     }
     int final_status = 0;
     if (live)
@@ -2282,9 +2291,15 @@ __global__ void __launch_bounds__(WAVE) msgsoma_kernel(DevImage im, DevState st,
 // One thread per such core, after msgsoma_kernel: the step's counts priced with the core's default costs
 // (src/pipeline.hpp:511-731) into the partial of the core's first neuron workgroup -- unit energies by role, soma-activity
 // counters -- and the core's message-processing delay (axon-in latency per message + the units' latencies per event).
-__global__ void msgsoma_finish_kernel(DevImage im, DevState st, int parity)
+__global__ void msgsoma_finish_kernel(DevImage im, DevState st, int parity, uint16_t *fired_log_row /* or NULL */)
 {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    // per message: how many of its synaptic events made the soma fire -> the step's row of the log (recorded runs), cleared
+    for (uint32_t a = k; a < im.n_msg_axons; a += gridDim.x * blockDim.x)
+    {
+        if (fired_log_row != nullptr) fired_log_row[a] = (uint16_t) min(st.msg_ax_fired[a], 65535u);
+        st.msg_ax_fired[a] = 0u;
+    }
     if (k >= im.n_msg_cores) return;
     const MsgCoreDev mcd = im.msg_core_dev[k];
     const sanafe_hip_msg_core_costs &c = mcd.costs;

@@ -349,6 +349,7 @@ struct sanafe_chip
     std::vector<double> rec_state; // [recorded steps][log_v_gids + log_u_gids]
     // host copies of the per-slot cost classes (for generation delays)
     std::vector<double> slot_lat[3];
+    std::vector<uint32_t> msg_ax_core; // per inbound axon of the message-pipeline cores on the device (msg_ax_*): index of its core
 
     // ---- cores that run on the host: soma inside the message pipeline, plugin synapse / dendrite units (host/host_cores.hpp) ----
     std::unique_ptr<sanafe_amd::HostCores> hcores;
@@ -489,7 +490,7 @@ struct sanafe_chip
     // ------------------------------------------------------------------------------
     template <typename M>
     void build_messages(int64_t timestep, const std::vector<uint8_t> &status, std::vector<std::vector<M>> &per_core,
-            int64_t mid_base) const
+            int64_t mid_base, const uint16_t *msg_fired = nullptr) const
     {
         constexpr bool FULL = std::is_same<M, Msg>::value; // the traced record carries every field of `Message`
         int64_t next_mid = mid_base;
@@ -522,6 +523,7 @@ struct sanafe_chip
                     M m{};
                     const uint32_t dc = mc.ax_dest_core[a];
                     const uint32_t dt = mc.core_tile[dc];
+                    const bool into_msg_core = a >= mc.n_device_axons; // a core whose soma is part of the message pipeline
                     if constexpr (FULL)
                     {
                         m.timestep = timestep;
@@ -531,7 +533,7 @@ struct sanafe_chip
                         m.dest_tile = dt;
                         m.dest_core_offset = mc.core_offset[dc];
                         m.dest_axon_id = mc.ax_dest_axon_id[a];
-                        m.spikes = mc.ax_nsyn[a];
+                        m.spikes = into_msg_core ? mc.msg_ax_nsyn[a - mc.n_device_axons] : mc.ax_nsyn[a];
                     }
                     m.src_core_id = c;
                     m.src_core_offset = mc.core_offset[c];
@@ -544,7 +546,23 @@ struct sanafe_chip
                     m.placeholder = 0;
                     m.generation_delay = next_delay + lat_access;
                     next_delay = 0.0;
-                    m.processing_delay = mc.ax_proc_delay[a];
+                    if (!into_msg_core) m.processing_delay = mc.ax_proc_delay[a];
+                    else
+                    {
+                        // process_message, src/chip.cpp:738-789: the axon-in latency, then per synaptic event the synapse's, the
+                        // dendrite's and the soma's latency BY THE STATUS ITS UPDATE RETURNED -- the device counted, per message,
+                        // the updates that fired (msgsoma_kernel)
+                        const uint64_t i = a - mc.n_device_axons;
+                        const sanafe_hip_msg_core_costs &k = mc.msg_costs[msg_ax_core[i]];
+                        if (msg_fired == nullptr) throw std::logic_error("messages into a message-pipeline core need the step's fired counts");
+                        const uint32_t n_ev = mc.msg_ax_nsyn[i], n_fired = std::min<uint32_t>(msg_fired[i], n_ev);
+                        const double updated = (0.0 + k.synapse_latency + k.dendrite_latency) + (k.soma_latency[0] + k.soma_latency[1]);
+                        const double fired = (0.0 + k.synapse_latency + k.dendrite_latency) + ((k.soma_latency[0] + k.soma_latency[1]) + k.soma_latency[2]);
+                        double lat = k.axon_in_latency;
+                        for (uint32_t q = 0; q < n_ev - n_fired; q++) lat += updated;
+                        for (uint32_t q = 0; q < n_fired; q++) lat += fired;
+                        m.processing_delay = 0.0 + lat;
+                    }
                     m.min_hop_delay = mc.ax_min_hop_delay[a];
                     m.sent_timestamp = m.received_timestamp = m.processed_timestamp = NEG_INF;
                     per_core[c].push_back(m);
@@ -953,6 +971,8 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
             for (int k = 0; k < 3; k++) chip->slot_lat[k][s] = (0.0 + cc.dendrite_latency) + cc.soma_latency[k];
         }
     }
+    if (chip->mc.msg_on_device)
+        for (size_t k = 0; k + 1 < mc.msg_ax_beg.size(); k++) chip->msg_ax_core.insert(chip->msg_ax_core.end(), mc.msg_ax_beg[k + 1] - mc.msg_ax_beg[k], static_cast<uint32_t>(k));
     if (!chip->mc.host_cores.empty() && !chip->mc.msg_on_device) // (msg_on_device: these cores run on the device, msgsoma_kernel)
     {
         try
@@ -1387,10 +1407,13 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
-    if (chip->mc.msg_on_device && (timing_model != SANAFE_TIMING_SIMPLE || want_messages || ((record & SANAFE_RECORD_STEPS) && chip->mc.log.any)))
+    if (chip->mc.msg_on_device && (record & SANAFE_RECORD_STEPS) && chip->mc.log.any)
         return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: cores whose soma is part of the message pipeline (buffer inside the soma unit / "
-                                                "before axon_out) are simulated under the simple timing model, without message traces or "
-                                                "optional perf columns: their message costs depend on the statuses the soma returns at run time");
+                                                "before axon_out) are simulated without optional perf columns: their per-unit costs depend on the "
+                                                "statuses the soma returns at run time");
+    if (chip->mc.msg_on_device && (timing_model != SANAFE_TIMING_SIMPLE || want_messages) && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces of a chip with cores whose soma is part of "
+                                                "the message pipeline need a single-rank chip");
     const bool want_state = (record & SANAFE_RECORD_STATE) != 0;
     if (want_state && chip->log_v_gids.empty() && chip->log_u_gids.empty())
         return fail(SANAFE_HIP_ERR_INVALID, "SANAFE_RECORD_STATE needs the neurons to log (sanafe_chip_set_state_log)");
@@ -1480,6 +1503,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             int64_t mid_base{0};
             std::vector<uint8_t> status;
             std::vector<uint32_t> bits;
+            std::vector<uint16_t> msg_fired; // chips with message-pipeline cores on the device: fired updates per message into them
             std::vector<Msg> flat;
             std::string error;
         };
@@ -1494,14 +1518,14 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 if (want_messages) // the traced record of every message, in scheduling order
                 {
                     thread_local sanafe_chip::SchedScratch<Msg> scratch;
-                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base, job.msg_fired.empty() ? nullptr : job.msg_fired.data());
                     job.ts.sim_time = H->schedule_detailed(scratch.per_core, true, scratch);
                     for (auto &q : scratch.per_core) job.flat.insert(job.flat.end(), q.begin(), q.end());
                 }
                 else // only sim_time is wanted: the compact message, queues and NoC state reused by this thread
                 {
                     thread_local sanafe_chip::SchedScratch<SchedMsg> scratch;
-                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base);
+                    H->build_messages(job.ts.timesteps, job.status, scratch.per_core, job.mid_base, job.msg_fired.empty() ? nullptr : job.msg_fired.data());
                     job.ts.sim_time = H->schedule_detailed(scratch.per_core, false, scratch);
                 }
             }
@@ -1547,7 +1571,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             }
         } guard{pool, qmutex, qcv, done_submitting};
         // one finished timestep: totals + the status of every slot -> records, or a job for the scheduler threads
-        auto process_step = [&](sanafe_hip_totals ts, const uint8_t *st_bytes) -> int {
+        // (final_bits / msg_fired: chips with message-pipeline cores on the device -- the spike record of the END of the step, which
+        // the message pipeline's soma calls latch too, and the fired updates per message into such a core)
+        const size_t n_msg_ax = chip->mc.msg_on_device ? chip->mc.msg_ax_pre.size() : 0;
+        auto process_step = [&](sanafe_hip_totals ts, const uint8_t *st_bytes, const uint32_t *final_bits = nullptr, const uint16_t *msg_fired = nullptr) -> int {
             chip->total_timesteps += 1;
             ts.timesteps = chip->total_timesteps;
             const int64_t mid_base = chip->total_messages_sent;
@@ -1556,8 +1583,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             if (record)
             {
                 bits.assign(hmc.n_slots / 32, 0);
-                for (uint32_t k = 0; k < hmc.n_slots; k++)
-                    if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
+                if (final_bits != nullptr) bits.assign(final_bits, final_bits + hmc.n_slots / 32);
+                else
+                    for (uint32_t k = 0; k < hmc.n_slots; k++)
+                        if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
                 if (hmc.log.any) chip->rec_optional.push_back(H->optional_columns(st_bytes));
             }
             if (!detailed)
@@ -1573,7 +1602,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                         // cores' FIFOs; no blocking is modelled and the network delay is the minimum hop delay
                         std::vector<uint8_t> st_copy(st_bytes, st_bytes + hmc.n_slots);
                         std::vector<std::vector<Msg>> per_core;
-                        H->build_messages(ts.timesteps, st_copy, per_core, mid_base);
+                        H->build_messages(ts.timesteps, st_copy, per_core, mid_base, msg_fired);
                         std::vector<Msg> &flat = chip->rec_messages.back();
                         for (auto &q : per_core)
                             for (Msg &m : q)
@@ -1595,6 +1624,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             job.ts = ts;
             job.mid_base = mid_base;
             job.status.assign(st_bytes, st_bytes + hmc.n_slots);
+            if (msg_fired != nullptr) job.msg_fired.assign(msg_fired, msg_fired + n_msg_ax);
             job.bits = std::move(bits);
             if (pool.empty())
             {
@@ -1678,6 +1708,8 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
             const int64_t k_cap = std::max<int64_t>(1, std::min<int64_t>(64, (int64_t{64} << 20) / std::max<uint32_t>(1, mc.n_slots)));
             std::vector<sanafe_hip_totals> tsv;
             std::vector<uint8_t> stv;
+            std::vector<uint32_t> rowv;
+            std::vector<uint16_t> firedv;
             for (int64_t s = 0; s < timesteps;)
             {
                 const int64_t k_steps = std::min(k_cap, timesteps - s);
@@ -1693,8 +1725,18 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 stv.resize(static_cast<size_t>(k_steps) * mc.n_slots);
                 DEV(sanafe_hip_read_step_totals(chip->dev, 0, k_steps, tsv.data()));
                 DEV(sanafe_hip_read_step_status(chip->dev, 0, k_steps, stv.data()));
+                if (n_msg_ax != 0)
+                {
+                    rowv.resize(static_cast<size_t>(k_steps) * (mc.n_slots / 32));
+                    firedv.resize(static_cast<size_t>(k_steps) * n_msg_ax);
+                    DEV(sanafe_hip_read_step_spike_rows(chip->dev, 0, k_steps, rowv.data()));
+                    DEV(sanafe_hip_read_step_msg_fired(chip->dev, 0, k_steps, firedv.data()));
+                }
                 for (int64_t k = 0; k < k_steps; k++)
-                    if (int rc = process_step(tsv[k], stv.data() + static_cast<size_t>(k) * mc.n_slots)) return rc;
+                    if (int rc = process_step(tsv[k], stv.data() + static_cast<size_t>(k) * mc.n_slots,
+                                n_msg_ax ? rowv.data() + static_cast<size_t>(k) * (mc.n_slots / 32) : nullptr,
+                                n_msg_ax ? firedv.data() + static_cast<size_t>(k) * n_msg_ax : nullptr))
+                        return rc;
                 s += k_steps;
             }
         }

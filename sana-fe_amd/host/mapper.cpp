@@ -1524,6 +1524,13 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     std::vector<uint64_t> core_axon_beg(LC + 1, 0);
     std::vector<uint32_t> dest_axon_count(d.n_cores, 0);
     std::vector<uint64_t> out_count(static_cast<size_t>(mc.n_global_slots) + 1, 0);
+    struct MsgAxonOut
+    {
+        uint32_t pre, dc, axon_id, hops;
+        double min_hop;
+        uint32_t host_core, idx_in_core;
+    };
+    std::vector<MsgAxonOut> mx; // inbound axons of the cores whose soma is part of the message pipeline (msg_on_device)
     const bool keep_out_tables = (n_ranks == 1);
     {
         size_t n_local_axons = 0;
@@ -1566,6 +1573,9 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 ha.pre = pre;
                 ha.syn_beg = static_cast<uint32_t>(hc.synapses.size());
                 ha.n_syn = nsyn;
+                if (mc.msg_on_device && keep_out_tables) // the host still rebuilds the messages INTO such a core (detailed timing)
+                    mx.push_back(MsgAxonOut{pre, dc, axon_id, B.hops[a], B.min_hop[a], static_cast<uint32_t>(host_core_index[dc]),
+                            static_cast<uint32_t>(hc.axons.size())});
                 hc.axons.push_back(ha);
                 for (int64_t k = B.first[a]; k < B.first[a] + nsyn; k++)
                 {
@@ -1730,9 +1740,45 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     {
         mc.out_ptr.assign(out_count.begin(), out_count.end());
         for (size_t s = 0; s < mc.n_global_slots; s++) mc.out_ptr[s + 1] += mc.out_ptr[s];
+        mc.n_device_axons = mc.ax_pre.size();
+        if (mx.empty())
+        {
         mc.out_axon.resize(mc.ax_pre.size());
         std::vector<uint64_t> cur(mc.out_ptr.begin(), mc.out_ptr.end() - 1);
         for (uint64_t a = 0; a < mc.ax_pre.size(); a++) mc.out_axon[cur[mc.ax_pre[a]]++] = a; // ascending destination core
+        }
+        else
+        {
+            // chips with msg cores (small ones): the device's axons and the msg cores' in one list per source neuron, ascending
+            // destination core (a neuron has one axon per destination core)
+            const uint64_t A = mc.ax_pre.size();
+            std::vector<uint32_t> msg_base(mc.host_cores.size() + 1, 0);
+            for (size_t k = 0; k < mc.host_cores.size(); k++) msg_base[k + 1] = msg_base[k] + static_cast<uint32_t>(mc.host_cores[k].axons.size());
+            std::vector<uint32_t> all_pre(mc.ax_pre.begin(), mc.ax_pre.end());
+            mc.ax_dest_core.resize(A + mx.size());
+            mc.ax_dest_axon_id.resize(A + mx.size());
+            mc.ax_hops.resize(A + mx.size());
+            mc.ax_min_hop_delay.resize(A + mx.size());
+            all_pre.resize(A + mx.size());
+            for (const MsgAxonOut &m : mx)
+            {
+                const uint64_t id = A + msg_base[m.host_core] + m.idx_in_core;
+                mc.ax_dest_core[id] = m.dc;
+                mc.ax_dest_axon_id[id] = m.axon_id;
+                mc.ax_hops[id] = m.hops;
+                mc.ax_min_hop_delay[id] = m.min_hop;
+                all_pre[id] = m.pre;
+                out_count[m.pre + 1]++;
+            }
+            mc.out_ptr.assign(out_count.begin(), out_count.end());
+            for (size_t s = 0; s < mc.n_global_slots; s++) mc.out_ptr[s + 1] += mc.out_ptr[s];
+            std::vector<uint64_t> ids(A + mx.size());
+            std::iota(ids.begin(), ids.end(), 0ull);
+            std::stable_sort(ids.begin(), ids.end(), [&](uint64_t x, uint64_t y) {
+                return all_pre[x] != all_pre[y] ? all_pre[x] < all_pre[y] : mc.ax_dest_core[x] < mc.ax_dest_core[y];
+            });
+            mc.out_axon = ids;
+        }
     }
 }
 } // namespace sanafe_amd

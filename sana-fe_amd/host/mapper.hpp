@@ -208,6 +208,10 @@ struct MappedChip
     // their tables to the image and no host replay object is created.  All such cores of a chip or none (SANAFE_HOST_CORES=1
     // keeps them on the host).
     bool msg_on_device{false};
+    // ... their inbound axons for the HOST's message reconstruction (detailed timing, message trace): axon ids from
+    // ax_pre.size() on in ax_dest_core / ax_dest_axon_id / ax_hops / ax_min_hop_delay and in out_axon (a source neuron's
+    // axons stay in ascending destination-core order); id - ax_pre.size() indexes msg_ax_* and the per-step fired counts
+    uint64_t n_device_axons{0};
     std::vector<uint32_t> msg_core, msg_ax_beg, msg_ax_pre, msg_ax_nsyn, msg_syn_beg, msg_syn_post;
     std::vector<double> msg_syn_weight;
     std::vector<sanafe_hip_msg_core_costs> msg_costs;

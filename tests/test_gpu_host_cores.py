@@ -112,7 +112,8 @@ def test_taps_dendrites_beyond_the_device_kernels(S, variant):
     assert _compare(chip, orc, 45) > 100
 
 
-def test_host_cores_need_simple_timing_and_one_rank(S):
+def test_host_cores_need_simple_timing_and_one_rank(S, monkeypatch):
+    monkeypatch.setenv("SANAFE_HOST_CORES", "1")  # (the host replay; on the device such cores take detailed timing, below)
     arch, net = nets.host_cores(S, position="axon_out")
     chip = S.SpikingChip(arch)
     chip.load(net)
@@ -149,3 +150,46 @@ def test_message_pipeline_somas_in_one_batched_run(S, position):
     for ka, kb in INT_KEYS:
         assert tot[ka] == acc[kb]
     assert np.array_equal(chip.potentials(), orc.potentials()) and np.array_equal(chip.status(), orc.status())
+
+
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_message_pipeline_somas_under_detailed_timing(S, position):
+    """Detailed timing and the message trace of a chip whose message-pipeline somas run on the device: a message INTO such a
+    core costs the axon-in latency plus, per synaptic event, the synapse's, the dendrite's and the soma's latency by the
+    status that update returned (process_message, src/chip.cpp:738-789) -- msgsoma_kernel counts the updates that fired per
+    message and step, the host rebuilds the messages from the neuron loop's statuses and schedules them
+    (src/schedule.cpp:234-281).  Every field of every message and sim_time against the oracle; the processing delay is a sum
+    the host orders by status rather than by synapse, hence the 1e-12."""
+    arch, net = nets.host_cores(S, position=position, seed=5)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    assert chip.device_layout()["msg_cores_on_device"] == 2
+    orc = OracleChip(S.to_desc(arch, net))
+    into_msg_cores = fired_updates = 0
+    for t in range(30):
+        a = chip.run(1, "detailed", record=True, messages=True)
+        b = orc.step("detailed")
+        for ka, kb in INT_KEYS:
+            assert a[ka] == b[kb], (t, ka, a[ka], b[kb])
+        for k in DBL_KEYS:
+            assert a[k] == pytest.approx(b[k], rel=1e-9, abs=1e-30), (t, k, a[k], b[k])
+        ma, mb = chip.step_messages(0), orc.messages()
+        assert len(ma) == len(mb), t
+        for name in ma.dtype.names:
+            if ma[name].dtype.kind == "f":
+                fin = np.isfinite(mb[name])
+                assert np.array_equal(np.isfinite(ma[name]), fin), (t, name)
+                assert np.allclose(ma[name][fin], mb[name][fin], rtol=1e-12, atol=0.0), (t, name)
+            else:
+                assert np.array_equal(ma[name], mb[name]), (t, name)
+        live = ma[ma["placeholder"] == 0]
+        into = np.isin(live["dest_core_id"], [2, 4])
+        into_msg_cores += int(into.sum())
+        assert np.array_equal(chip.step_fired(0), (orc.status() == 3).astype(np.uint8)), t
+    assert into_msg_cores > 50
+    # the batched run (several steps per device call, scheduler threads) gives the same simulated time
+    chip.reset()
+    orc.reset()
+    tot = chip.run(20, "detailed")
+    ref = sum(orc.step("detailed")["sim_time"] for _ in range(20))
+    assert tot["sim_time"] == pytest.approx(ref, rel=1e-9)
