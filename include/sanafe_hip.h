@@ -297,8 +297,9 @@ int sanafe_hip_get_push_info(sanafe_hip_chip *chip, uint32_t *enabled, uint32_t 
  *   info[0] core groups (0: the chip has no event layout)   [1] segments of the source space (grid = groups x segments)
  *   [2] 16-byte units of all blocks   [3] words per (neuron, group) block x 1000   [4] lanes per block   [5] weight-code bits
  *   [6] accumulator shift   [7] 1: every step goes by events (SANAFE_EVENT=2)   [8] event threshold of the decision
+ *   [9] events per step up to which the neuron-major block table is used (the group-major one above)   [10] steps that used it
  * SANAFE_EVENT=0 off / 1 build whatever the block length / 2 build and always use; SANAFE_EVENT_SEGMENTS,
- * SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_LPB (4 | 8), SANAFE_EVENT_MAX_EVENTS. */
+ * SANAFE_EVENT_GROUP_CORES, SANAFE_EVENT_LPB (4 | 8), SANAFE_EVENT_MAX_EVENTS, SANAFE_EVENT_SPARSE_EVENTS. */
 /* Cores whose soma is part of the message pipeline and that run on the device (sanafe_hip_image::msg_*): their number. */
 int sanafe_hip_get_msg_cores(sanafe_hip_chip *chip);
 /* ... and, for recorded steps with the status log (record bit 1), per message INTO such a core (= inbound axon, in the order
@@ -306,7 +307,7 @@ int sanafe_hip_get_msg_cores(sanafe_hip_chip *chip);
  * (process_message, src/chip.cpp:738-789: the soma's latency is by the status its update returned) -- the host's NoC
  * schedule and message trace need it per step.  out: [count][msg_ax_beg[n_msg_cores]]. */
 int sanafe_hip_read_step_msg_fired(sanafe_hip_chip *chip, int64_t first, int64_t count, uint16_t *out);
-#define SANAFE_HIP_EVENT_INFO_FIELDS 9
+#define SANAFE_HIP_EVENT_INFO_FIELDS 11
 int sanafe_hip_get_event_info(sanafe_hip_chip *chip, uint64_t *info, int n);
 
 /* Bytes of the device layout, for roofline bookkeeping (bench.py): what the design itself has to move.

@@ -406,12 +406,12 @@ class SpikingChip(_Base):
         H.sanafe_hip_get_push_info(self.device_handle(), C.byref(en), C.byref(pushed))
         H.sanafe_hip_get_bitmap_slices.argtypes = [C.c_void_p]
         H.sanafe_hip_get_sub_accumulators.argtypes = [C.c_void_p]
-        ev = (C.c_uint64 * 9)()
+        ev = (C.c_uint64 * 11)()
         H.sanafe_hip_get_event_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        H.sanafe_hip_get_event_info(self.device_handle(), ev, 9)
+        H.sanafe_hip_get_event_info(self.device_handle(), ev, 11)
         event = {"groups": int(ev[0]), "segments": int(ev[1]), "units": int(ev[2]), "words_per_block": ev[3] / 1000.0,
                  "lanes_per_block": int(ev[4]), "code_bits": int(ev[5]), "shift": int(ev[6]), "always": bool(ev[7]),
-                 "max_events": int(ev[8])} if ev[0] else None
+                 "max_events": int(ev[8]), "sparse_max_events": int(ev[9]), "sparse_steps": int(ev[10])} if ev[0] else None
         return {"syn_format": fmt.value, "n_compact_slices": n.value, "acc_shift": int(H.sanafe_hip_get_acc_shift(self.device_handle())),
                 "event_layout": event, "msg_cores_on_device": int(self._msg_cores(H)),
                 "push_enabled": bool(en.value), "push_only": en.value == 2, "pushed_steps": int(pushed.value),

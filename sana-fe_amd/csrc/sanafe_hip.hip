@@ -127,6 +127,9 @@ struct sanafe_hip_chip
     long long *h_events{nullptr};    // pinned ring DevState::host_events points at
     long long epoch_first_step{1};   // Timestep::timestep of the first step whose events this chip's ring can hold
     int cur_pushed{0};               // mode of the step whose neuron launch went out last
+    int cur_sparse{0};               // ... delivered by events: with the neuron-major table (few neurons fire)
+    uint64_t ev_sparse_max_events{0}; // synaptic events per step up to which the neuron-major table is the faster one
+    long long sparse_steps{0};
     long long pushed_steps{0};       // steps delivered by the push path / the event kernel since create
     long long ev_pending{-1};        // t_host after the step whose input still lies in DevState::ev_part (-1: none)
     uint32_t *cur_slog{nullptr};     // spike-record row of the step whose neuron launch went out last (msgsoma_kernel patches it)
@@ -581,9 +584,15 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     // need a fired neuron's blocks read one contiguous 5 KB region at about the same time: each 128-byte line comes out of
     // HBM once and is served to the other XCDs by the Infinity Cache; with the blocks of a GROUP together -- tried -- every
     // line is private to one workgroup and the launch is HBM-bound on half-used lines: 97 instead of 71 us at 10 % activity).
-    // The TABLE is group-major -- meta[g][n] = first 16-byte unit of block (n, g) | units << 32 | core mask << 48, one
-    // self-contained 8-byte entry per lookup -- so that a workgroup, which walks the fired neurons of its segment in ascending
-    // order, reads its group's entries front to back: at the headline's activity a 128-byte line serves ~5 lookups.
+    // The TABLE -- meta = first 16-byte unit of block (n, g) | units << 32 | core mask << 48, one self-contained 8-byte entry
+    // per lookup -- exists twice.  Group-major [g][n]: a workgroup, which walks the fired neurons of its segment in ascending
+    // order, reads its group's entries front to back; at the headline's activity a 128-byte line serves ~5 lookups and a
+    // wavefront's 16 lookups touch 3-4 lines.  Neuron-major [n][g]: the ~9 workgroups of an XCD that take neighbouring groups
+    // of the same segment share one or two lines per fired neuron, where the group-major table costs each of them a line of
+    // its own for one 8-byte entry -- the better table while few neurons fire (measured on C3: +11 % timesteps/s at 2 %
+    // activity, +7 % at 10 %, -9 % at 34 %: every lookup of a wavefront is a line of its own).  The host picks per step
+    // (decide_pushed: ev_sparse_max_events).
+    const uint64_t msn = 1u, msg = N; // strides of the (group-major) table by neuron and group
     std::vector<uint64_t> meta((uint64_t) NG * N + 1u, 0ull);
     std::vector<uint64_t> neuron_units(N + 1, 0ull);
     parallel_for(N, [&](uint64_t lo, uint64_t hi) {
@@ -605,7 +614,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
             {
                 const uint64_t units = (cnt[n * NG + g] + 7u) / 8u;
                 if (units > 0xffffu) bad = true;
-                meta[(uint64_t) g * N + n] = off | (units << 32) | ((uint64_t) mask[n * NG + g] << 48);
+                meta[g * msg + n * msn] = off | (units << 32) | ((uint64_t) mask[n * NG + g] << 48);
                 off += units;
             }
         }
@@ -634,7 +643,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
                     const uint64_t n = h.ax_pre[a];
                     const uint64_t src = h.core_syn_base[core] + h.ax_syn_beg[a];
                     const size_t sg = (size_t) std::min<uint32_t>((uint32_t) (n / EV_TILE) / seg_tiles, segments - 1u) * acc_max;
-                    uint64_t at = (meta[g * N + n] & 0xffffffffull) * 8u + cnt[n * NG + g];
+                    uint64_t at = (meta[g * msg + n * msn] & 0xffffffffull) * 8u + cnt[n * NG + g];
                     for (uint32_t k = 0; k < h.ax_nsyn[a]; k++)
                     {
                         const uint32_t idx = acc0 + (h.syn_meta[src + k] & 0xffffu);
@@ -649,7 +658,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
             // padding words of every block: code 0 into the trash entries behind the group's accumulators
             for (uint64_t n = 0; n < N; n++)
             {
-                const uint64_t b0 = (meta[g * N + n] & 0xffffffffull) * 8u, b1 = b0 + ((meta[g * N + n] >> 32) & 0xffffull) * 8u;
+                const uint64_t b0 = (meta[g * msg + n * msn] & 0xffffffffull) * 8u, b1 = b0 + ((meta[g * msg + n * msn] >> 32) & 0xffffull) * 8u;
                 for (uint64_t p = b0 + cnt[n * NG + g]; p < b1; p++) words[p] = (uint16_t) ((groups[g].n_acc + (uint32_t) (p & (EV_TRASH - 1u))) << code_bits);
             }
         }
@@ -667,6 +676,17 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     lut.resize(32, 0.0);
     TRY(upload(c, groups.data(), groups.size(), &im.ev_group));
     TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta.data()), meta.size(), &im.ev_meta));
+    {
+        std::vector<uint64_t> meta_n(meta.size(), 0ull);
+        parallel_for(N, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t n = lo; n < hi; n++)
+                for (uint32_t g = 0; g < NG; g++) meta_n[n * NG + g] = meta[(uint64_t) g * N + n];
+        });
+        TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta_n.data()), meta_n.size(), &im.ev_meta_n));
+    }
+    // (between 10 % and 34 % activity on C3, see above)
+    c->ev_sparse_max_events = (uint64_t) ((double) h.n_synapses * 0.2);
+    if (const char *env = std::getenv("SANAFE_EVENT_SPARSE_EVENTS")) c->ev_sparse_max_events = (uint64_t) std::max(0LL, std::atoll(env));
     TRY(upload(c, words.data(), words.size(), &im.ev_words));
     TRY(upload(c, chunk_core.data(), chunk_core.size(), &im.ev_chunk_core));
     TRY(upload(c, lut.data(), lut.size(), &im.ev_lut));
@@ -692,7 +712,7 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     c->ev_waves = 16;
     if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 8 ? 8 : std::atoi(env) == 4 ? 4 : 16;
     c->layout_bytes[9] = total_units * 16ull;
-    c->layout_bytes[10] = meta.size() * 8ull;
+    c->layout_bytes[10] = meta.size() * 8ull; // (one of the two tables: a step reads one)
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
     // 8 unit slots per block and batch from ~32 words per block on (4 lanes x 2 units: 16 neurons per batch), else 4
     c->ev_lpb = 4;
@@ -1881,7 +1901,12 @@ extern "C" int sanafe_hip_read_step_state(sanafe_hip_chip *c, int64_t first, int
 static int decide_pushed(sanafe_hip_chip *c, long long t)
 {
     if (c->im.push_cap == 0u) return 0;
-    if (c->im.push_always != 0u) return 1;
+    if (c->im.push_always != 0u)
+    {
+        c->cur_sparse = c->ev_sparse_max_events != 0u ? 1 : 0; // (forced modes know no event counts: the table by the environment)
+        return 1;
+    }
+    c->cur_sparse = 0;
     const long long n = (t - DECISION_LAG) / DECISION_STRIDE * DECISION_STRIDE; // the last step at or before t - LAG that published
     if (n < c->epoch_first_step || c->h_events == nullptr) return 0; // no history yet: pull
     volatile long long *e = c->h_events + 2 * (n % HOST_EVENT_RING);
@@ -1895,7 +1920,9 @@ static int decide_pushed(sanafe_hip_chip *c, long long t)
                 c->dbg_waits++;
                 c->dbg_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             }
-            return __atomic_load_n(&e[0], __ATOMIC_RELAXED) <= (long long) c->im.push_max_events ? 1 : 0;
+            const long long events = __atomic_load_n(&e[0], __ATOMIC_RELAXED);
+            c->cur_sparse = events <= (long long) c->ev_sparse_max_events ? 1 : 0;
+            return events <= (long long) c->im.push_max_events ? 1 : 0;
         }
         if ((spins & 0x3fffu) == 0x3fffu)
         {
@@ -1987,7 +2014,9 @@ static int launch_deliver_slices(sanafe_hip_chip *c, uint32_t first, uint32_t co
         if (first + count == c->im.n_slices)
         {
             long long done = c->t_host;
-            void *args[] = {&c->im, &c->st, &done};
+            int sparse = c->cur_sparse;
+            c->sparse_steps += sparse;
+            void *args[] = {&c->im, &c->st, &done, &sparse};
             HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(64u * (uint32_t) c->ev_waves), args, 0, c->stream));
             c->ev_pending = c->t_host + 1;
         }
@@ -2189,6 +2218,8 @@ extern "C" int sanafe_hip_get_event_info(sanafe_hip_chip *c, uint64_t *info, int
     info[6] = c->im.ev_groups ? (uint64_t) c->im.ev_shift : 0;
     info[7] = c->im.ev_groups ? c->im.ev_always : 0;
     info[8] = c->im.ev_groups ? c->im.push_max_events : 0;
+    info[9] = c->im.ev_groups ? c->ev_sparse_max_events : 0;
+    info[10] = (uint64_t) c->sparse_steps;
     return 0;
 }
 extern "C" int sanafe_hip_get_layout(sanafe_hip_chip *c, int *syn_format, uint32_t *n_compact_slices)

@@ -203,6 +203,7 @@ struct DevImage
     uint32_t ev_always;           // 1: every step is delivered by events, the streaming kernel is never launched (tests)
     int ev_shift;                 // every event adds weight + 2^ev_shift; bounds proven per (segment, accumulator)
     const struct EvGroup *ev_group;   // [ev_groups]
+    const unsigned long long *ev_meta_n; // the same entries [n_global_slots][ev_groups] (steps in which few neurons fire)
     const unsigned long long *ev_meta; // [ev_groups][n_global_slots]: bits 0-31 first 16-byte unit of block (neuron, group),
                                   // bits 32-47 its length in units, bits 48-63 which cores of the group the neuron reaches
                                   // (one message each).  Group-major: a workgroup reads its group's entries front to back.
@@ -1990,7 +1991,7 @@ __device__ __forceinline__ uint4 ev_load16(const uint4 *p)
 }
 template <int LPB, int CODE_BITS, int WAVES, int UPL = 1>
 __global__ void __launch_bounds__(WAVES * WAVE)
-event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
+event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, int sparse /* neuron-major table */)
 {
     constexpr uint32_t ACC_MAX = 1u << (16 - CODE_BITS);
     constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
@@ -2017,7 +2018,9 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     if (threadIdx.x < eg.n_acc / WAVE) s_chunk_core[threadIdx.x] = (uint8_t) (im.ev_chunk_core[(eg.slot0 >> 6) + threadIdx.x] - eg.core0);
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
-    const unsigned long long *mgroup = im.ev_meta + (size_t) g * im.n_global_slots; // this group's table entries
+    // this group's table entries: every msn-th (the host picks the table by the step's activity)
+    const unsigned long long *mgroup = sparse ? im.ev_meta_n + g : im.ev_meta + (size_t) g * im.n_global_slots;
+    const uint32_t msn = sparse ? im.ev_groups : 1u;
     uint16_t *list = s_list[wave];
     const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
     uint32_t msg_cnt[(16 + LPB - 1) / LPB];        // messages to core q, q + LPB, ... of the group, over this lane's neurons
@@ -2058,7 +2061,7 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
         auto fetch_meta = [&](uint32_t b, Meta &m) {
             m.have = b + j < len;
             const uint32_t f = list_slot0 + (uint32_t) list[m.have ? b + j : b];
-            m.m0 = mgroup[f];
+            m.m0 = mgroup[(size_t) f * msn];
         };
         auto fetch_words = [&](const Meta &m, Words &w) {
             w.units = m.have ? (uint32_t) (m.m0 >> 32) & 0xffffu : 0u;

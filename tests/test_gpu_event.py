@@ -19,12 +19,17 @@ from test_gpu_parity import DBL_KEYS, INT_KEYS, check_batched, check_stepwise  #
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("p_fire,segments,group_cores,lpb", [(0.02, "1", "16", "4"), (0.02, "3", "3", "8"), (0.5, "2", "5", "4")])
-def test_every_step_by_events_matches_the_oracle(S, monkeypatch, p_fire, segments, group_cores, lpb):
+@pytest.mark.parametrize("p_fire,segments,group_cores,lpb,table", [(0.02, "1", "16", "4", "n"), (0.02, "3", "3", "8", "g"), (0.5, "2", "5", "4", "g"),
+                                                                  (0.5, "2", "5", "4", "n")])
+def test_every_step_by_events_matches_the_oracle(S, monkeypatch, p_fire, segments, group_cores, lpb, table):
     """SANAFE_EVENT=2: every step goes through the event kernel, the streaming kernel is never launched.  One and several
     segments of the source space (the last one empty: 4 tiles over 3 segments of 2), core groups that do not fill the
-    8-way block -> group mapping, both lane shapes, sparse and dense activity (blocks longer than one batch slot)."""
+    8-way block -> group mapping, both lane shapes, sparse and dense activity (blocks longer than one batch slot), the
+    neuron-major and the group-major copy of the block table (forced modes take the neuron-major one unless
+    SANAFE_EVENT_SPARSE_EVENTS=0)."""
     monkeypatch.setenv("SANAFE_EVENT", "2")
+    if table == "g":
+        monkeypatch.setenv("SANAFE_EVENT_SPARSE_EVENTS", "0")
     monkeypatch.setenv("SANAFE_EVENT_SEGMENTS", segments)
     monkeypatch.setenv("SANAFE_EVENT_GROUP_CORES", group_cores)
     monkeypatch.setenv("SANAFE_EVENT_LPB", lpb)
@@ -37,6 +42,7 @@ def test_every_step_by_events_matches_the_oracle(S, monkeypatch, p_fire, segment
     assert ev["segments"] == int(segments) and ev["lanes_per_block"] == int(lpb), ev
     assert ev["groups"] == {"16": 2, "3": 6, "5": 4}[group_cores], ev  # (at most 15 cores of 256 slots fit 4,096 - 64 accumulators)
     assert lay["pushed_steps"] == 14, lay  # steps delivered by events are counted like pushed ones
+    assert ev["sparse_steps"] == (14 if table == "n" else 0), ev
 
 
 def test_event_or_stream_decided_per_step(S, monkeypatch):
@@ -45,6 +51,7 @@ def test_event_or_stream_decided_per_step(S, monkeypatch):
     Same result as the oracle and as the chip without the event layout."""
     monkeypatch.setenv("SANAFE_EVENT", "1")
     monkeypatch.setenv("SANAFE_EVENT_MAX_EVENTS", "7400")  # 4,530 events in step 1, 7,000-8,100 from step 9 on
+    monkeypatch.setenv("SANAFE_EVENT_SPARSE_EVENTS", "7100")
     arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=200, out_degree=30, arch_kind="loihi", p_fire=0.05, seed=52)
     chip, orc, tot = check_batched(S, arch, net, steps=40)
     lay = chip.device_layout()
@@ -54,6 +61,9 @@ def test_event_or_stream_decided_per_step(S, monkeypatch):
     ev = chip.step_totals(0, 40)["spikes"]
     expect = sum(1 for t in range(1, 41) if (t - 16) // 4 * 4 >= 1 and ev[(t - 16) // 4 * 4 - 1] <= 7400)
     assert lay["pushed_steps"] == expect and 4 <= expect <= 20, (lay, expect)
+    # ... and with the neuron-major block table when it caused at most SANAFE_EVENT_SPARSE_EVENTS
+    sparse = sum(1 for t in range(1, 41) if (t - 16) // 4 * 4 >= 1 and ev[(t - 16) // 4 * 4 - 1] <= 7100)
+    assert lay["event_layout"]["sparse_steps"] == sparse and 0 < sparse < expect, (lay, sparse, expect)
     monkeypatch.setenv("SANAFE_EVENT", "0")
     monkeypatch.setenv("SANAFE_PUSH", "0")
     plain = S.SpikingChip(arch)
