@@ -103,6 +103,7 @@ struct ExtStreams
 {
     const MappedChip *mc{nullptr};
     std::vector<std::mt19937> poisson_gen; // per input unit instance (src/models.hpp:366-374)
+    std::vector<uint64_t> poisson_gen_key; // ... its (core, unit) key
     std::vector<size_t> poisson_col_gen;   // per Poisson column: its unit's generator
     std::uniform_real_distribution<double> uni{0.0, 1.0};
     GlibcRand rand;
@@ -112,16 +113,19 @@ struct ExtStreams
     void init(const MappedChip &m)
     {
         mc = &m;
-        std::map<uint32_t, size_t> gen_of_unit; // one generator per input unit instance
+        std::map<uint64_t, size_t> gen_of_unit; // one generator per input unit instance
         for (const MappedChip::ExtColumn &c : m.ext)
             if (c.kind == MappedChip::ExtColumn::Poisson)
             {
-                if (!gen_of_unit.count(c.gen))
+                if (!gen_of_unit.count(c.unit_key))
                 {
-                    gen_of_unit[c.gen] = poisson_gen.size();
+                    gen_of_unit[c.unit_key] = poisson_gen.size();
                     poisson_gen.emplace_back(c.seed);
+                    // (a double from std::uniform_real_distribution takes two 32-bit draws: generate_canonical<double, 53>)
+                    if (c.skip_updates > 0) poisson_gen.back().discard(2ull * static_cast<unsigned long long>(c.skip_updates));
+                    poisson_gen_key.push_back(c.unit_key);
                 }
-                poisson_col_gen.push_back(gen_of_unit[c.gen]);
+                poisson_col_gen.push_back(gen_of_unit[c.unit_key]);
             }
         for (const MappedChip::NoiseStream &ns : m.noise_streams)
         {
@@ -150,6 +154,19 @@ struct ExtStreams
             noise_values.push_back(std::move(vals));
             noise_pos.push_back(0);
         }
+    }
+    // load(net, overwrite=false) after timesteps (src/chip.cpp:129-138): every programmed unit keeps its state -- the process's
+    // std::rand() sequence goes on, a unit's std::mt19937 and its noise file's read position stay where they are; units the new
+    // network brings into use start fresh.
+    void carry_from(const ExtStreams &old)
+    {
+        rand = old.rand;
+        for (size_t k = 0; k < poisson_gen.size(); k++)
+            for (size_t j = 0; j < old.poisson_gen.size(); j++)
+                if (old.poisson_gen_key[j] == poisson_gen_key[k]) poisson_gen[k] = old.poisson_gen[j];
+        for (size_t k = 0; k < noise_pos.size(); k++)
+            for (size_t j = 0; j < old.noise_pos.size(); j++)
+                if (old.mc->noise_streams[j].unit_key == mc->noise_streams[k].unit_key) noise_pos[k] = old.noise_pos[j];
     }
     void fill_row(int32_t *row)
     {
@@ -220,10 +237,32 @@ struct sanafe_chip
     std::vector<uint32_t> dirty_slots;
     bool classes_dirty{false};
     bool inputs_dirty{false};
+    bool structure_dirty{false};       // a value-stream column came or went (Poisson rate / random_mask set after load()): rebuild_device()
     std::vector<uint8_t> input_rewind; // per input: its train was replaced since the last commit
     static std::string class_key(const sanafe_hip_soma_class &c) { return std::string(reinterpret_cast<const char *>(&c), sizeof(c)); }
+    int rebuild_device();
+    // A value-stream column of slot `ls` comes (col != nullptr) or goes: the columns stay in slot order -- the order the
+    // reference's sweep reaches the neurons; the device tables follow at the next commit (rebuild_device).
+    void change_ext_column(uint32_t ls, const MappedChip::ExtColumn *col)
+    {
+        auto at = std::lower_bound(mc.ext.begin(), mc.ext.end(), ls, [](const MappedChip::ExtColumn &c, uint32_t slot) { return c.slot < slot; });
+        if (col != nullptr) mc.ext.insert(at, *col);
+        else if (at != mc.ext.end() && at->slot == ls) mc.ext.erase(at);
+        // (slot_ext is rebuilt with the device; until then no lookup may trust it)
+        mc.slot_ext.assign(mc.ext.empty() ? 0 : mc.n_slots, 0xffffffffu);
+        uint64_t r = 0;
+        for (size_t k = 0; k < mc.ext.size(); k++)
+        {
+            mc.slot_ext[mc.ext[k].slot] = static_cast<uint32_t>(k);
+            if (mc.ext[k].kind == MappedChip::ExtColumn::TrueNorthRand) mc.ext[k].rand_index = r++;
+        }
+        mc.n_rand_global = r;
+        structure_dirty = true;
+    }
     int commit_attributes()
     {
+        if (structure_dirty)
+            if (int rc = rebuild_device()) return rc;
         if (classes_dirty)
         {
             if (sanafe_hip_write_soma_classes(dev, static_cast<uint32_t>(mc.soma_classes.size()), mc.soma_classes.data()) != 0)
@@ -304,8 +343,20 @@ struct sanafe_chip
             const bool has_column = !mc.slot_ext.empty() && mc.slot_ext[ls] != 0xffffffffu;
             if (has_column) mc.ext[mc.slot_ext[ls]].poisson = num;
             else if (num > 0.0)
-                return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: an input neuron that had poisson == 0 at load() cannot get a "
-                                                        "Poisson rate later on the MI355X backend (no value-stream column)");
+            {
+                // no column yet: the unit's generator has drawn at every update so far all the same (src/models.cpp:876)
+                if (n_ranks != 1 || a >= mc.in_seed.size())
+                    return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: an input neuron that had poisson == 0 at load() cannot get a "
+                                                            "Poisson rate later on a tile-sharded chip");
+                MappedChip::ExtColumn col;
+                col.slot = ls;
+                col.kind = MappedChip::ExtColumn::Poisson;
+                col.poisson = num;
+                col.seed = mc.in_seed[a];
+                col.unit_key = mc.in_unit_key[a];
+                col.skip_updates = total_timesteps;
+                change_ext_column(ls, &col);
+            }
         }
         return 0;
     }
@@ -1003,6 +1054,57 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
     return 0;
 }
 
+// A structural patch (a value-stream column came or went): the device chip is created again from the patched tables and the
+// run-time state moves over slot by slot -- the layout is the same.  The generators and file positions of the value streams
+// stay where they are (ExtStreams::carry_from); a new Poisson generator skips the draws its unit has made so far.
+int sanafe_chip::rebuild_device()
+{
+    if (!dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "the chip has no device (mapped only)");
+    if (n_ranks != 1 || xc.kind != sanafe_amd::Exchange::None || !mc.host_neurons.empty() || hcores || !mc.tap_slot.empty())
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a Poisson rate / random_mask that comes or goes after load() needs a single-rank "
+                                                "chip without plugin / host-side units or `taps` dendrites");
+    const size_t n = mc.n_slots;
+    std::vector<double> v(n, 0.0), u(n, 0.0), ring(static_cast<size_t>(mc.ring_slots) * n, 0.0);
+    std::vector<int32_t> rf(n, 0);
+    std::vector<uint8_t> stt(n, 0), rv(static_cast<size_t>(mc.ring_slots) * n, 0), arr(n, 0);
+    std::vector<uint32_t> last(n, 0), pos(std::max<size_t>(1, mc.in_train_beg.size()), 0);
+    sanafe_hip_state s{0, v.data(), u.data(), rf.data(), stt.data(), ring.data(), rv.data(), arr.data(), last.data(), pos.data()};
+    if (sanafe_hip_export_state(dev, &s) != 0) return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+    if (inputs_dirty) // replaced trains start over; the new image holds the patched trains already
+        for (size_t a = 0; a < input_rewind.size() && a < pos.size(); a++)
+            if (input_rewind[a]) pos[a] = 0;
+    const sanafe_hip_image im = mc.image();
+    sanafe_hip_chip *fresh = nullptr;
+    if (sanafe_hip_chip_create(&im, device, &fresh) != 0) return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+    if (sanafe_hip_import_state(fresh, &s) != 0)
+    {
+        sanafe_hip_chip_destroy(fresh);
+        return fail(SANAFE_HIP_ERR_INVALID, sanafe_hip_last_error());
+    }
+    sanafe_hip_chip_destroy(dev);
+    dev = fresh;
+    try
+    {
+        ExtStreams streams;
+        streams.init(mc);
+        streams.carry_from(ext);
+        ext = std::move(streams);
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    structure_dirty = classes_dirty = inputs_dirty = false; // (the new image holds every patch made so far)
+    dirty_slots.clear();
+    std::fill(input_rewind.begin(), input_rewind.end(), 0);
+    if (!log_v_gids.empty() || !log_u_gids.empty())
+    {
+        const std::vector<int64_t> lv = log_v_gids, lu = log_u_gids;
+        if (int rc = sanafe_chip_set_state_log(this, static_cast<int64_t>(lv.size()), lv.data(), static_cast<int64_t>(lu.size()), lu.data())) return rc;
+    }
+    return 0;
+}
+
 // load(net, overwrite=false) on a chip that has already simulated timesteps (src/chip.cpp:129-138: the new neurons are
 // mapped next to the programmed ones, every unit keeps its state): the combined network was lowered into `to`; the
 // programmed neurons keep their global ids, so their state moves slot by slot -- potentials, LIF input currents,
@@ -1014,9 +1116,9 @@ extern "C" int sanafe_chip_carry_state(sanafe_chip *to, sanafe_chip *from)
     const MappedChip &a = from->mc, &b = to->mc;
     if (from->n_ranks != 1 || to->n_ranks != 1) return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: adding a network to a tile-sharded chip after timesteps have run");
     for (const sanafe_chip *c : {from, to})
-        if (!c->mc.ext.empty() || !c->mc.host_neurons.empty() || c->hcores || !c->mc.tap_slot.empty())
+        if (!c->mc.host_neurons.empty() || c->hcores || !c->mc.tap_slot.empty())
             return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: load(net, overwrite=False) after timesteps have been simulated is not "
-                                                    "available with stochastic value streams, plugin / host-side units or `taps` dendrites "
+                                                    "available with plugin / host-side units or `taps` dendrites "
                                                     "(their state lives in host objects that a new lowering re-creates)");
     if (from->n_neurons > to->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "the new chip does not hold the programmed neurons");
     auto buffers = [](const MappedChip &m, std::vector<double> &v, std::vector<double> &u, std::vector<int32_t> &rf, std::vector<uint8_t> &stt,
@@ -1082,6 +1184,7 @@ extern "C" int sanafe_chip_carry_state(sanafe_chip *to, sanafe_chip *from)
     }
     sb.timesteps = t;
     DEV(sanafe_hip_import_state(to->dev, &sb));
+    to->ext.carry_from(from->ext); // stochastic value streams: the generators and file positions of the programmed units
     to->total_timesteps = from->total_timesteps;
     to->total_messages_sent = from->total_messages_sent;
     to->total_energy = from->total_energy;
@@ -2131,11 +2234,26 @@ extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, cons
             sanafe_amd::apply_soma_attribute(model == SANAFE_SOMA_PERSIST ? static_cast<uint32_t>(SANAFE_SOMA_TRUENORTH) : model, a, p, fx);
             if (fx.random_mask_set)
             {
-                uint32_t old_mask = 0;
-                if (!mc.slot_ext.empty() && mc.slot_ext[ls] != 0xffffffffu) old_mask = mc.ext[mc.slot_ext[ls]].mask;
+                // TrueNorthModel::update draws std::rand() only for a neuron with a mask (src/models.cpp:752-758): a mask that
+                // comes or goes changes which neurons draw -- the value-stream columns follow
+                const bool has_column = !mc.slot_ext.empty() && mc.slot_ext[ls] != 0xffffffffu;
+                const uint32_t old_mask = has_column ? mc.ext[mc.slot_ext[ls]].mask : 0u;
                 if (fx.random_mask != old_mask)
-                    return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: random_mask cannot change after load() on the MI355X backend "
-                                                            "(it defines the chip's rand() schedule)");
+                {
+                    if (has_column && fx.random_mask != 0u) mc.ext[mc.slot_ext[ls]].mask = fx.random_mask;
+                    else if (chip->n_ranks != 1)
+                        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a random_mask cannot come or go after load() on a tile-sharded "
+                                                                "chip (it defines the chip's rand() schedule)");
+                    else if (has_column) chip->change_ext_column(ls, nullptr);
+                    else
+                    {
+                        MappedChip::ExtColumn col;
+                        col.slot = ls;
+                        col.kind = MappedChip::ExtColumn::TrueNorthRand;
+                        col.mask = fx.random_mask;
+                        chip->change_ext_column(ls, &col);
+                    }
+                }
             }
             if (fx.bias_set)
             {

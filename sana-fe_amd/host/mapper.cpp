@@ -1134,6 +1134,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 col.poisson = poisson;
                 col.seed = core_input_base[c] + static_cast<uint32_t>(su.input_rank) + 1u;
                 col.gen = sh.gen; // the unit's generator: its neurons draw from it one after the other
+                col.unit_key = (static_cast<uint64_t>(c) << 16) | static_cast<uint64_t>(soma_unit[gid]);
                 mc.ext.push_back(col);
             }
             mc.slot_aux[ls] = static_cast<uint32_t>(mc.in_train_beg.size());
@@ -1151,6 +1152,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             }
             mc.in_rate_period.push_back(period);
             mc.in_shared.push_back(k_members > 1 ? 1 : 0);
+            mc.in_seed.push_back(core_input_base[c] + static_cast<uint32_t>(su.input_rank) + 1u);
+            mc.in_unit_key.push_back((static_cast<uint64_t>(c) << 16) | static_cast<uint64_t>(soma_unit[gid]));
         }
         else
         {
@@ -1172,6 +1175,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     MappedChip::NoiseStream ns;
                     ns.path = su.noise_path;
                     ns.random_mask = su.noise_random_mask;
+                    ns.unit_key = (static_cast<uint64_t>(c) << 16) | static_cast<uint64_t>(soma_unit[gid]);
                     mc.noise_streams.push_back(ns);
                 }
                 MappedChip::ExtColumn col;

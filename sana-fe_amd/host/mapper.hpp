@@ -88,6 +88,8 @@ struct MappedChip
     std::vector<uint32_t> in_train_beg, in_train_len, in_train_bits;
     std::vector<int64_t> in_rate_period;
     std::vector<uint8_t> in_shared;    // per input neuron: its `input` unit instance holds other neurons too
+    std::vector<uint32_t> in_seed;     // per input neuron: the std::mt19937 seed of its unit instance (src/models.hpp:347) ...
+    std::vector<uint64_t> in_unit_key; // ... and the unit's key (ExtColumn::unit_key): a Poisson rate set after load() needs them
     // ---- external per-step value streams (include/sanafe_hip.h: slot_ext, sanafe_hip_write_ext) ----
     // One column per neuron that consumes a sequential host-side source at every update.
     struct ExtColumn
@@ -101,11 +103,15 @@ struct MappedChip
         uint32_t mask{0};          // TrueNorth random_range_mask
         uint64_t rand_index{0};    // position of the neuron among ALL rand()-consuming neurons of the chip
         uint32_t stream{0};        // LIF noise: index into noise_streams
+        uint64_t unit_key{0};      // Poisson: (core << 16 | soma unit) of the unit instance -- the same across lowerings of one chip
+        int64_t skip_updates{0};   // Poisson column added after load(): updates the unit had made by then -- its generator draws at
+                                   // every update whatever the rate (src/models.cpp:876), so a fresh one skips as many draws
     };
     struct NoiseStream // one per (core, LIF unit with a `noise` file): every instance opens its own stream
     {
         std::string path;
         long random_mask{0x7f}, sign_mask{0x100}; // src/models.hpp:271-272, src/models.cpp:367-371
+        uint64_t unit_key{0};                     // (core << 16 | soma unit)
     };
     // ---- `taps` dendrites (MultiTapModel1D, src/models.cpp:167-348): one entry per neuron behind such a unit ----
     std::vector<uint32_t> tap_slot, tap_count; // local slot, number of taps (<= 8)

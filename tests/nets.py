@@ -204,7 +204,7 @@ def truenorth_net(S, n_tiles=16, neurons_per_core=256, remote_fraction=0.8, seed
     return arch, net
 
 
-def stochastic(S, tmp_path, n_lif=96, n_in=6, n_tn=0, seed=9, noise_bits=None):
+def stochastic(S, tmp_path, n_lif=96, n_in=6, n_tn=0, seed=9, noise_bits=None, silent_inputs=()):
     """Every sequential host-side source the models consume: Poisson inputs
     (std::mt19937 per input unit), LIF neurons on a soma unit that reads a noise file, spread over several cores."""
     D = S.description
@@ -220,6 +220,8 @@ def stochastic(S, tmp_path, n_lif=96, n_in=6, n_tn=0, seed=9, noise_bits=None):
     gin = net.create_neuron_group("in", n_in, {}, "loihi_sparse_synapse", "loihi_dendrites", False, True)
     for i in range(n_in):
         attrs = {"poisson": ((D.ATTR_DOUBLE, 0.15 + 0.1 * i, None, None), D.FWD_ALL)}
+        if i in silent_inputs:
+            attrs = {}  # no Poisson rate at load(): the unit's generator draws at every update all the same
         if i == 1:
             attrs["spikes"] = ((D.ATTR_LIST, 0.0, None, [0.0, 1.0, 1.0, 0.0, 1.0]), D.FWD_ALL)
         gin.apply_config(i, i + 1, soma_hw_name="loihi_inputs[%d]" % (i % 3), attrs=attrs)
