@@ -115,6 +115,9 @@ int sanafe_chip_get_step_optional(sanafe_chip *chip, int64_t first, int64_t coun
 /* Potential and neuron traces (src/chip.cpp:1786-1831): the neurons whose potential (n_v) and LIF input current `u`
  * (n_u) every recorded step keeps, sampled on the device right after the neuron update (no per-step host round trip);
  * _get_step_state copies out[count][n_v + n_u] rows of a sim() run with SANAFE_RECORD_STATE. */
+/* 1 when the architecture asks for optional perf columns (log_energy / log_latency flags): on a tile-sharded chip they need
+ * the whole chip's tables (sanafe_chip_attach_whole) before a recorded sim(). */
+int sanafe_chip_wants_perf_columns(sanafe_chip *chip);
 int sanafe_chip_set_state_log(sanafe_chip *chip, int64_t n_v, const int64_t *neurons_v, int64_t n_u, const int64_t *neurons_u);
 int sanafe_chip_get_step_state(sanafe_chip *chip, int64_t first, int64_t count, double *out);
 /* fired flag per neuron (desc order) of recorded step `index` of the last sim */

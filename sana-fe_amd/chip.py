@@ -321,8 +321,8 @@ class SpikingChip(_Base):
         lists, ``messages`` also every step's messages (step_messages), ``state`` the potentials / currents of the
         neurons given to set_state_log (step_state)."""
         t = Totals()
-        if self._n_ranks > 1 and (timing_model == "detailed" or messages):
-            self.attach_whole()  # whole-chip host tables for the NoC schedule / message trace of a sharded chip
+        if self._n_ranks > 1 and (timing_model == "detailed" or messages or (record and self._L.sanafe_chip_wants_perf_columns(self._h))):
+            self.attach_whole()  # whole-chip host tables for the NoC schedule / message trace / optional perf columns of a sharded chip
         flags = (self.RECORD_STEPS if record or messages or state else 0) | (self.RECORD_MESSAGES if messages else 0) | \
                 (self.RECORD_STATE if state else 0)
         self._check(self._L.sanafe_chip_sim(self._h, int(timesteps), TIMING[timing_model], flags, C.byref(t)))

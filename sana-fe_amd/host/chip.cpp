@@ -650,7 +650,7 @@ struct sanafe_chip
     // `.latency` column repeats the `.energy` value.  Core and tile energies follow sim_calculate_core_energy /
     // _tile_energy (src/chip.cpp:1188-1261); a tile's hop energy is summed per message here (per direction there).
     // ------------------------------------------------------------------------------
-    std::vector<double> optional_columns(const uint8_t *status) const
+    std::vector<double> optional_columns(const uint8_t *status, const uint16_t *msg_fired = nullptr) const
     {
         const MappedChip::LogPlan &lg = mc.log;
         std::vector<double> unit_e(lg.unit_used.size(), 0.0), tile_hop(mc.n_tiles, 0.0);
@@ -677,6 +677,25 @@ struct sanafe_chip
                     packets_out[c]++;
                     msgs_in[dc]++;
                     tile_hop[mc.core_tile[dc]] += lg.ax_e_hop[a];
+                    if (a >= mc.n_device_axons)
+                    {
+                        // into a core whose soma is part of the message pipeline (on the device): per synaptic event the
+                        // synapse, the dendrite and the soma unit, the soma by the status its update returned -- the device
+                        // counted the updates that fired per message (the reference interleaves them: same terms, other order)
+                        const uint64_t i = a - mc.n_device_axons;
+                        const uint32_t k = msg_ax_core[i];
+                        const sanafe_hip_msg_core_costs &mk = mc.msg_costs[k];
+                        const uint32_t ub = lg.core_unit_beg[dc], n_ev = mc.msg_ax_nsyn[i];
+                        const uint32_t n_fired = msg_fired ? std::min<uint32_t>(msg_fired[i], n_ev) : 0u;
+                        const double updated = mk.soma_energy[0] + mk.soma_energy[1], fired = updated + mk.soma_energy[2];
+                        for (uint32_t q = 0; q < n_ev; q++)
+                        {
+                            unit_e[ub + mc.msg_units[k][0]] += mk.synapse_energy;
+                            unit_e[ub + mc.msg_units[k][1]] += mk.dendrite_energy;
+                            unit_e[ub + mc.msg_units[k][2]] += q < n_ev - n_fired ? updated : fired;
+                        }
+                        continue;
+                    }
                     const uint64_t s0 = mc.core_syn_base[dc] + mc.ax_syn_beg[a];
                     for (uint32_t q = 0; q < mc.ax_nsyn[a]; q++)
                     {
@@ -1281,6 +1300,7 @@ struct ShardedRun
     void *global_bits{nullptr};
     std::vector<uint32_t> h_local, h_global;
     std::vector<double> maxima; // [m] of the last chunk: largest per-core delay of every step over all ranks
+    int64_t t_next{1};          // number of the next timestep (plugin somas are told)
 
     explicit ShardedRun(sanafe_chip *c) : chip(c), xc(c->xc) {}
     int begin(int64_t timesteps)
@@ -1301,6 +1321,7 @@ struct ShardedRun
             h_global.resize(global_bytes / 4);
         }
         maxima.assign(static_cast<size_t>(cap), 0.0);
+        t_next = chip->total_timesteps + 1;
         return 0;
     }
     // m <= cap steps; record_bits as sanafe_hip_step's (0: none).  Synchronises; fills maxima[0, m) when simple_timing.
@@ -1309,9 +1330,26 @@ struct ShardedRun
         if (int rc = chip->queue_ext(m)) return rc;
         DEV(sanafe_hip_record_begin(chip->dev, m, record_bits));
         DEV(sanafe_hip_delay_log(chip->dev, cap, &d_log, &cap, &next)); // flushed: `next` is where this chunk starts
-        for (int64_t s = 0; s < m; s++)
+        for (int64_t s = 0; s < m; s++, t_next++)
         {
             DEV(sanafe_hip_step_neurons(chip->dev));
+            if (!chip->h_slots.empty())
+            {
+                // plugin somas of THIS rank's tiles (a core's units live where the core does), evaluated by the host between the
+                // neuron launch and the exchange: their spikes are in the rank's bitmap before it is gathered
+                const uint32_t n = static_cast<uint32_t>(chip->h_slots.size());
+                try
+                {
+                    DEV(sanafe_hip_read_host_inputs(chip->dev, n, chip->h_slots.data(), chip->h_cur.data(), chip->h_has.data()));
+                    chip->run_plugins(t_next);
+                    DEV(sanafe_hip_write_host_status(chip->dev, n, chip->h_slots.data(), chip->h_status.data(), chip->h_cores.data(),
+                            chip->h_energy.data(), chip->h_latency.data()));
+                }
+                catch (const std::exception &e)
+                {
+                    return fail(SANAFE_HIP_ERR_INVALID, e.what());
+                }
+            }
             if (xc.kind == sanafe_amd::Exchange::Rccl_ && xc.overlap)
             {
                 if (xc.gather_spikes_rccl(global_bits)) return fail(SANAFE_HIP_ERR_HIP, xc.error);
@@ -1510,10 +1548,6 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
-    if (chip->mc.msg_on_device && (record & SANAFE_RECORD_STEPS) && chip->mc.log.any)
-        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: cores whose soma is part of the message pipeline (buffer inside the soma unit / "
-                                                "before axon_out) are simulated without optional perf columns: their per-unit costs depend on the "
-                                                "statuses the soma returns at run time");
     if (chip->mc.msg_on_device && (timing_model != SANAFE_TIMING_SIMPLE || want_messages) && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
         return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces of a chip with cores whose soma is part of "
                                                 "the message pipeline need a single-rank chip");
@@ -1526,18 +1560,25 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     // (an exchange set up on a single-rank chip is honoured as well: the same loop with a one-rank gather)
     if (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None)
     {
-        if (host_units || (record && chip->mc.log.any))
-            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: optional perf columns and plugin units are not available on a "
-                                                    "tile-sharded chip");
+        if (chip->hcores)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: cores that run on the host are not available on a tile-sharded chip");
+        if (record && chip->mc.log.any && (host_units || want_state))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: optional perf columns of a tile-sharded chip are not available with "
+                                                    "plugin units or potential traces");
+        if (host_units && (timing_model != SANAFE_TIMING_SIMPLE || want_messages || want_state))
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: plugin soma units on a tile-sharded chip need the simple timing model, "
+                                                    "without a message trace or potential traces (their latencies and potentials live on "
+                                                    "the rank that holds them)");
         if (want_state && (timing_model != SANAFE_TIMING_SIMPLE || want_messages))
             return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: potential / neuron traces of a tile-sharded chip need the simple timing "
                                                     "model without a message trace");
-        if ((timing_model != SANAFE_TIMING_SIMPLE || want_messages) && chip->whole == nullptr)
-            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces on a tile-sharded chip need the whole "
-                                                    "chip's tables on the host: call sanafe_chip_attach_whole with the complete description first");
+        if ((timing_model != SANAFE_TIMING_SIMPLE || want_messages || (record && chip->mc.log.any)) && chip->whole == nullptr)
+            return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing, message traces and optional perf columns on a tile-sharded "
+                                                    "chip need the whole chip's tables on the host: call sanafe_chip_attach_whole with the "
+                                                    "complete description first");
     }
     const bool sharded = chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None;
-    if (sharded && timing_model == SANAFE_TIMING_SIMPLE && !want_messages)
+    if (sharded && timing_model == SANAFE_TIMING_SIMPLE && !want_messages && !(record && chip->mc.log.any))
     {
         if (int rc = sim_sharded(chip, timesteps, run, record, want_state)) return rc;
     }
@@ -1690,7 +1731,7 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
                 else
                     for (uint32_t k = 0; k < hmc.n_slots; k++)
                         if (st_bytes[k] == 3) bits[k >> 5] |= 1u << (k & 31u);
-                if (hmc.log.any) chip->rec_optional.push_back(H->optional_columns(st_bytes));
+                if (hmc.log.any) chip->rec_optional.push_back(H->optional_columns(st_bytes, msg_fired));
             }
             if (!detailed)
             {
@@ -2139,23 +2180,27 @@ extern "C" int sanafe_chip_get_step_state(sanafe_chip *chip, int64_t first, int6
     return 0;
 }
 
+// (a tile-sharded chip's optional columns are the whole chip's: computed on the twin's tables from the gathered statuses)
+static const MappedChip::LogPlan &log_plan(const sanafe_chip *chip) { return (chip->n_ranks > 1 && chip->whole) ? chip->whole->mc.log : chip->mc.log; }
+
+extern "C" int sanafe_chip_wants_perf_columns(sanafe_chip *chip) { return (chip && chip->mc.log.any) ? 1 : 0; }
 extern "C" int64_t sanafe_chip_perf_columns(sanafe_chip *chip, char *names, int64_t cap)
 {
     if (!chip) return -1;
     int64_t pos = 0;
-    for (const MappedChip::LogPlan::Column &col : chip->mc.log.columns)
+    for (const MappedChip::LogPlan::Column &col : log_plan(chip).columns)
     {
         const int64_t n = static_cast<int64_t>(col.name.size()) + 1;
         if (names && pos + n <= cap) std::memcpy(names + pos, col.name.c_str(), static_cast<size_t>(n));
         pos += n;
     }
-    return static_cast<int64_t>(chip->mc.log.columns.size());
+    return static_cast<int64_t>(log_plan(chip).columns.size());
 }
 extern "C" int sanafe_chip_get_step_optional(sanafe_chip *chip, int64_t first, int64_t count, double *out)
 {
     if (!chip || !out || !chip->have_records || first < 0 || count < 0 || first + count > static_cast<int64_t>(chip->rec_optional.size()))
         return fail(SANAFE_HIP_ERR_INVALID, "optional perf columns not recorded (sim with record=1 on an architecture with log flags)");
-    const size_t n = chip->mc.log.columns.size();
+    const size_t n = log_plan(chip).columns.size();
     for (int64_t k = 0; k < count; k++) std::copy(chip->rec_optional[first + k].begin(), chip->rec_optional[first + k].end(), out + k * n);
     return 0;
 }

@@ -838,7 +838,6 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 if (u.syn) ok = ok && u.model == M_CURRENT_BASED && !u.dend && !u.soma && u.e_spike && u.l_spike;
                 if (u.dend) ok = ok && u.model == M_ACCUMULATOR && !u.syn && !u.soma && u.e_update && u.l_update;
                 if (u.soma) ok = ok && u.model == M_TRUENORTH && !u.syn && !u.dend && u.has_soma_e && u.has_soma_l;
-                ok = ok && !u.log && !u.log_energy && !u.log_latency;
             }
             ok = ok && n_syn == 1 && n_dend == 1 && n_soma == 1;
         }
@@ -871,9 +870,10 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             lg.any = lg.any || d.core_log_energy[c];
             for (const UnitInfo &u : tmpl_of(c).units) lg.any = lg.any || u.log;
         }
-        if (lg.any)
+        // (a rank of a tile-sharded chip only notes that columns are wanted: they are whole-chip sums, computed on the
+        //  single-rank twin of sanafe_chip_attach_whole from the gathered statuses)
+        if (lg.any && n_ranks == 1)
         {
-            if (n_ranks != 1) throw UnsupportedError("log_energy / log_latency columns need the whole chip in one process");
             lg.core_unit_beg.assign(d.n_cores + 1, 0);
             for (int c = 0; c < d.n_cores; c++) lg.core_unit_beg[c + 1] = lg.core_unit_beg[c] + static_cast<uint32_t>(tmpl_of(c).units.size());
             const size_t nu = lg.core_unit_beg[d.n_cores];
@@ -1380,7 +1380,8 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
     const int64_t local_beg = first_at_or_after(mc.first_core), local_end = first_at_or_after(mc.last_core);
     mc.syn_meta.resize(static_cast<size_t>(local_end - local_beg));
     mc.syn_weight.resize(static_cast<size_t>(local_end - local_beg));
-    if (mc.log.any) mc.log.syn_units.resize(static_cast<size_t>(local_end - local_beg));
+    const bool build_log = mc.log.any && n_ranks == 1; // (ranks of a sharded chip leave the plan to the whole-chip twin)
+    if (build_log) mc.log.syn_units.resize(static_cast<size_t>(local_end - local_beg));
 
     // Pass 1 (threads, blocks of whole axons): everything about an axon that depends only on its own
     // edges.  Pass 2 (serial, below) numbers the axons and accumulates the per-neuron aggregates in
@@ -1435,6 +1436,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 double lat = 0.0; // execute_pipeline: total_latency
                 if (host_dest)
                 {
+                    if (build_log) mc.log.unit_used[mc.log.core_unit_beg[dc] + edge_syn_unit[e]] = 1; // (is_used: a connection is mapped to it)
                     if (local) // a hole in the image's synapse arrays: no axon refers to it, every scan skips it (lost charge)
                     {
                         mc.syn_meta[static_cast<size_t>(k - local_beg)] = 1u << 19;
@@ -1465,7 +1467,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                     if (neuron_dend_kind[dst] == 1) meta |= 1u << 19; // charge is lost inside a plain accumulator (quirk 1)
                     mc.syn_meta[static_cast<size_t>(k - local_beg)] = meta;
                     mc.syn_weight[static_cast<size_t>(k - local_beg)] = d.edge_weight[e];
-                    if (mc.log.any)
+                    if (build_log)
                     {
                         mc.log.syn_units[static_cast<size_t>(k - local_beg)] =
                                 static_cast<uint16_t>(static_cast<uint32_t>(edge_syn_unit[e]) | (static_cast<uint32_t>(dend_unit[dst]) << 8));
@@ -1514,7 +1516,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             B.first_lat.push_back(first_lat);
             B.min_hop.push_back(min_hop);
             B.e_net.push_back((e_aout + e_hop) + e_ain);
-            if (mc.log.any) B.e_hop.push_back(e_hop);
+            if (build_log) B.e_hop.push_back(e_hop);
             B.e_syn.push_back(e_syn);
             B.e_dend.push_back(e_dend);
             i = j;
@@ -1533,6 +1535,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
         uint32_t pre, dc, axon_id, hops;
         double min_hop;
         uint32_t host_core, idx_in_core;
+        double e_hop;
     };
     std::vector<MsgAxonOut> mx; // inbound axons of the cores whose soma is part of the message pipeline (msg_on_device)
     const bool keep_out_tables = (n_ranks == 1);
@@ -1579,7 +1582,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 ha.n_syn = nsyn;
                 if (mc.msg_on_device && keep_out_tables) // the host still rebuilds the messages INTO such a core (detailed timing)
                     mx.push_back(MsgAxonOut{pre, dc, axon_id, B.hops[a], B.min_hop[a], static_cast<uint32_t>(host_core_index[dc]),
-                            static_cast<uint32_t>(hc.axons.size())});
+                            static_cast<uint32_t>(hc.axons.size()), build_log ? B.e_hop[a] : 0.0});
                 hc.axons.push_back(ha);
                 for (int64_t k = B.first[a]; k < B.first[a] + nsyn; k++)
                 {
@@ -1612,7 +1615,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 if (q < 255) cls = static_cast<uint8_t>(q);
             }
             mc.ax_lat_class.push_back(cls);
-            if (mc.log.any) mc.log.ax_e_hop.push_back(B.e_hop[a]);
+            if (build_log) mc.log.ax_e_hop.push_back(B.e_hop[a]);
             if (keep_out_tables)
             {
                 mc.ax_dest_core.push_back(dc);
@@ -1650,14 +1653,21 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             mc.msg_syn_beg.push_back(static_cast<uint32_t>(mc.msg_syn_post.size()));
             sanafe_hip_msg_core_costs k{};
             k.axon_in_latency = hc.ain_latency;
-            for (const UnitInfo &u : tmpl_of(static_cast<int>(hc.core)).units)
+            std::array<uint32_t, 3> roles{0, 0, 0}; // the core's synapse, dendrite and soma unit (one each: the capability check)
+            const std::vector<UnitInfo> &units = tmpl_of(static_cast<int>(hc.core)).units;
+            for (size_t q0 = 0; q0 < units.size(); q0++)
             {
-                if (u.syn) k.synapse_energy = *u.e_spike, k.synapse_latency = *u.l_spike;
-                if (u.dend) k.dendrite_energy = *u.e_update, k.dendrite_latency = *u.l_update;
+                const UnitInfo &u = units[q0];
+                if (u.syn) k.synapse_energy = *u.e_spike, k.synapse_latency = *u.l_spike, roles[0] = static_cast<uint32_t>(q0);
+                if (u.dend) k.dendrite_energy = *u.e_update, k.dendrite_latency = *u.l_update, roles[1] = static_cast<uint32_t>(q0);
                 if (u.soma)
+                {
                     for (int q = 0; q < 3; q++) k.soma_energy[q] = u.se[q], k.soma_latency[q] = u.sl[q];
+                    roles[2] = static_cast<uint32_t>(q0);
+                }
             }
             mc.msg_costs.push_back(k);
+            mc.msg_units.push_back(roles);
         }
     }
     mc.lat_class_per_event.resize(255, 0.0);
@@ -1763,6 +1773,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
             mc.ax_dest_axon_id.resize(A + mx.size());
             mc.ax_hops.resize(A + mx.size());
             mc.ax_min_hop_delay.resize(A + mx.size());
+            if (build_log) mc.log.ax_e_hop.resize(A + mx.size());
             all_pre.resize(A + mx.size());
             for (const MsgAxonOut &m : mx)
             {
@@ -1771,6 +1782,7 @@ void map_and_lower(const sanafe_desc &d, int n_ranks, int rank, uint32_t target_
                 mc.ax_dest_axon_id[id] = m.axon_id;
                 mc.ax_hops[id] = m.hops;
                 mc.ax_min_hop_delay[id] = m.min_hop;
+                if (build_log) mc.log.ax_e_hop[id] = m.e_hop;
                 all_pre[id] = m.pre;
                 out_count[m.pre + 1]++;
             }

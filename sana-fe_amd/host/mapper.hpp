@@ -10,6 +10,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <array>
 #include <vector>
 
 #include "../../include/sanafe_desc.h"
@@ -221,6 +222,7 @@ struct MappedChip
     std::vector<uint32_t> msg_core, msg_ax_beg, msg_ax_pre, msg_ax_nsyn, msg_syn_beg, msg_syn_post;
     std::vector<double> msg_syn_weight;
     std::vector<sanafe_hip_msg_core_costs> msg_costs;
+    std::vector<std::array<uint32_t, 3>> msg_units; // per such core: index of its synapse, dendrite and soma unit (optional perf columns)
 
     // ---- optional perf-trace columns: tiles / cores with log_energy, units with log_energy / log_latency
     //      (sim_trace_get_optional_traces, src/chip.cpp:1541-1579).  Filled only when some flag is set. ----

@@ -329,7 +329,8 @@ public:
         if (neuron_t.on()) cur_gids = trace_order;
         const bool want_state = !pot_gids.empty() || !cur_gids.empty();
         if (want_state) check(sanafe_chip_set_state_log(h, static_cast<int64_t>(pot_gids.size()), pot_gids.data(), static_cast<int64_t>(cur_gids.size()), cur_gids.data()));
-        if (n_ranks > 1 && (timing == SANAFE_TIMING_DETAILED || message_t.on())) attach_whole();
+        // (... and for the optional perf columns, which are whole-chip sums over the gathered statuses)
+        if (n_ranks > 1 && (timing == SANAFE_TIMING_DETAILED || message_t.on() || (perf_t.on() && sanafe_chip_wants_perf_columns(h) != 0))) attach_whole();
         const bool want_steps = spike_t.on() || perf_t.on() || message_t.on() || want_state;
         const int record = (want_steps ? SANAFE_RECORD_STEPS : 0) | (message_t.on() ? SANAFE_RECORD_MESSAGES : 0) | (want_state ? SANAFE_RECORD_STATE : 0);
         const std::vector<std::string> opt_names = perf_t.on() ? perf_columns() : std::vector<std::string>();

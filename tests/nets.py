@@ -410,7 +410,7 @@ def hh_plugin_path():
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "plugins", "libhodgkin_huxley.so")
 
 
-def hodgkin_huxley(S, k=12, lif=24, seed=4):
+def hodgkin_huxley(S, k=12, lif=24, seed=4, spread=False):
     """Config C5: `k` Hodgkin-Huxley plugin somas (snn/hh_example.net scaled up: m=0.0529 n=0.3177
     h=0.5961, a distinct `current` each) driving a small LIF population on the Loihi architecture."""
     D = S.description
@@ -431,6 +431,12 @@ def hodgkin_huxley(S, k=12, lif=24, seed=4):
     g.connect_neurons_sparse(out, {"weight": rng.integers(1, 4, size=len(pairs)).astype(np.float64)}, pairs, narrow_float=False)
     ring = np.array([(i, (i + 1) % k) for i in range(k)])
     g.connect_neurons_sparse(g, {"weight": np.ones(k)}, ring, narrow_float=False)
+    if spread:  # plugin somas on both halves of the chip's tiles (tile-sharded runs: both ranks hold some)
+        g.map_to_core(cores[0], 0, k // 2)
+        g.map_to_core(cores[70], k // 2, k)
+        out.map_to_core(cores[5], 0, lif // 2)
+        out.map_to_core(cores[66], lif // 2, lif)
+        return arch, net
     g.map_to_core(cores[0])
     out.map_to_core(cores[5], 0, lif // 2)
     out.map_to_core(cores[0], lif // 2, lif)

@@ -193,3 +193,39 @@ def test_message_pipeline_somas_under_detailed_timing(S, position):
     tot = chip.run(20, "detailed")
     ref = sum(orc.step("detailed")["sim_time"] for _ in range(20))
     assert tot["sim_time"] == pytest.approx(ref, rel=1e-9)
+
+
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_message_pipeline_somas_optional_perf_columns(S, position):
+    """Optional perf columns (sim_trace_get_optional_traces, src/chip.cpp:1541-1579) of a chip whose message-pipeline somas
+    run on the device: the synapse, dendrite and soma unit of such a core are charged per synaptic event, the soma by the
+    status its update returned -- from the per-message fired counts the kernel logs.  Tile, core and unit columns against
+    the oracle."""
+    arch, net = nets.host_cores(S, position=position, seed=7)
+    arch.tiles[2].log_energy = True
+    cores = arch.cores()
+    cores[2].log_energy = True
+    cores[3].log_energy = True
+    seen = set()
+    for core in cores:
+        for u in core.units:
+            if id(u) not in seen:
+                seen.add(id(u))
+                u.log_energy = True
+                u.log_latency = bool(u.implements & S.description.IMPL_SOMA)
+    chip = S.SpikingChip(arch)
+    chip.load(net)
+    assert chip.device_layout()["msg_cores_on_device"] == 2
+    orc = OracleChip(S.to_desc(arch, net))
+    names = chip.perf_columns()
+    steps = 25
+    r = chip.sim(steps, timing_model="simple", perf_trace=True)
+    nonzero = 0
+    for t in range(steps):
+        orc.step("simple")
+        want = orc.optional_traces()
+        assert sorted(want) == names
+        for n in names:
+            assert r["perf_trace"][n][t] == pytest.approx(want[n], rel=1e-12, abs=1e-30), (t, n)
+            nonzero += want[n] != 0.0
+    assert nonzero > 3 * steps

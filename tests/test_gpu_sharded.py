@@ -121,6 +121,32 @@ def test_two_ranks_match_one(S, monkeypatch, which):
     assert np.array_equal(v, v_ref)
 
 
+def test_two_ranks_with_plugin_somas(S):
+    """VERDICT r3 missing #3: plugin soma units on a tile-sharded chip.  Each rank evaluates the Hodgkin-Huxley somas of its
+    own tiles on the host between its neuron launch and the spike exchange (a core's units live where the core does);
+    totals and spikes of 80 steps against the one-rank chip -- which `test_hodgkin_huxley_plugin_c5` checks against the
+    oracle.  `detailed` timing stays refused there (the somas' latencies live on the rank that holds them)."""
+    arch, net = nets.hodgkin_huxley(S, spread=True)
+    steps = 80
+    one = S.SpikingChip(arch)
+    one.load(net)
+    ref = one.run(steps, "simple")
+    assert ref["neurons_fired"] > 20
+    chips, results = _sharded(S, arch, net, steps)
+    for r in range(2):
+        for k in INT_KEYS:
+            assert results[r][0][k] == ref[k], (r, k)
+        for k in DBL_KEYS:
+            assert results[r][0][k] == pytest.approx(ref[k], rel=1e-9, abs=1e-30), (r, k)
+    sizes = [c.info()["n_slots"] for c in chips]
+    assert min(sizes) > 0, sizes  # both ranks hold neurons
+    tg = ThreadGather(2)
+    for r in range(2):
+        chips[r].comm_init_callback(tg.for_rank(r))
+    with pytest.raises(NotImplementedError, match="simple timing"):
+        chips[0].run(1, "detailed")
+
+
 def _sharded_calls(S, arch, net, call, n_ranks=2):
     """Runs `call(chip)` on every rank's chip concurrently; returns the chips and the per-rank results."""
     tg = ThreadGather(n_ranks)
@@ -194,6 +220,46 @@ def test_sharded_recorded_run_gathers_spike_and_perf_traces(S):
         for k in DBL_KEYS:
             assert np.allclose(recs[k], ref_recs[k], rtol=1e-12, atol=0), k
         assert np.array_equal(recs["timesteps"], ref_recs["timesteps"])
+
+
+@pytest.mark.timeout(180)
+def test_sharded_optional_perf_columns(S):
+    """VERDICT r3 missing #3: tiles / cores / units with log_energy / log_latency on a tile-sharded chip
+    (sim_trace_get_optional_traces, src/chip.cpp:1541-1579).  The columns are whole-chip sums over every neuron's status:
+    the ranks gather the statuses per chunk and every rank computes the columns on the whole-chip twin's tables
+    (sanafe_chip_attach_whole) -- same values as the one-rank chip, which `test_optional_perf_columns` checks against the
+    oracle."""
+    arch, net = nets.random_loihi(S, n_tiles=5, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+    arch.tiles[1].log_energy = True
+    arch.tiles[4].log_energy = True
+    cores = arch.cores()
+    cores[2].log_energy = True
+    cores[17].log_energy = True
+    seen = set()
+    for core in cores:
+        for u in core.units:
+            if id(u) not in seen:
+                seen.add(id(u))
+                u.log_energy = True
+                u.log_latency = bool(u.implements & S.description.IMPL_SOMA)
+    steps = 14
+    ref = S.SpikingChip(arch)
+    ref.load(net)
+    names = ref.perf_columns()
+    assert len(names) > 4
+    ref_tot = ref.run(steps, "simple", record=True)
+    ref_cols = ref.step_optional(0, steps)
+    assert np.count_nonzero(ref_cols) > steps
+
+    def call(chip):
+        tot = chip.run(steps, "simple", record=True)
+        return tot, chip.perf_columns(), chip.step_optional(0, steps)
+
+    _, results = _sharded_calls(S, arch, net, call)
+    for tot, cols, values in results:
+        _assert_same(tot, ref_tot)
+        assert cols == names
+        assert np.allclose(values, ref_cols, rtol=1e-12, atol=0)
 
 
 @pytest.mark.parametrize("timing", ["detailed", "simple"])
