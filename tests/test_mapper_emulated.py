@@ -131,6 +131,25 @@ def test_unsupported_configs_fail_loudly(S):
         S.map_only(arch, net, n_ranks=2, rank=0)
 
 
+def test_log_flags_map_on_every_rank_and_on_message_pipeline_cores(S):
+    """log_energy / log_latency flags (optional perf columns) no longer keep a chip off the sharded path or its
+    message-pipeline somas off the device: a rank only notes that columns are wanted (the whole-chip twin computes them), and
+    the per-event unit charges of a message-pipeline core come from the device's per-message counts."""
+    arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+    arch.tiles[1].log_energy = True
+    for u in arch.cores()[0].units:
+        u.log_energy = True
+    whole, _ = S.map_only(arch, net)
+    parts = [S.map_only(arch, net, n_ranks=2, rank=r)[0] for r in range(2)]
+    assert parts[0]["n_slots"] + parts[1]["n_slots"] == whole["n_slots"]
+    arch, net = nets.host_cores(S, position="axon_out")
+    plain, _ = S.map_only(arch, net)
+    for u in arch.cores()[2].units:
+        u.log_energy = True
+    flagged, _ = S.map_only(arch, net)
+    assert plain["n_msg_cores"] == flagged["n_msg_cores"] == 2
+
+
 def test_unmapped_neuron_raises(S):
     arch, net = nets.example(S)
     net.groups["out"].core[1] = -1
