@@ -120,6 +120,7 @@ struct sanafe_hip_chip
     size_t ord_lds{0};              // format 8: dynamic LDS of ordered_deliver_kernel (the spike bitmap), 0: probe global memory
     const void *deliver_fn{nullptr}; // the deliver_kernel instantiation this chip launches (deliver_variants)
     const void *event_fn{nullptr};   // event_deliver_kernel instantiation (chips with the event layout, DevImage::ev_*)
+    const void *event_fn_sparse{nullptr}; // ... reading the neuron-major copy of the block table (steps in which few neurons fire)
     int ev_lpb{4};                   // its lanes per block
     int ev_upl{1};                   // its 16-byte units per lane and batch
     int ev_waves{16};                // its wavefronts per workgroup
@@ -676,14 +677,6 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     lut.resize(32, 0.0);
     TRY(upload(c, groups.data(), groups.size(), &im.ev_group));
     TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta.data()), meta.size(), &im.ev_meta));
-    {
-        std::vector<uint64_t> meta_n(meta.size(), 0ull);
-        parallel_for(N, [&](uint64_t lo, uint64_t hi) {
-            for (uint64_t n = lo; n < hi; n++)
-                for (uint32_t g = 0; g < NG; g++) meta_n[n * NG + g] = meta[(uint64_t) g * N + n];
-        });
-        TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta_n.data()), meta_n.size(), &im.ev_meta_n));
-    }
     // (between 10 % and 34 % activity on C3, see above)
     c->ev_sparse_max_events = (uint64_t) ((double) h.n_synapses * 0.2);
     if (const char *env = std::getenv("SANAFE_EVENT_SPARSE_EVENTS")) c->ev_sparse_max_events = (uint64_t) std::max(0LL, std::atoll(env));
@@ -713,6 +706,15 @@ int build_event(sanafe_hip_chip *c, const sanafe_hip_image &h)
     if (const char *env = std::getenv("SANAFE_EVENT_WAVES")) c->ev_waves = std::atoi(env) == 8 ? 8 : std::atoi(env) == 4 ? 4 : 16;
     c->layout_bytes[9] = total_units * 16ull;
     c->layout_bytes[10] = meta.size() * 8ull; // (one of the two tables: a step reads one)
+    {
+        // (uploaded last: what the busy steps read -- group-major table, blocks -- keeps the addresses it had without this copy)
+        std::vector<uint64_t> meta_n(meta.size(), 0ull);
+        parallel_for(N, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t n = lo; n < hi; n++)
+                for (uint32_t g = 0; g < NG; g++) meta_n[n * NG + g] = meta[(uint64_t) g * N + n];
+        });
+        TRY(upload(c, reinterpret_cast<const unsigned long long *>(meta_n.data()), meta_n.size(), &im.ev_meta_n));
+    }
     c->ev_grid = 8u * ((NG + 7u) / 8u) * segments;
     // 8 unit slots per block and batch from ~32 words per block on (4 lanes x 2 units: 16 neurons per batch), else 4
     c->ev_lpb = 4;
@@ -1765,7 +1767,10 @@ extern "C" int sanafe_hip_chip_create(const sanafe_hip_image *image, int device,
         c->deliver_block = (uint32_t) v->block;
         if (im.ev_groups != 0u)
         {
-#define SANAFE_EV(L, B, W, U) if (c->ev_lpb == L && im.ev_code_bits == B && c->ev_waves == W && c->ev_upl == U) c->event_fn = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W, U>)
+#define SANAFE_EV(L, B, W, U) \
+    if (c->ev_lpb == L && im.ev_code_bits == B && c->ev_waves == W && c->ev_upl == U) \
+        c->event_fn = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W, U, false>), \
+        c->event_fn_sparse = reinterpret_cast<const void *>(event_deliver_kernel<L, B, W, U, true>)
 #define SANAFE_EVW(L, B, U) SANAFE_EV(L, B, 4, U); SANAFE_EV(L, B, 8, U); SANAFE_EV(L, B, 16, U)
             SANAFE_EVW(4, 4, 1); SANAFE_EVW(8, 4, 1); SANAFE_EVW(4, 4, 2); SANAFE_EVW(4, 5, 1); SANAFE_EVW(8, 5, 1); SANAFE_EVW(4, 5, 2);
 #undef SANAFE_EVW
@@ -2014,10 +2019,9 @@ static int launch_deliver_slices(sanafe_hip_chip *c, uint32_t first, uint32_t co
         if (first + count == c->im.n_slices)
         {
             long long done = c->t_host;
-            int sparse = c->cur_sparse;
-            c->sparse_steps += sparse;
-            void *args[] = {&c->im, &c->st, &done, &sparse};
-            HIPCHK(hipLaunchKernel(c->event_fn, dim3(c->ev_grid), dim3(64u * (uint32_t) c->ev_waves), args, 0, c->stream));
+            c->sparse_steps += c->cur_sparse;
+            void *args[] = {&c->im, &c->st, &done};
+            HIPCHK(hipLaunchKernel(c->cur_sparse ? c->event_fn_sparse : c->event_fn, dim3(c->ev_grid), dim3(64u * (uint32_t) c->ev_waves), args, 0, c->stream));
             c->ev_pending = c->t_host + 1;
         }
         return 0;

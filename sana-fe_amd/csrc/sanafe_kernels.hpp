@@ -1989,9 +1989,9 @@ __device__ __forceinline__ uint4 ev_load16(const uint4 *p)
     return *p;
 #endif
 }
-template <int LPB, int CODE_BITS, int WAVES, int UPL = 1>
+template <int LPB, int CODE_BITS, int WAVES, int UPL = 1, bool SPARSE = false /* the neuron-major copy of the block table */>
 __global__ void __launch_bounds__(WAVES * WAVE)
-event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */, int sparse /* neuron-major table */)
+event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated before this one */)
 {
     constexpr uint32_t ACC_MAX = 1u << (16 - CODE_BITS);
     constexpr uint32_t CODE_MASK = (1u << CODE_BITS) - 1u;
@@ -2018,9 +2018,9 @@ event_deliver_kernel(DevImage im, DevState st, long long done /* steps simulated
     if (threadIdx.x < eg.n_acc / WAVE) s_chunk_core[threadIdx.x] = (uint8_t) (im.ev_chunk_core[(eg.slot0 >> 6) + threadIdx.x] - eg.core0);
     __syncthreads();
     const uint32_t tile0 = seg * im.ev_seg_tiles, tile1 = min(tile0 + im.ev_seg_tiles, im.ev_tiles);
-    // this group's table entries: every msn-th (the host picks the table by the step's activity)
-    const unsigned long long *mgroup = sparse ? im.ev_meta_n + g : im.ev_meta + (size_t) g * im.n_global_slots;
-    const uint32_t msn = sparse ? im.ev_groups : 1u;
+    // this group's table entries: every msn-th (the host picks the table, i.e. the instantiation, by the step's activity)
+    const unsigned long long *mgroup = SPARSE ? im.ev_meta_n + g : im.ev_meta + (size_t) g * im.n_global_slots;
+    const uint32_t msn = SPARSE ? im.ev_groups : 1u;
     uint16_t *list = s_list[wave];
     const uint32_t j = lane / LPB, q = lane % LPB; // this lane: neuron j of the batch, unit q (+ LPB, ...) of its block
     uint32_t msg_cnt[(16 + LPB - 1) / LPB];        // messages to core q, q + LPB, ... of the group, over this lane's neurons
