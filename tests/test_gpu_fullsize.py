@@ -103,14 +103,23 @@ def test_c3_full_size_properties(S, monkeypatch, cores, npc):
         # device falls back on when few neurons fire), against the same numpy replay and the streaming run above
         assert lay["sub_accumulators"] and lay["n_bitmap_slices"] == info["n_slices"] and lay["event_layout"] is not None
         monkeypatch.setenv("SANAFE_EVENT", "2")
-        chip_e, tot_e, recs_e, fired_e, v_e, vlog_e = _run(S, arch, net, replay.sample)
-        assert chip_e.device_layout()["pushed_steps"] == STEPS
-        replay.check(fired_e, vlog_e)
-        assert np.array_equal(fired, fired_e) and np.array_equal(v, v_e)
-        for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
-            assert np.array_equal(recs[k], recs_e[k]), k
-        for k in ("total_energy", "synapse_energy", "soma_energy", "network_energy", "sim_time"):
-            assert np.allclose(recs[k], recs_e[k], rtol=1e-12, atol=0), k
+        # ... through both copies of the block table: the group-major one is what the line of record's steps read (34 % of
+        # the neurons fire), the neuron-major one what quiet steps read; forced modes take the latter unless told otherwise
+        for table in ("group", "neuron"):
+            if table == "group":
+                monkeypatch.setenv("SANAFE_EVENT_SPARSE_EVENTS", "0")
+            else:
+                monkeypatch.delenv("SANAFE_EVENT_SPARSE_EVENTS")
+            chip_e, tot_e, recs_e, fired_e, v_e, vlog_e = _run(S, arch, net, replay.sample)
+            lay_e = chip_e.device_layout()
+            assert lay_e["pushed_steps"] == STEPS and lay_e["event_layout"]["sparse_steps"] == (0 if table == "group" else STEPS), lay_e
+            replay.check(fired_e, vlog_e)
+            assert np.array_equal(fired, fired_e) and np.array_equal(v, v_e)
+            for k in ("spikes", "packets_sent", "neurons_updated", "neurons_fired", "total_hops"):
+                assert np.array_equal(recs[k], recs_e[k]), (table, k)
+            for k in ("total_energy", "synapse_energy", "soma_energy", "network_energy", "sim_time"):
+                assert np.allclose(recs[k], recs_e[k], rtol=1e-12, atol=0), (table, k)
+            del chip_e
         return
     # the same image through the other delivery code paths -- dictionary words with fp64 accumulators (format 6), 4-byte
     # int8 words streamed (format 0), 12-bit weight words gathered (format 1): identical results
