@@ -128,6 +128,7 @@ def lib():
     L.sanafe_chip_read_totals.argtypes = [C.c_void_p, C.POINTER(Totals)]
     L.sanafe_chip_perf_columns.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.sanafe_chip_perf_columns.restype = C.c_int64
+    L.sanafe_chip_wants_perf_columns.argtypes = [C.c_void_p]
     L.sanafe_chip_get_step_optional.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
     L.sanafe_chip_set_state_log.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p]
     L.sanafe_chip_get_step_state.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]
@@ -272,6 +273,8 @@ class SpikingChip(_Base):
 
     def perf_columns(self):
         """Names of the optional perf-trace columns (tiles / cores / units with log_energy / log_latency)."""
+        if self._n_ranks > 1 and self._L.sanafe_chip_wants_perf_columns(self._h):
+            self.attach_whole()  # a rank only knows that columns are wanted: the whole-chip twin holds their plan
         n = self._L.sanafe_chip_perf_columns(self._h, None, 0)
         if n <= 0:
             return []

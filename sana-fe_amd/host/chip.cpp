@@ -1548,6 +1548,10 @@ extern "C" int sanafe_chip_sim(sanafe_chip *chip, int64_t timesteps, int timing_
     chip->rec_count = 0;
     const bool host_units = !chip->mc.host_neurons.empty() || chip->hcores != nullptr;
     const bool want_messages = (record & SANAFE_RECORD_MESSAGES) != 0;
+    if (chip->mc.msg_on_device && host_units && (timing_model != SANAFE_TIMING_SIMPLE || want_messages || ((record & SANAFE_RECORD_STEPS) && chip->mc.log.any)))
+        return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a chip with plugin soma units AND cores whose soma is part of the message pipeline "
+                                                "is simulated under the simple timing model, without message traces or optional perf columns "
+                                                "(the per-message fired counts are logged by batched runs only)");
     if (chip->mc.msg_on_device && (timing_model != SANAFE_TIMING_SIMPLE || want_messages) && (chip->n_ranks > 1 || chip->xc.kind != sanafe_amd::Exchange::None))
         return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: detailed timing and message traces of a chip with cores whose soma is part of "
                                                 "the message pipeline need a single-rank chip");
