@@ -542,6 +542,10 @@ def map_only(arch, net, n_ranks=1, rank=0, ext_steps=0):
                 out[n] = np.ctypeslib.as_array(v, shape=(counts[n],)).copy() if counts[n] else np.zeros(0)
             elif n == "soma_classes":
                 out[n] = [{f: getattr(v[i], f) for f, _ in SomaClass._fields_} for i in range(im.n_soma_classes)]
+            elif n == "msg_costs":
+                # sanafe_hip_msg_core_costs: axon_in_latency, synapse e / l, dendrite e / l, soma_energy[3], soma_latency[3]
+                out[n] = (np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), shape=(int(im.n_msg_cores), 11)).copy()
+                          if im.n_msg_cores else np.zeros((0, 11)))
             elif n == "cost_classes":
                 out[n] = [dict(soma_energy=list(v[i].soma_energy), soma_latency=list(v[i].soma_latency),
                                dendrite_energy=v[i].dendrite_energy, dendrite_latency=v[i].dendrite_latency)

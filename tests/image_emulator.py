@@ -55,6 +55,9 @@ class ImageEmulator:
         status = np.zeros(n, dtype=np.uint8)
         has_in = np.where((self.inkind == 1) | (self.inkind == 2), True, self.valid[rs])  # kinds 0 and 4 read the buffer
         cur = np.where(self.inkind == 1, 0.0, np.where(self.valid[rs], self.ring[rs], 0.0))
+        none = self.inkind == 6  # SANAFE_IN_NONE: the soma of a message-pipeline core, called without an input by the neuron loop
+        has_in = np.where(none, False, has_in)
+        cur = np.where(none, 0.0, cur)
         cur = np.where(self.inkind == 2, np.where(self.last_set, 0.0 + self.last_w, 0.0), cur)
         self.last_set[:] = False
         gated = self.inkind == 3
@@ -145,8 +148,12 @@ class ImageEmulator:
             if period > 0 and t % period == 0:
                 send = True
             status[g] = 3 if send else 1
+        # SANAFE_SOMA_PERSIST (buffer before axon_out): the neuron pipeline holds no unit -- the status the message pipeline
+        # left persists (and is what axon_out sends spikes for); not a soma call of the neuron loop
+        persist = self.model == 5
+        status[persist] = self.status[persist]
         self.status = status
-        live = self.model != 0
+        live = (self.model != 0) & ~persist
         cc = im["cost_classes"]
         se = np.array([c["soma_energy"] for c in cc])[self.ccls]
         sl = np.array([c["soma_latency"] for c in cc])[self.ccls]
@@ -156,7 +163,7 @@ class ImageEmulator:
         ar = np.arange(n)
         fired = status == 3
         tot = dict(timesteps=1, spikes=int(im["slot_events"][fired].sum()), packets_sent=int(im["slot_packets"][fired].sum()),
-                   neurons_updated=int((status >= 2).sum()), neurons_fired=int(fired.sum()),
+                   neurons_updated=int(((status >= 2) & live).sum()), neurons_fired=int((fired & live).sum()),
                    total_hops=int(im["slot_hops"][fired].sum()))
         tot["soma_energy"] = float(se[ar, idx][live].sum())
         tot["dendrite_energy"] = float(de[live].sum() + im["slot_e_dend"][fired].sum())
@@ -233,6 +240,56 @@ class ImageEmulator:
                 ws = (t + 1) % self.R
                 self.ring[ws][g] = self.tap_v[i][0]
                 self.valid[ws][g] = True
+        # ---- msgsoma_kernel: cores whose soma is part of the message pipeline -- one TrueNorth update per synaptic event, in
+        #      delivery order, with the running sum of the step's currents (AccumulatorModel::update) ----
+        sc = im["soma_classes"]
+        for k in range(int(im.get("n_msg_cores", 0))):
+            core = int(im["msg_core"][k])
+            nb = int(im["core_nbase"][core])
+            costs = im["msg_costs"][k]
+            ain_l, syn_e, syn_l, dend_e, dend_l = costs[0:5]
+            se, sl = costs[5:8], costs[8:11]
+            acc, events, fired_updates, msgs = {}, 0, 0, 0
+            q = int(im["msg_syn_beg"][k])
+            for a in range(int(im["msg_ax_beg"][k]), int(im["msg_ax_beg"][k + 1])):
+                nsyn = int(im["msg_ax_nsyn"][a])
+                if not fired_global[im["msg_ax_pre"][a]]:
+                    q += nsyn
+                    continue
+                msgs += 1
+                for j in range(q, q + nsyn):
+                    g = nb + int(im["msg_syn_post"][j])
+                    p = sc[min(int(self.pcls[g]), len(sc) - 1)]
+                    acc[g] = acc.get(g, 0.0) + im["msg_syn_weight"][j]
+                    v = self.v[g]
+                    if p["leak_towards_zero"]:
+                        v = v - p["leak_decay"] if v > 0 else (v + p["leak_decay"] if v < 0 else v)
+                    else:
+                        v = v + p["leak_decay"]
+                    v = v + im["slot_bias"][g]
+                    v = v + acc[g]
+                    st = 2
+                    if v >= p["threshold"]:
+                        v = p["reset"] if p["reset_mode"] == 2 else (v - p["threshold"] if p["reset_mode"] == 1 else
+                                                                     (p["threshold"] if p["reset_mode"] == 3 else v))
+                        st = 3
+                    elif v <= p["reverse_threshold"]:
+                        rr = p["reverse_reset_mode"]
+                        v = p["reverse_reset"] if rr == 2 else (v + p["reverse_threshold"] if rr == 1 else
+                                                                (p["reverse_threshold"] if rr == 3 else v))
+                    self.v[g] = v
+                    self.status[g] = st
+                    events += 1
+                    fired_updates += st == 3
+                q += nsyn
+            tot["synapse_energy"] += events * syn_e
+            tot["dendrite_energy"] += events * dend_e
+            soma = events * (se[0] + se[1]) + fired_updates * se[2]
+            tot["soma_energy"] += soma
+            tot["total_energy"] += events * syn_e + events * dend_e + soma
+            tot["neurons_updated"] += events
+            tot["neurons_fired"] += int(fired_updates)
+            proc[core] = msgs * ain_l + events * ((syn_l + dend_l) + (sl[0] + sl[1])) + fired_updates * sl[2]
         tot["sim_time"] = float(max(proc.max(), gen.max()) + im["sync_delay"])
         self.t = t
         return tot

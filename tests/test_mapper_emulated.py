@@ -131,6 +131,19 @@ def test_unsupported_configs_fail_loudly(S):
         S.map_only(arch, net, n_ranks=2, rank=0)
 
 
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_message_pipeline_somas(S, position):
+    """Row a5 without a GPU: cores with the buffer inside the soma unit / before axon_out and built-in units lower to the
+    image's msg_* tables (inbound axons and synapses in delivery order, the units' default costs) and SANAFE_IN_NONE /
+    SANAFE_SOMA_PERSIST neurons; the emulation of msgsoma_kernel -- one TrueNorth update per synaptic event with the
+    running sum of the step's currents -- must reproduce the oracle: statuses at the end of every step, potentials,
+    counters, energies and the simple timing model's step time."""
+    arch, net = nets.host_cores(S, position=position)
+    im, _ = S.map_only(arch, net)
+    assert im["n_msg_cores"] == 2 and len(im["msg_ax_pre"]) > 50
+    compare(S, arch, net, steps=40)
+
+
 def test_log_flags_map_on_every_rank_and_on_message_pipeline_cores(S):
     """log_energy / log_latency flags (optional perf columns) no longer keep a chip off the sharded path or its
     message-pipeline somas off the device: a rank only notes that columns are wanted (the whole-chip twin computes them), and
