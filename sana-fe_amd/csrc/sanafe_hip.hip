@@ -1,7 +1,7 @@
 // sanafe_hip.hip -- SANA-FE's per-timestep simulation loop for MI355X (gfx950, CDNA4).
 //
 // Implements the C ABI of include/sanafe_hip.h.  Two launches per timestep (one on push-only chips), all on one
-// HIP stream, no host round trip between steps:
+// HIP stream, no host round trip between steps (the host reads the published event counts from pinned memory):
 //
 //   K1 neuron_kernel   one 256-thread workgroup per up to four 64-slot chunks of a simulated core, one wavefront per
 //                      chunk; SoA neuron state, coalesced 8-byte loads; soma update (LIF / TrueNorth / input, incl.
@@ -21,8 +21,16 @@
 //                      in order, and says itself whether its axon spiked) or gathered (few spikes).
 //                      Reference: process_messages / process_message, src/chip.cpp:656-764;
 //                      AccumulatorModel / AccumulatorWithDelayModel src/models.cpp:71-131.
+//   K2e event_deliver_kernel   steps in which few neurons fire (up to ~58 % on C3): a second, source-neuron-major copy of
+//                      the 2-byte words; a workgroup owns the LDS accumulators of one group of destination cores and one
+//                      segment of the source space, lists the neurons that fired and adds only their blocks -- work in
+//                      proportion to the step's synaptic events, like the reference's loop.  The host picks the kernel (and
+//                      which copy of the block table it reads) per step from the event counts the device publishes.
 //   K2o ordered_deliver_kernel   chips with non-integer weights: one lane per accumulator folds the accumulator's own
 //                      synapse list in the reference's delivery order (bit-equal fp64 sums, no atomics).
+//   K2m msgsoma_kernel  cores whose SOMA is part of the message pipeline (buffer inside the soma unit / before axon_out):
+//                      one lane per post-synaptic neuron walks its inbound synapses in delivery order and updates the
+//                      TrueNorth soma once per synaptic event (src/mapped.cpp:27-58, src/chip.cpp:738-789).
 //   K3 reduce_l1 / l2  fixed-order, two-level reduction of the per-wavefront partials and the slices' processing
 //                      delays into the timestep totals, simple timing model, run totals, t += 1.  Rides in the
 //                      leading workgroups of the NEXT two neuron launches; reduce_kernel flushes the last steps.
