@@ -237,6 +237,7 @@ struct sanafe_chip
     std::vector<uint32_t> dirty_slots;
     bool classes_dirty{false};
     bool inputs_dirty{false};
+    int64_t ext_hook_steps{0};         // rows drawn through sanafe_chip_generate_ext (the host-side test hook) instead of sim()
     bool structure_dirty{false};       // a value-stream column came or went (Poisson rate / random_mask set after load()): rebuild_device()
     std::vector<uint8_t> input_rewind; // per input: its train was replaced since the last commit
     static std::string class_key(const sanafe_hip_soma_class &c) { return std::string(reinterpret_cast<const char *>(&c), sizeof(c)); }
@@ -354,7 +355,7 @@ struct sanafe_chip
                 col.poisson = num;
                 col.seed = mc.in_seed[a];
                 col.unit_key = mc.in_unit_key[a];
-                col.skip_updates = total_timesteps;
+                col.skip_updates = total_timesteps + ext_hook_steps;
                 change_ext_column(ls, &col);
             }
         }
@@ -1078,7 +1079,22 @@ extern "C" int sanafe_chip_create(const sanafe_desc *desc, int device, int n_ran
 // stay where they are (ExtStreams::carry_from); a new Poisson generator skips the draws its unit has made so far.
 int sanafe_chip::rebuild_device()
 {
-    if (!dev) return fail(SANAFE_HIP_ERR_NO_DEVICE, "the chip has no device (mapped only)");
+    if (!dev) // mapped only (host-side checks): the value streams follow the new columns, there is nothing else to re-create
+    {
+        try
+        {
+            ExtStreams streams;
+            streams.init(mc);
+            streams.carry_from(ext);
+            ext = std::move(streams);
+        }
+        catch (const std::exception &e)
+        {
+            return fail(SANAFE_HIP_ERR_INVALID, e.what());
+        }
+        structure_dirty = false;
+        return 0;
+    }
     if (n_ranks != 1 || xc.kind != sanafe_amd::Exchange::None || !mc.host_neurons.empty() || hcores || !mc.tap_slot.empty())
         return fail(SANAFE_HIP_ERR_UNSUPPORTED, "UnsupportedError: a Poisson rate / random_mask that comes or goes after load() needs a single-rank "
                                                 "chip without plugin / host-side units or `taps` dendrites");
@@ -2050,7 +2066,10 @@ extern "C" int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, in
 extern "C" int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out)
 {
     if (!chip || steps < 0 || (steps > 0 && !out && !chip->mc.ext.empty())) return fail(SANAFE_HIP_ERR_INVALID, "bad arguments");
+    if (chip->structure_dirty)
+        if (int rc = chip->rebuild_device()) return rc;
     const size_t n = chip->mc.ext.size();
+    chip->ext_hook_steps += steps; // (the units' update count, for columns that arrive later: see set_input_attribute)
     try
     {
         for (int64_t s = 0; s < steps && n > 0; s++) chip->ext.fill_row(out + static_cast<size_t>(s) * n);
@@ -2260,7 +2279,9 @@ extern "C" int sanafe_chip_set_bias(sanafe_chip *chip, int64_t count, const int6
 extern "C" int sanafe_chip_set_attribute(sanafe_chip *chip, int64_t neuron, const char *key, int type, double num, const char *str)
 {
     if (!chip || !key) return fail(SANAFE_HIP_ERR_INVALID, "null argument");
-    if (!chip->dev) return fail(SANAFE_HIP_ERR_INVALID, "the chip has no device (mapped only)");
+    // (mapped-only chips take the attributes that only touch the host's value streams: the host-side checks of those)
+    if (!chip->dev && std::strcmp(key, "poisson") != 0 && std::strcmp(key, "random_mask") != 0)
+        return fail(SANAFE_HIP_ERR_INVALID, "the chip has no device (mapped only)");
     if (neuron < 0 || neuron >= chip->n_neurons) return fail(SANAFE_HIP_ERR_INVALID, "neuron id out of range");
     MappedChip &mc = chip->mc;
     const uint32_t s = mc.slot_of_gid[neuron];
