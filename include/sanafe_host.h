@@ -97,6 +97,10 @@ int sanafe_chip_generate_ext(sanafe_chip *chip, int64_t steps, int32_t *out);
  * NeuronStatus byte per local slot of a single-rank chip, device or mapped-only) and schedules them `reps` times. */
 int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, int reps, double *sim_time, int64_t *n_messages,
         double *build_seconds, double *schedule_seconds);
+/* The same for a chip whose message-pipeline somas run on the device (sanafe_hip_image::msg_*): `status` is what the NEURON LOOP
+ * left (the step's status log), `msg_fired` per message into such a core how many of its synaptic events made the soma fire
+ * (sanafe_hip_read_step_msg_fired) -- the message's processing delay depends on it (src/chip.cpp:738-789). */
+int sanafe_test_schedule_msg(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, double *sim_time, int64_t *n_messages);
 /* Self-check hook: the first n values of the host's restatement of glibc rand() for `seed`. */
 void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out);
 int sanafe_chip_reset(sanafe_chip *chip);

@@ -2030,7 +2030,20 @@ extern "C" void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out)
 // Test / profiling hook: rebuilds the messages of one timestep from `status` (one NeuronStatus byte per local slot)
 // and runs the detailed NoC schedule `reps` times on the calling thread -- no device involved, so the host-side cost
 // per message can be measured on any machine.  Returns sim_time of the step and the number of messages.
+static int test_schedule(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, int reps, double *sim_time, int64_t *n_messages,
+        double *build_seconds, double *schedule_seconds);
 extern "C" int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, int reps, double *sim_time, int64_t *n_messages,
+        double *build_seconds, double *schedule_seconds)
+{
+    return test_schedule(chip, status, nullptr, reps, sim_time, n_messages, build_seconds, schedule_seconds);
+}
+// ... for chips with message-pipeline cores on the device: `msg_fired` = per message into such a core (sanafe_hip_image::msg_ax_*
+// order) how many of its synaptic events made the soma fire -- what sanafe_hip_read_step_msg_fired returns for a recorded step.
+extern "C" int sanafe_test_schedule_msg(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, double *sim_time, int64_t *n_messages)
+{
+    return test_schedule(chip, status, msg_fired, 1, sim_time, n_messages, nullptr, nullptr);
+}
+static int test_schedule(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, int reps, double *sim_time, int64_t *n_messages,
         double *build_seconds, double *schedule_seconds)
 {
     if (!chip || !status || chip->mc.out_ptr.empty()) return fail(SANAFE_HIP_ERR_INVALID, "needs a single-rank chip and a status array");
@@ -2043,7 +2056,7 @@ extern "C" int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, in
         for (int r = 0; r < reps; r++)
         {
             const auto t0 = std::chrono::steady_clock::now();
-            chip->build_messages(1, st, scratch.per_core, 0);
+            chip->build_messages(1, st, scratch.per_core, 0, msg_fired);
             const auto t1 = std::chrono::steady_clock::now();
             last = chip->schedule_detailed(scratch.per_core, false, scratch);
             const auto t2 = std::chrono::steady_clock::now();

@@ -153,6 +153,7 @@ class ImageEmulator:
         persist = self.model == 5
         status[persist] = self.status[persist]
         self.status = status
+        self.loop_status = status.copy()  # what the step's status log holds: the statuses the neuron loop left
         live = (self.model != 0) & ~persist
         cc = im["cost_classes"]
         se = np.array([c["soma_energy"] for c in cc])[self.ccls]
@@ -250,6 +251,8 @@ class ImageEmulator:
             ain_l, syn_e, syn_l, dend_e, dend_l = costs[0:5]
             se, sl = costs[5:8], costs[8:11]
             acc, events, fired_updates, msgs = {}, 0, 0, 0
+            if k == 0:
+                self.msg_fired = np.zeros(len(im["msg_ax_pre"]), dtype=np.uint16)  # per message: updates that fired
             q = int(im["msg_syn_beg"][k])
             for a in range(int(im["msg_ax_beg"][k]), int(im["msg_ax_beg"][k + 1])):
                 nsyn = int(im["msg_ax_nsyn"][a])
@@ -281,6 +284,7 @@ class ImageEmulator:
                     self.status[g] = st
                     events += 1
                     fired_updates += st == 3
+                    self.msg_fired[a] += st == 3
                 q += nsyn
             tot["synapse_energy"] += events * syn_e
             tot["dendrite_energy"] += events * dend_e

@@ -144,6 +144,39 @@ def test_message_pipeline_somas(S, position):
     compare(S, arch, net, steps=40)
 
 
+@pytest.mark.parametrize("position", ["soma_inside", "axon_out"])
+def test_message_pipeline_somas_detailed_timing_on_the_host(S, position):
+    """`detailed` timing of such a chip is host work on two device logs: the statuses the neuron loop left and, per message
+    into a message-pipeline core, how many of its synaptic events made the soma fire (the message's processing delay
+    depends on it, src/chip.cpp:738-789).  With both taken from the emulation, the host's message reconstruction (the
+    mapper's out tables incl. the axons of those cores) and NoC schedule must give the oracle's simulated time and message
+    count, step by step -- no GPU involved."""
+    import ctypes as C
+    arch, net = nets.host_cores(S, position=position, seed=5)
+    im, _ = S.map_only(arch, net)
+    emu = ImageEmulator(im)
+    orc = OracleChip(S.to_desc(arch, net))
+    chip = S.SpikingChip(arch, device=-1)
+    chip.load(net)
+    L = S.chip.lib()
+    L.sanafe_test_schedule_msg.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    into_msg_cores = 0
+    for t in range(30):
+        emu.step()
+        b = orc.step("detailed")
+        status = np.ascontiguousarray(emu.loop_status, dtype=np.uint8)
+        fired = np.ascontiguousarray(emu.msg_fired, dtype=np.uint16)
+        sim_time, n = C.c_double(), C.c_int64()
+        assert L.sanafe_test_schedule_msg(chip._h, status.ctypes.data, fired.ctypes.data, C.byref(sim_time), C.byref(n)) == 0, \
+            L.sanafe_last_error()
+        assert sim_time.value == pytest.approx(b["sim_time"], rel=1e-9), t
+        msgs = orc.messages()
+        assert n.value == len(msgs), t
+        live = msgs[msgs["placeholder"] == 0]
+        into_msg_cores += int(np.isin(live["dest_core_id"], [2, 4]).sum())
+    assert into_msg_cores > 50
+
+
 def test_log_flags_map_on_every_rank_and_on_message_pipeline_cores(S):
     """log_energy / log_latency flags (optional perf columns) no longer keep a chip off the sharded path or its
     message-pipeline somas off the device: a rank only notes that columns are wanted (the whole-chip twin computes them), and
