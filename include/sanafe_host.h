@@ -101,6 +101,8 @@ int sanafe_test_schedule(sanafe_chip *chip, const uint8_t *status, int reps, dou
  * left (the step's status log), `msg_fired` per message into such a core how many of its synaptic events made the soma fire
  * (sanafe_hip_read_step_msg_fired) -- the message's processing delay depends on it (src/chip.cpp:738-789). */
 int sanafe_test_schedule_msg(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, double *sim_time, int64_t *n_messages);
+/* Test hook: the optional perf columns (sanafe_chip_perf_columns) of one timestep from the same two logs. */
+int sanafe_test_optional_columns(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, double *out);
 /* Self-check hook: the first n values of the host's restatement of glibc rand() for `seed`. */
 void sanafe_test_glibc_rand(uint32_t seed, int64_t n, uint32_t *out);
 int sanafe_chip_reset(sanafe_chip *chip);

@@ -2043,6 +2043,24 @@ extern "C" int sanafe_test_schedule_msg(sanafe_chip *chip, const uint8_t *status
 {
     return test_schedule(chip, status, msg_fired, 1, sim_time, n_messages, nullptr, nullptr);
 }
+// Test hook: the optional perf columns of one timestep (sim_trace_get_optional_traces, src/chip.cpp:1541-1579) from the statuses
+// the neuron loop left and, on chips with message-pipeline cores on the device, the fired counts per message -- what a
+// recorded sim() computes from the device's step logs.  out: sanafe_chip_perf_columns() values.
+extern "C" int sanafe_test_optional_columns(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, double *out)
+{
+    if (!chip || !status || !out || chip->mc.out_ptr.empty() || !chip->mc.log.any)
+        return fail(SANAFE_HIP_ERR_INVALID, "needs a single-rank chip with log flags, a status array and an output array");
+    try
+    {
+        const std::vector<double> cols = chip->optional_columns(status, msg_fired);
+        std::copy(cols.begin(), cols.end(), out);
+    }
+    catch (const std::exception &e)
+    {
+        return fail(SANAFE_HIP_ERR_INVALID, e.what());
+    }
+    return 0;
+}
 static int test_schedule(sanafe_chip *chip, const uint8_t *status, const uint16_t *msg_fired, int reps, double *sim_time, int64_t *n_messages,
         double *build_seconds, double *schedule_seconds)
 {

@@ -177,6 +177,59 @@ def test_message_pipeline_somas_detailed_timing_on_the_host(S, position):
     assert into_msg_cores > 50
 
 
+def _flag_everything(S, arch, tiles, cores):
+    for t in tiles:
+        arch.tiles[t].log_energy = True
+    all_cores = arch.cores()
+    for c in cores:
+        all_cores[c].log_energy = True
+    seen = set()
+    for core in all_cores:
+        for u in core.units:
+            if id(u) not in seen:
+                seen.add(id(u))
+                u.log_energy = True
+                u.log_latency = bool(u.implements & S.description.IMPL_SOMA)
+
+
+@pytest.mark.parametrize("which", ["loihi", "soma_inside", "axon_out"])
+def test_optional_perf_columns_on_the_host(S, which):
+    """The optional perf columns (tiles / cores / units with log_energy / log_latency; sim_trace_get_optional_traces,
+    src/chip.cpp:1541-1579) are host sums over the device's step logs: with the logs taken from the emulation they must
+    equal the oracle's, on an ordinary chip and on chips whose message-pipeline somas run on the device (their units are
+    charged per synaptic event from the fired counts per message) -- no GPU involved."""
+    import ctypes as C
+    if which == "loihi":
+        arch, net = nets.random_loihi(S, n_tiles=4, neurons_per_core=40, out_degree=12, arch_kind="loihi", seed=7)
+        _flag_everything(S, arch, tiles=(1,), cores=(2, 5))
+    else:
+        arch, net = nets.host_cores(S, position=which, seed=7)
+        _flag_everything(S, arch, tiles=(2,), cores=(2, 3))
+    im, _ = S.map_only(arch, net)
+    emu = ImageEmulator(im)
+    orc = OracleChip(S.to_desc(arch, net))
+    chip = S.SpikingChip(arch, device=-1)
+    chip.load(net)
+    names = chip.perf_columns()
+    assert len(names) > 4
+    L = S.chip.lib()
+    L.sanafe_test_optional_columns.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    nonzero = 0
+    for t in range(20):
+        emu.step()
+        orc.step("simple")
+        want = orc.optional_traces()
+        assert sorted(want) == names
+        status = np.ascontiguousarray(emu.loop_status, dtype=np.uint8)
+        fired = np.ascontiguousarray(getattr(emu, "msg_fired", np.zeros(1)), dtype=np.uint16)
+        out = np.zeros(len(names))
+        assert L.sanafe_test_optional_columns(chip._h, status.ctypes.data, fired.ctypes.data, out.ctypes.data) == 0, L.sanafe_last_error()
+        for k, n in enumerate(names):
+            assert out[k] == pytest.approx(want[n], rel=1e-12, abs=1e-30), (t, n)
+            nonzero += want[n] != 0.0
+    assert nonzero > 40
+
+
 def test_log_flags_map_on_every_rank_and_on_message_pipeline_cores(S):
     """log_energy / log_latency flags (optional perf columns) no longer keep a chip off the sharded path or its
     message-pipeline somas off the device: a rank only notes that columns are wanted (the whole-chip twin computes them), and
